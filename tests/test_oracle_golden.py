@@ -1,0 +1,191 @@
+"""Pins the CPU oracle (oracle/segvlad_oracle.py) against golden vectors captured from the
+reference's own function bodies (tools/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import segvlad_oracle as O
+from revisit_anything_amd import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def L(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_pixel_map():
+    z = L("pixel_map.npz")
+    for key in z.files:
+        _, H, W = key.split("_")
+        _, ind = O.pixel_to_token_index(int(H), int(W))
+        assert np.array_equal(ind, z[key])
+
+
+@pytest.mark.parametrize("name", ["same", "x2", "x2clip", "nonint", "down"])
+def test_incidence_cases(name):
+    z = L("incidence_cases.npz")
+    S, Hm, Wm, H, W = z[f"{name}_shape"]
+    m = np.unpackbits(z[f"{name}_masks"], axis=1)[:, :Hm * Wm].reshape(S, Hm, Wm).astype(bool)
+    inc = O.incidence(m, int(H), int(W))
+    assert np.array_equal(inc, z[f"{name}_inc"])
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 4, 6, 12, 50])
+def test_adjacency_cases(S):
+    z = L("adjacency_cases.npz")
+    m = np.unpackbits(z[f"S{S}_masks"], axis=1)[:, :60 * 80].reshape(S, 60, 80).astype(bool)
+    m2 = synth.make_masks(S, 60, 80, seed=300 + S, hmin=3, hmax=20, wmin=3, wmax=25)
+    assert np.array_equal(m, m2)  # synth generators are seed-stable
+    for order in (1, 2, 3):
+        A = O.nbr_masks_agg_fast_single([x for x in m], order)
+        assert np.array_equal(A, z[f"S{S}_o{order}"]), (S, order)
+
+
+def test_adjacency_known_answers():
+    # SURVEY App. B known answers
+    A = O.adjacency_from_centroids(np.array([[2., 2.], [10., 10.], [2., 20.]]), 2)
+    assert np.array_equal(A, np.array([[1, 1, 0]] * 3, dtype=bool))
+    c = np.array([[2., 2.], [10., 10.], [2., 20.], [18., 28.]])
+    assert np.array_equal(O.adjacency_from_centroids(c, 1),
+                          np.array([[1, 1, 1, 0], [1, 1, 1, 1], [1, 1, 1, 1], [0, 1, 1, 1]], dtype=bool))
+    assert O.adjacency_from_centroids(c, 2).all()
+    assert np.array_equal(O.adjacency_from_centroids(np.array([[1., 1.]]), 3), np.array([[True]]))
+
+
+def test_vlad_tiny():
+    z = L("vlad_tiny.npz")
+    D, K, H, W, S = (int(z[k]) for k in "DKHWS")
+    C = synth.make_vocab(K, D, seed=1001)
+    tok = synth.make_tokens(C, (H // 14) * (W // 14), seed=2001, noise=0.3)
+    masks = z["masks"]
+    inc = O.incidence(masks, H, W)
+    assert np.array_equal(inc, z["inc"])
+    for order in (0, 1, 3):
+        adj = None if order == 0 else z[f"adj_o{order}"]
+        if order:
+            assert np.array_equal(O.nbr_masks_agg_fast_single([m for m in masks], order), adj)
+        out, aux = O.seg_vlad(tok, inc, C, adj, return_aux=True)
+        assert np.array_equal(aux["labels"], z["labels"])
+        assert np.abs(out - z[f"vlad_o{order}"]).max() < 1e-7
+
+
+def test_vlad_ref_shape():
+    z = L("vlad_ref_shape.npz")
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    tok = synth.make_tokens(voc, 34 * 45, seed=2002)
+    masks = synth.make_masks(50, 240, 320, seed=2102)
+    inc = O.incidence(masks, 480, 640)
+    assert np.array_equal(np.packbits(inc, axis=1), z["inc"])
+    adj = O.nbr_masks_agg_fast_single([m for m in masks], 3)
+    assert np.array_equal(adj, z["adj"])
+    out, aux = O.seg_vlad(tok, inc, voc, adj, return_aux=True)
+    assert np.array_equal(aux["labels"].astype(np.uint8), z["labels"])
+    assert np.abs(out[:, ::61] - z["sub"]).max() < 1e-8
+    assert np.abs(out[:, :256] - z["head"]).max() < 1e-8
+    assert np.abs(out[:, -256:] - z["tail"]).max() < 1e-8
+    Gm = np.random.Generator(np.random.PCG64(777)).standard_normal((32 * 1536, 16))
+    assert np.abs(out @ Gm - z["proj"]).max() < 1e-6
+
+
+def test_vlad_ref_shape_adversarial_labels():
+    """Isotropic tokens: near-tied assignments.  Labels must agree wherever the fp64 top-2 gap
+    exceeds fp32 GEMM rounding; the descriptor must still agree where labels agree everywhere."""
+    z = L("vlad_ref_shape_adv.npz")
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    tok = synth.make_tokens(voc, 34 * 45, seed=2003, adversarial=True)
+    xn = O.normalize_tokens_f32(tok)
+    labels, gap = O.assign_labels(xn, voc)
+    ok = gap > 1e-6
+    assert ok.mean() > 0.99
+    assert np.array_equal(labels[ok].astype(np.uint8), z["labels"][ok])
+    if np.array_equal(labels.astype(np.uint8), z["labels"]):
+        masks = synth.make_masks(50, 240, 320, seed=2102)
+        out = O.seg_vlad(tok, O.incidence(masks, 480, 640), voc, None)
+        assert np.abs(out[:, ::61] - z["sub"]).max() < 1e-8
+
+
+def test_vlad_k64_parametric():
+    z = L("vlad_k64.npz")
+    D, K, S, N = (int(z[k]) for k in ("D", "K", "S", "N"))
+    C = synth.make_vocab(K, D, seed=1003)
+    tok = synth.make_tokens(C, N, seed=2004, noise=0.2)
+    out, aux = O.seg_vlad(tok, z["inc"], C, z["adj"], return_aux=True)
+    assert np.array_equal(aux["labels"], z["labels"])
+    assert np.abs(out - z["vlad"]).max() < 1e-7
+    out0 = O.seg_vlad(tok, z["inc"], C, None)
+    assert np.all(out0[3] == 0)  # without the neighbour union a segment with no tokens stays all-zero
+
+
+def test_vote_cases():
+    z = L("vote_cases.npz")
+    off = z["off"]
+    segRange = [np.arange(off[i], off[i + 1]) for i in range(len(off) - 1)]
+    for n in (1, 5):
+        p = O.get_matches_wt_borda_im(z["matches"], len(segRange), z["sims"], segRange, z["imInds"], n=n)
+        exp = z[f"wt_n{n}"]
+        for i, row in enumerate(p):
+            assert list(row) == [x for x in exp[i] if x >= 0]
+    p, counts = O.get_matches_max_seg_topk(z["matches"], len(segRange), segRange, z["imInds"], n=5)
+    exp = z["cnt_n5"]
+    for i, row in enumerate(p):
+        assert list(row) == [x for x in exp[i] if x >= 0]
+    p = O.get_matches_wt_borda_im(z["tie_matches"], 1, z["tie_sims"], [np.arange(2)], z["tie_imInds"], n=4)
+    assert list(p[0]) == list(z["tie_pred"])
+
+
+def test_recall_cases():
+    z = L("recall_cases.npz")
+    gt = [[int(x) for x in row if x >= 0] for row in z["gt"]]
+    r = O.calc_recall([list(p) for p in z["preds"]], gt, 5)
+    assert np.allclose(r, z["recalls"], rtol=0, atol=0)
+
+
+def test_pca_small():
+    z = L("pca_small.npz")
+    Y = O.pca_transform(z["X"], z["mean"], z["components"], z["explained_variance"], whiten=True)
+    assert np.abs(Y - z["Y"]).max() < 1e-6 * np.abs(z["Y"]).max()
+
+
+def test_e2e_small_recall_segloc():
+    z = L("e2e_small.npz")
+    n_img, S, d, n_q = (int(z[k]) for k in ("n_img", "S", "d", "n_q"))
+    R, img = synth.make_planted_db(n_img, S, d, seed=3000)
+    Q, tau, off = synth.make_planted_queries(R, n_img, S, n_q, seed=4000, sigma_q=3.0)
+    gt = [[int(t)] for t in tau]
+    gt[5] = []
+    segRange2 = [np.arange(off[i], off[i + 1]) for i in range(n_q)]
+    sr = np.random.Generator(np.random.PCG64(1)).uniform(0.5, 2.0, size=(R.shape[0], 1))
+    sq = np.random.Generator(np.random.PCG64(2)).uniform(0.5, 2.0, size=(Q.shape[0], 1))
+    recalls, preds, m50, s50 = O.recall_segloc(R.astype(np.float64) * sr, Q.astype(np.float64) * sq, gt, segRange2,
+                                               img.astype(np.int64), pca=True)
+    assert np.array_equal(m50, z["matches_50"])
+    assert np.abs(s50 - z["sims_50"]).max() <= 1e-6
+    for i, p in enumerate(preds):
+        assert list(p) == [x for x in z["preds"][i] if x >= 0]
+    assert np.allclose(recalls, z["recalls"])
+
+
+def test_bit_pack_roundtrip():
+    r = np.random.Generator(np.random.PCG64(5))
+    b = r.random((7, 1530)) < 0.3
+    w = O.pack_bits_u64(b)
+    assert w.shape == (7, 24) and w.dtype == np.dtype("<u8")
+    assert np.array_equal(O.unpack_bits_u64(w, 1530), b)
+    assert (int(w[2, 3]) >> 5) & 1 == int(b[2, 3 * 64 + 5])
+
+
+def test_merge_topk_equals_global():
+    r = np.random.Generator(np.random.PCG64(9))
+    Rm = r.standard_normal((500, 16)).astype(np.float32)
+    Qm = r.standard_normal((20, 16)).astype(np.float32)
+    d2, idx = O.knn_l2(Rm, Qm, 10)
+    parts = [(0, 170), (170, 340), (340, 500)]
+    dp, ip = [], []
+    for a, b in parts:
+        d, i = O.knn_l2(Rm[a:b], Qm, 10)
+        dp.append(d)
+        ip.append(i + a)
+    dm, im = O.merge_topk(dp, ip, 10)
+    assert np.array_equal(im, idx) and np.array_equal(dm, d2)

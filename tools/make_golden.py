@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE's own function bodies.  Runs ONLY in the build
+container (needs /root/reference); the outputs are committed under tests/golden/ as data.
+
+Recipe: ast-parse func_vpr.py / place_rec_main.py, keep only the named
+top-level FunctionDefs, exec them in a namespace that holds numpy/torch/scipy, and reroute the
+hard-coded 'cuda' device strings to 'cpu'.  No reference source is copied anywhere: the functions
+are executed where they lie and only their inputs' seeds + outputs are stored.
+
+Inputs are regenerated from seeds by revisit_anything_amd.synth in the tests, so fixtures hold
+only parameters and expected outputs (plus small masks where needed).
+"""
+import ast
+import os
+import pickle
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.spatial import Delaunay
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from revisit_anything_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def extract(path, names, ns):
+    body = [n for n in ast.parse(open(path).read()).body if isinstance(n, ast.FunctionDef) and n.name in names]
+    # keep the LAST definition of duplicated names (python semantics), error if any is missing
+    assert {n.name for n in body} == set(names), set(names) - {n.name for n in body}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+
+
+def patch_cuda_to_cpu():
+    _to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = ["cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a]
+        k = {kk: ("cpu" if kk == "device" and isinstance(v, str) and v.startswith("cuda") else v) for kk, v in k.items()}
+        return _to(self, *a, **k)
+
+    torch.Tensor.to = to
+    _zeros = torch.zeros
+
+    def zeros(*a, **k):
+        k = {kk: ("cpu" if kk == "device" and isinstance(v, str) and v.startswith("cuda") else v) for kk, v in k.items()}
+        return _zeros(*a, **k)
+
+    torch.zeros = zeros
+
+
+class NumpyIndexFlatL2:
+    """faiss.IndexFlatL2 stand-in (faiss is not installable here): fp32 inputs, exact squared L2
+    evaluated in fp64 and rounded to fp32, ascending, stable (ties -> lower id)."""
+
+    def __init__(self, d):
+        self.d = d
+        self.x = None
+
+    def add(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        self.x = x if self.x is None else np.concatenate([self.x, x])
+
+    def search(self, q, k):
+        q = np.ascontiguousarray(q, dtype=np.float32).astype(np.float64)
+        r = self.x.astype(np.float64)
+        d2 = ((q * q).sum(1)[:, None] + (r * r).sum(1)[None, :] - 2 * q @ r.T).astype(np.float32)
+        o = np.argsort(d2, axis=1, kind="stable")[:, :k]
+        return np.take_along_axis(d2, o, 1), o.astype(np.int64)
+
+
+def load_ref():
+    fv = types.ModuleType("func_vpr")
+    fv.__dict__.update(np=np, torch=torch, F=F, time=time, Delaunay=Delaunay)
+    extract(f"{REF}/func_vpr.py",
+            {"first_k_unique_indices", "weighted_borda_count", "get_matches", "calc_recall", "normalizeFeat",
+             "vlad_single", "vlad_matmuls_per_cluster", "seg_vlad_gpu_single_img", "seg_vlad_gpu_single",
+             "getNbrsDelaunay", "nbrMasksAGGFastSingle", "getIdxSingleFast"}, fv.__dict__)
+    prm = types.ModuleType("place_rec_main")
+    prm.__dict__.update(np=np, torch=torch, func_vpr=fv, os=os, pickle=pickle,
+                        faiss=types.SimpleNamespace(IndexFlatL2=NumpyIndexFlatL2))
+    extract(f"{REF}/place_rec_main.py", {"recall_segloc"}, prm.__dict__)
+    patch_cuda_to_cpu()
+    return fv, prm
+
+
+def ref_ind_matrix(H, W):
+    """place_rec_main.py:187-194 executed literally (the double python loop) for small H, W."""
+    dh, dw = H // 14, W // 14
+    idx_matrix = np.empty((H, W, 2)).astype("int32")
+    for i in range(H):
+        for j in range(W):
+            idx_matrix[i, j] = np.array([np.clip(i // 14, 0, dh - 1), np.clip(j // 14, 0, dw - 1)])
+    ind_matrix = np.ravel_multi_index(idx_matrix.reshape(-1, 2).T, (dh, dw))
+    return idx_matrix, ind_matrix
+
+
+def capture_vlad(fv):
+    """Wrap vlad_matmuls_per_cluster so the internal (masks, labels) of vlad_single are recorded."""
+    rec = {}
+    orig = fv.vlad_matmuls_per_cluster
+
+    def wrapper(num_c, masks, res, clus_labels, adjMat=None, device="cuda"):
+        rec["inc"] = masks.bool().numpy().copy()
+        rec["labels"] = clus_labels.numpy().copy()
+        rec["res"] = res.numpy().copy()
+        return orig(num_c, masks, res, clus_labels, adjMat=adjMat, device="cpu")
+
+    fv.vlad_matmuls_per_cluster = wrapper
+    return rec
+
+
+def run_seg_vlad(fv, rec, tokens_dn, masks, C, H, W, adj, D):
+    dh, dw = H // 14, W // 14
+    idx, ind = ref_ind_matrix(H, W)
+    dino = torch.from_numpy(tokens_dn.reshape(1, D, dh, dw))
+    cfg = {"desired_height": H, "desired_width": W}
+    gd = fv.seg_vlad_gpu_single_img(torch.tensor(ind), idx, dino, "k", [m for m in masks], torch.from_numpy(C), cfg,
+                                    desc_dim=D, adj_mat=None if adj is None else adj)
+    return gd.numpy(), rec["inc"].copy(), rec["labels"].copy()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    fv, prm = load_ref()
+    rec = capture_vlad(fv)
+
+    # ---- shipped vocabularies (data files of the reference) -------------------------------------
+    voc = torch.load(f"{REF}/cache/vocabulary/dinov2_vitg14/l31_value_c32/indoor/c_centers.pt").numpy()
+    np.save(f"{OUT}/vocab_indoor_k32_d1536.npy", voc.astype(np.float32))
+    vnv = [d for d in sorted(os.listdir(f"{REF}/cache/vocabulary/dinov2_vitg14/l31_value_c32")) if "NV" in d][0]
+    vocnv = torch.load(f"{REF}/cache/vocabulary/dinov2_vitg14/l31_value_c32/{vnv}/c_centers.pt").numpy()
+    np.save(f"{OUT}/vocab_nv_k32_d768.npy", vocnv.astype(np.float32))
+    print("vocab", voc.shape, vocnv.shape, vnv)
+
+    # ---- pixel->token map ------------------------------------------------------------------------
+    pm = {}
+    for (H, W) in [(84, 112), (100, 130), (480, 640)]:
+        idx, ind = ref_ind_matrix(H, W)
+        pm[f"ind_{H}_{W}"] = ind.astype(np.int64)
+    np.savez_compressed(f"{OUT}/pixel_map.npz", **pm)
+
+    # ---- vlad_tiny: D=32 K=8 N=6x8 S=6, 2x upsample, orders 0/1/3 ----------------------------------
+    D, K, H, W, S = 32, 8, 84, 112, 6
+    C = synth.make_vocab(K, D, seed=1001)
+    tok = synth.make_tokens(C, (H // 14) * (W // 14), seed=2001, noise=0.3)
+    masks = synth.make_masks(S, H // 2, W // 2, seed=2101, hmin=4, hmax=20, wmin=4, wmax=30)
+    tiny = dict(D=D, K=K, H=H, W=W, S=S, masks=masks)
+    for order in (0, 1, 3):
+        adj = fv.nbrMasksAGGFastSingle([m for m in masks], order) if order else None
+        gd, inc, lab = run_seg_vlad(fv, rec, tok, masks, C, H, W, adj, D)
+        assert gd.shape == (S, 32 * D) and np.all(gd[:, K * D:] == 0)
+        tiny[f"vlad_o{order}"] = gd[:, :K * D]
+        tiny[f"adj_o{order}"] = np.eye(S, dtype=bool) if adj is None else adj.numpy()
+        tiny["inc"], tiny["labels"] = inc, lab
+    np.savez_compressed(f"{OUT}/vlad_tiny.npz", **tiny)
+
+    # ---- vlad_ref_shape: REF geometry, real indoor vocabulary, S=50, order 3 ----------------------
+    D, K, H, W, S = 1536, 32, 480, 640, 50
+    tok = synth.make_tokens(voc, 34 * 45, seed=2002)
+    masks = synth.make_masks(S, 240, 320, seed=2102)
+    adj = fv.nbrMasksAGGFastSingle([m for m in masks], 3)
+    t0 = time.time()
+    gd, inc, lab = run_seg_vlad(fv, rec, tok, masks, voc, H, W, adj, D)
+    print("ref-shape seg_vlad (reference body, cpu) %.3fs" % (time.time() - t0), gd.shape, gd.dtype)
+    G = np.random.Generator(np.random.PCG64(777)).standard_normal((K * D, 16))
+    np.savez_compressed(f"{OUT}/vlad_ref_shape.npz", S=S, adj=adj.numpy(), labels=lab.astype(np.uint8),
+                        inc=np.packbits(inc, axis=1), proj=gd @ G, sub=gd[:, ::61], head=gd[:, :256], tail=gd[:, -256:])
+    # adversarial tokens (near-tied assignments) at reduced N: labels + descriptor subsample
+    tokA = synth.make_tokens(voc, 34 * 45, seed=2003, adversarial=True)
+    gdA, incA, labA = run_seg_vlad(fv, rec, tokA, masks, voc, H, W, None, D)
+    np.savez_compressed(f"{OUT}/vlad_ref_shape_adv.npz", labels=labA.astype(np.uint8), sub=gdA[:, ::61], proj=gdA @ G)
+
+    # ---- K=64 through the only K-parametric entry (vlad_matmuls_per_cluster) -----------------------
+    D, K, S, N = 32, 64, 66, 20 * 15
+    C64 = synth.make_vocab(K, D, seed=1003)
+    tok = synth.make_tokens(C64, N, seed=2004, noise=0.2)
+    r = np.random.Generator(np.random.PCG64(2104))
+    inc64 = r.random((S, N)) < 0.15
+    inc64[3] = False  # a segment that covers no token
+    adj64 = (r.random((S, S)) < 0.05) | np.eye(S, dtype=bool)
+    xn = F.normalize(torch.from_numpy(tok.T.copy()), dim=1)
+    cn = F.normalize(torch.from_numpy(C64), dim=1)
+    lab = torch.argmax(xn @ cn.T, dim=1)
+    res = xn - torch.from_numpy(C64)[lab]
+    out64, _ = fv.vlad_matmuls_per_cluster(K, torch.from_numpy(inc64).double(), res.double(), lab,
+                                           adjMat=torch.from_numpy(adj64).double())
+    np.savez_compressed(f"{OUT}/vlad_k64.npz", D=D, K=K, S=S, N=N, inc=inc64, adj=adj64, labels=lab.numpy(),
+                        vlad=out64.numpy())
+
+    # ---- incidence cases (captured mask_idx) --------------------------------------------------------
+    ic = {}
+    cases = [("same", 112, 140, 112, 140), ("x2", 60, 80, 120, 160), ("x2clip", 63, 77, 126, 154),
+             ("nonint", 50, 70, 126, 150), ("down", 200, 260, 100, 130)]
+    Cs = synth.make_vocab(4, 8, seed=1)
+    for name, Hm, Wm, H, W in cases:
+        m = synth.make_blob_masks(7, Hm, Wm, seed=hash(name) % 1000 if False else len(name) * 31 + Hm)
+        tok = synth.make_tokens(Cs, (H // 14) * (W // 14), seed=5)
+        _, inc, _ = run_seg_vlad(fv, rec, tok, m, Cs, H, W, None, 8)
+        ic[f"{name}_masks"] = np.packbits(m.reshape(7, -1), axis=1)
+        ic[f"{name}_shape"] = np.array([7, Hm, Wm, H, W])
+        ic[f"{name}_inc"] = inc
+    np.savez_compressed(f"{OUT}/incidence_cases.npz", **ic)
+
+    # ---- adjacency cases ----------------------------------------------------------------------------
+    ac = {}
+    for S in (1, 2, 3, 4, 6, 12, 50):
+        m = synth.make_masks(S, 60, 80, seed=300 + S, hmin=3, hmax=20, wmin=3, wmax=25)
+        ac[f"S{S}_masks"] = np.packbits(m.reshape(S, -1), axis=1)
+        for order in (1, 2, 3):
+            ac[f"S{S}_o{order}"] = fv.nbrMasksAGGFastSingle([x for x in m], order).numpy()
+    np.savez_compressed(f"{OUT}/adjacency_cases.npz", **ac)
+
+    # ---- vote cases ----------------------------------------------------------------------------------
+    vc = {}
+    r = np.random.Generator(np.random.PCG64(600))
+    n_ref_img, segs, n_q = 300, 20, 40
+    imInds = np.repeat(np.arange(n_ref_img), segs)
+    seg_per_q = r.integers(1, 30, size=n_q)
+    off = np.concatenate([[0], np.cumsum(seg_per_q)])
+    nq = int(off[-1])
+    matches = r.integers(0, n_ref_img * segs, size=(nq, 50)).astype(np.int64)
+    # make votes concentrate: half of each query's matches come from a small image pool
+    for i in range(n_q):
+        pool = r.integers(0, n_ref_img, size=4)
+        rows = slice(off[i], off[i + 1])
+        sel = r.random((off[i + 1] - off[i], 50)) < 0.5
+        repl = pool[r.integers(0, 4, size=sel.shape)] * segs + r.integers(0, segs, size=sel.shape)
+        matches[rows] = np.where(sel, repl, matches[rows])
+    sims = np.sort(r.uniform(0.2, 1.9, size=(nq, 50)).astype(np.float32), axis=1)[:, ::-1].copy()
+    segRange = [np.arange(off[i], off[i + 1]) for i in range(n_q)]
+    gt = [[0]] * n_q
+    for n in (1, 5):
+        p = fv.get_matches(matches, gt, sims, segRange, imInds, n=n, method="max_seg_topk_wt_borda_Im")
+        vc[f"wt_n{n}"] = np.array([list(x) + [-1] * (n - len(x)) for x in p], dtype=np.int64)
+    p = fv.get_matches(matches, gt, sims, segRange, imInds, n=5, method="max_seg_topk")
+    vc["cnt_n5"] = np.array([list(x) + [-1] * (5 - len(x)) for x in p], dtype=np.int64)
+    vc.update(matches=matches, sims=sims, off=off, imInds=imInds)
+    # hand-made tie cases: equal weights -> order must follow first appearance (rank-major, then segment)
+    tm = np.array([[3, 1, 2, 0], [2, 3, 0, 1]], dtype=np.int64)          # 2 segments x 4 ranks, 4 ref segs
+    ts = np.array([[1.0, 0.5, 0.5, 0.25], [1.0, 0.5, 0.5, 0.25]], dtype=np.float32)
+    tim = np.array([2, 0, 3, 1])  # image ids must stay < len(imIndsRef): func_vpr.py:219 indexes imIndsRef with them
+    p = fv.get_matches(tm, [[0]], ts, [np.arange(2)], tim, n=4, method="max_seg_topk_wt_borda_Im")
+    vc.update(tie_matches=tm, tie_sims=ts, tie_imInds=tim, tie_pred=np.array(p[0], dtype=np.int64))
+    np.savez_compressed(f"{OUT}/vote_cases.npz", **vc)
+
+    # ---- recall cases ---------------------------------------------------------------------------------
+    r = np.random.Generator(np.random.PCG64(700))
+    preds = r.integers(0, 40, size=(60, 5))
+    gts = [list(r.integers(0, 40, size=r.integers(0, 4))) for _ in range(60)]
+    gts[7] = []
+    rec5 = fv.calc_recall([list(p) for p in preds], gts, 5)
+    gtpad = np.full((60, 4), -1, dtype=np.int64)
+    for i, g in enumerate(gts):
+        gtpad[i, :len(g)] = g
+    np.savez_compressed(f"{OUT}/recall_cases.npz", preds=preds, gt=gtpad, recalls=np.array(rec5))
+
+    # ---- pca_small (sklearn installed here; pins the affine map, not the fit) -----------------------------
+    from sklearn.decomposition import PCA
+    r = np.random.Generator(np.random.PCG64(800))
+    X = (r.standard_normal((200, 64)) @ r.standard_normal((64, 64))).astype(np.float32)
+    pca = PCA(n_components=8, whiten=True, svd_solver="arpack", random_state=0).fit(X)
+    Xt = r.standard_normal((30, 64))
+    np.savez_compressed(f"{OUT}/pca_small.npz", mean=pca.mean_, components=pca.components_,
+                        explained_variance=pca.explained_variance_, X=Xt, Y=pca.transform(Xt))
+
+    # ---- e2e_small: recall_segloc chain (kNN via the NumPy IndexFlatL2 stand-in) ---------------------------
+    n_img, S, d, n_q = 260, 10, 1024, 30
+    R, img = synth.make_planted_db(n_img, S, d, seed=3000)
+    Q, tau, off = synth.make_planted_queries(R, n_img, S, n_q, seed=4000, sigma_q=3.0)
+    gt = [[int(t)] for t in tau]
+    gt[5] = []
+    segRange2 = [np.arange(off[i], off[i + 1]) for i in range(n_q)]
+    captured = {}
+    gm = fv.get_matches
+
+    def gm_wrap(matches, gt_, sims, srq, imr, n=1, method="max_sim"):
+        captured.update(matches=matches.copy(), sims=sims.copy())
+        p = gm(matches, gt_, sims, srq, imr, n=n, method=method)
+        captured["preds"] = p
+        return p
+
+    fv.get_matches = gm_wrap
+    # the reference scales descriptors by arbitrary norms before normalizeFeat; feed un-normalised rows
+    scale_r = np.random.Generator(np.random.PCG64(1)).uniform(0.5, 2.0, size=(R.shape[0], 1))
+    scale_q = np.random.Generator(np.random.PCG64(2)).uniform(0.5, 2.0, size=(Q.shape[0], 1))
+    recalls = prm.recall_segloc("/tmp", "synthetic", {"pca": True, "results_pkl_suffix": "x"}, "e2e",
+                                torch.from_numpy(R.astype(np.float64) * scale_r), torch.from_numpy(Q.astype(np.float64) * scale_q),
+                                gt, segRange2, img.astype(np.int64), False, "indoor", save_results=False)
+    fv.get_matches = gm
+    np.savez_compressed(f"{OUT}/e2e_small.npz", n_img=n_img, S=S, d=d, n_q=n_q, recalls=np.array(recalls),
+                        preds=np.array([list(p) + [-1] * (5 - len(p)) for p in captured["preds"]], dtype=np.int64),
+                        matches_50=captured["matches"], sims_50=captured["sims"])
+    print("e2e recalls", recalls)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()
