@@ -1,0 +1,141 @@
+/*
+ * segvlad.h -- C-ABI of the MI355X-native SegVLAD hot path (libsegvlad_hip.so, gfx950).
+ *
+ * The reference (AnyLoc/Revisit-Anything, all Python) exposes no FFI; the boundary it offers is
+ * the function surface of func_vpr.py / place_rec_main.py.  Each entry point below replaces the
+ * cited reference function(s); the Python module revisit_anything_amd.func_vpr maps the reference's
+ * names/arguments onto these calls (INTEGRATION.md shows the ctypes stub a maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  Bulk data pointers may be DEVICE or HOST pointers
+ *     (hipPointerGetAttributes decides; host data is staged through a context-owned buffer).
+ *     Pointers documented "host" must be host memory (small launch-geometry metadata).
+ *   - every function returns 0 (SEGVLAD_OK) or a negative error code; the message is available from
+ *     segvlad_last_error(ctx).  No exception crosses the ABI.
+ *   - one context per (device, stream).  A context is not re-entrant; distinct contexts may be
+ *     driven from distinct host threads.  Work is enqueued on the context's HIP stream
+ *     (segvlad_set_stream) and is asynchronous unless an output pointer is host memory.
+ *   - results are freshly written into caller-owned buffers; inputs are never modified.
+ *   - arithmetic: fp32 on device (the reference's fp64 aggregation is matched to <=1e-6 cosine);
+ *     integer/bit outputs (incidence, labels away from audited ties, kNN ids away from ties,
+ *     vote order) are exact.
+ */
+#ifndef SEGVLAD_H
+#define SEGVLAD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct segvlad_ctx segvlad_ctx;
+
+enum {
+  SEGVLAD_OK = 0,
+  SEGVLAD_ERR_ARG = -1,    /* bad argument (null pointer, negative size, unsupported shape)   */
+  SEGVLAD_ERR_HIP = -2,    /* a HIP runtime call failed                                        */
+  SEGVLAD_ERR_STATE = -3,  /* call order (e.g. segvlad_images before segvlad_set_vocab)        */
+  SEGVLAD_ERR_LIMIT = -4,  /* documented implementation limit exceeded                        */
+  SEGVLAD_ERR_NOMEM = -5
+};
+
+#define SEGVLAD_VOTE_WT_BORDA_IM 0 /* get_matches(method="max_seg_topk_wt_borda_Im"), func_vpr.py:207-224 */
+#define SEGVLAD_VOTE_COUNT 1       /* get_matches(method="max_seg_topk"),            func_vpr.py:118-125 */
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int segvlad_version(void);
+int segvlad_create(segvlad_ctx** out, int device_id);
+int segvlad_destroy(segvlad_ctx* ctx);
+const char* segvlad_last_error(const segvlad_ctx* ctx);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
+int segvlad_set_stream(segvlad_ctx* ctx, void* hip_stream);
+int segvlad_synchronize(segvlad_ctx* ctx);
+
+/* ---- vocabulary: torch.load(c_centers.pt) + F.normalize(c_centers)   place_rec_main.py:149-154,
+ *      func_vpr.py:1145.  C is [K][D] fp32; both C and its row-normalised copy stay on device.   */
+int segvlad_set_vocab(segvlad_ctx* ctx, const float* C, int K, int D);
+
+/* ---- mask -> token incidence: nearest-upsample + argwhere + scatter  func_vpr.py:1088-1092 with
+ *      the pixel->token map of place_rec_main.py:187-194 folded in.
+ *      masks [S][Hm][Wm] bytes (non-zero = true); inc_bits [S][ceil(N/64)] u64, bit (t%64) of word
+ *      (t/64) = token t covered; N = (H/patch)*(W/patch).  S may span a whole batch of images.   */
+int segvlad_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                      uint64_t* inc_bits);
+
+/* ---- mask centroids: np.nonzero(mask).mean(1)[::-1]                  func_vpr.py:1314
+ *      centroids [S][2] fp64 (x, y); an empty mask yields NaN (the reference raises ValueError).  */
+int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* centroids);
+
+/* ---- segment VLAD for a batch of B images of identical token geometry
+ *      seg_vlad_gpu_single(_img) -> vlad_single -> vlad_matmuls_per_cluster   func_vpr.py:1065-1210
+ *      tokens      [B][D][N] fp32, as stored by the reference (D-major, N contiguous)
+ *      inc_bits    [S_tot][ceil(N/64)] u64 from segvlad_incidence
+ *      seg_offsets [B+1] int32 HOST: segments of image b are rows seg_offsets[b]..seg_offsets[b+1]
+ *      adj         concatenated per-image [S_b][S_b] byte matrices (row-major, non-zero = 1), or
+ *                  NULL for order 0 (identity)                                func_vpr.py:1192-1193
+ *      out         [S_tot][K*D] fp32, cluster-major, intra-normalised then L2-normalised
+ *      labels_out  [B][N] u8 or NULL      (argmax_k <x^, c^_k>, first max)    func_vpr.py:1146
+ *      gap_out     [B][N] fp32 or NULL    (top-1 minus top-2 cosine: the tie audit)
+ *      block_norms_out [S_tot][K] fp32 or NULL (||V[s,k,:]|| before intra-normalisation)          */
+int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                   const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out,
+                   float* gap_out, float* block_norms_out);
+
+/* ---- PCA apply: pickle.load + PCA.transform                          func_vpr.py:1419-1443
+ *      Y = ((X - mean) @ comps^T) / sqrt(expl_var) when whiten!=0.  comps [P][KD] fp32.          */
+int segvlad_pca_set(segvlad_ctx* ctx, const float* mean, const float* comps, const float* expl_var, int P, int KD,
+                    int whiten);
+/*      X [n][KD] -> Y [n][P]; l2norm!=0 additionally applies normalizeFeat (func_vpr.py:1673-1676) */
+int segvlad_pca_apply(segvlad_ctx* ctx, const float* X, int n, float* Y, int l2norm);
+
+/* ---- row L2 normalisation: normalizeFeat                             func_vpr.py:1673-1676
+ *      (no epsilon: an all-zero row becomes NaN exactly like the reference).  X may equal Y.      */
+int segvlad_normalize_rows(segvlad_ctx* ctx, const float* X, int n, int d, float* Y);
+
+/* ---- exact kNN: faiss.IndexFlatL2(d).add / .search                   place_rec_main.py:53-60
+ *      The index keeps a device copy of the rows.  img_of_seg (imIndsRef / imInds1,
+ *      place_rec_main.py:252) may be NULL if segvlad_vote is given the map explicitly.            */
+int segvlad_db_reset(segvlad_ctx* ctx);
+int segvlad_db_add(segvlad_ctx* ctx, const float* R, int n, int d, const int32_t* img_of_seg);
+int segvlad_db_size(segvlad_ctx* ctx, int64_t* n_rows, int* d);
+/*      d2_out [nq][k] fp32 ascending squared L2; idx_out [nq][k] int64 (ties -> lower id; slots
+ *      beyond the database size hold (+inf, -1) like faiss).  1 <= k <= 1024.                      */
+int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_out, int64_t* idx_out);
+
+/* ---- merge of per-shard top-k lists (no reference counterpart: the reference is single-process).
+ *      d2_parts/idx_parts [nq][parts*k] (shard-major within a row, global ids); output top-k by
+ *      (distance, lower id).                                                                       */
+int segvlad_merge_topk(segvlad_ctx* ctx, const float* d2_parts, const int64_t* idx_parts, int nq, int parts, int k,
+                       float* d2_out, int64_t* idx_out);
+
+/* ---- top-50 slice + "2 - d^2":  sims_50 = 2 - sims[:, :50]           place_rec_main.py:78-81     */
+int segvlad_sims_from_d2(segvlad_ctx* ctx, const float* d2, const int64_t* idx, int nq, int k_in, int k_keep,
+                         float* sims_out, int64_t* idx_out);
+
+/* ---- global min / max of the kept similarities                        func_vpr.py:212-213
+ *      minmax_out [2] fp32 = {min, max}.                                                          */
+int segvlad_minmax(segvlad_ctx* ctx, const float* sims, int64_t count, float* minmax_out);
+
+/* ---- image vote: get_matches + weighted_borda_count                   func_vpr.py:61-77, 207-224
+ *      idx [nq][k] int64 reference-segment ids, sims [nq][k] fp32, img_of_seg [n_ref_seg] int32
+ *      (NULL = the map given to segvlad_db_add; n_ref_seg is then ignored), qseg_offsets [n_img+1]
+ *      int32 HOST.
+ *      smin/smax: the GLOBAL extrema (func_vpr.py:212-213); pass NaN to have them computed from
+ *      `sims`.  pred_out [n_img][n_top] int32 (-1 padded), score_out [n_img][n_top] fp64 or NULL
+ *      (mode COUNT: the integer vote count as a double).  Ties: first appearance (rank-major, then
+ *      segment) for WT_BORDA_IM; (count desc, image id asc) for COUNT.                             */
+int segvlad_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const int32_t* img_of_seg,
+                 int64_t n_ref_seg, const int32_t* qseg_offsets, int n_img, int k, float smin, float smax, int n_top, int mode,
+                 int32_t* pred_out, double* score_out);
+
+/* ---- instrumentation: HIP-event time (ms) of the kernels enqueued by the last call of the named
+ *      stage ("assign", "prep", "aggregate", "incidence", "pca", "knn_gemm", "knn_select", "vote").
+ *      Only valid after segvlad_set_profiling(ctx, 1); returns <0 if the stage never ran.          */
+int segvlad_set_profiling(segvlad_ctx* ctx, int on);
+int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGVLAD_H */

@@ -1,0 +1,81 @@
+"""ctypes binding of include/segvlad.h.  Loads the in-tree libsegvlad_hip.so and fails loudly when
+it is missing or cannot be loaded -- there is NO CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_ctx_p = C.c_void_p
+_f32p = C.c_void_p  # all bulk pointers are passed as raw addresses (host or device)
+
+SEGVLAD_OK = 0
+VOTE_WT_BORDA_IM = 0
+VOTE_COUNT = 1
+
+# name -> (restype, argtypes); kept in one table so tests can check the exported symbols against the header
+SIGNATURES = {
+    "segvlad_version": (C.c_int, []),
+    "segvlad_create": (C.c_int, [C.POINTER(c_ctx_p), C.c_int]),
+    "segvlad_destroy": (C.c_int, [c_ctx_p]),
+    "segvlad_last_error": (C.c_char_p, [c_ctx_p]),
+    "segvlad_set_stream": (C.c_int, [c_ctx_p, C.c_void_p]),
+    "segvlad_synchronize": (C.c_int, [c_ctx_p]),
+    "segvlad_set_vocab": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int]),
+    "segvlad_incidence": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "segvlad_mask_centroids": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "segvlad_images": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_void_p,
+                                  _f32p, _f32p]),
+    "segvlad_pca_set": (C.c_int, [c_ctx_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
+    "segvlad_pca_apply": (C.c_int, [c_ctx_p, _f32p, C.c_int, _f32p, C.c_int]),
+    "segvlad_normalize_rows": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, _f32p]),
+    "segvlad_db_reset": (C.c_int, [c_ctx_p]),
+    "segvlad_db_add": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p]),
+    "segvlad_db_size": (C.c_int, [c_ctx_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "segvlad_search": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, _f32p, C.c_void_p]),
+    "segvlad_merge_topk": (C.c_int, [c_ctx_p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p]),
+    "segvlad_sims_from_d2": (C.c_int, [c_ctx_p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p]),
+    "segvlad_minmax": (C.c_int, [c_ctx_p, _f32p, C.c_int64, _f32p]),
+    "segvlad_vote": (C.c_int, [c_ctx_p, C.c_void_p, _f32p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "segvlad_set_profiling": (C.c_int, [c_ctx_p, C.c_int]),
+    "segvlad_stage_ms": (C.c_int, [c_ctx_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+class SegVLADError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first if the sources are newer and hipcc is present) the HIP library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if build_if_missing and _build.needs_build():
+        try:
+            _build.build()
+        except Exception as e:  # no hipcc on this box: use the shipped .so if there is one
+            if not os.path.exists(path):
+                raise SegVLADError(f"libsegvlad_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise SegVLADError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                           "There is no CPU fallback.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise SegVLADError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

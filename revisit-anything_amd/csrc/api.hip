@@ -1,0 +1,548 @@
+// C-ABI of libsegvlad_hip.so (see include/segvlad.h).  Host-side orchestration only: argument
+// checks, host/device pointer staging, scratch sizing and kernel sequencing on the context stream.
+#include <stdarg.h>
+
+#include <cmath>
+
+#include "ctx.h"
+
+int segvlad_ctx::fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err, sizeof(err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+bool sv_is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof(a));
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory reports an error on some runtimes
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeUnified;
+}
+
+void sv_begin(segvlad_ctx* ctx) {
+  ctx->stage_used = 0;
+  ctx->pending_out.clear();
+  ctx->err[0] = 0;
+  (void)hipSetDevice(ctx->device);
+}
+
+static DevBuf* next_stage(segvlad_ctx* ctx) {
+  if (ctx->stage_used >= (int)ctx->stage.size()) ctx->stage.resize(ctx->stage_used + 1);
+  return &ctx->stage[ctx->stage_used++];
+}
+
+int sv_in(segvlad_ctx* ctx, const void* p, size_t bytes, const void** dev) {
+  if (bytes == 0) {
+    *dev = p;
+    return SEGVLAD_OK;
+  }
+  if (sv_is_device_ptr(p)) {
+    *dev = p;
+    return SEGVLAD_OK;
+  }
+  DevBuf* b = next_stage(ctx);
+  SV_HIP(b->reserve(bytes));
+  SV_HIP(hipMemcpyAsync(b->p, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // pageable host memory: hipMemcpyAsync returns after the staging copy, so the caller may reuse p
+  *dev = b->p;
+  return SEGVLAD_OK;
+}
+
+int sv_out(segvlad_ctx* ctx, void* p, size_t bytes, void** dev) {
+  if (bytes == 0 || sv_is_device_ptr(p)) {
+    *dev = p;
+    return SEGVLAD_OK;
+  }
+  DevBuf* b = next_stage(ctx);
+  SV_HIP(b->reserve(bytes));
+  ctx->pending_out.push_back({p, b->p, bytes});
+  *dev = b->p;
+  return SEGVLAD_OK;
+}
+
+int sv_finish(segvlad_ctx* ctx) {
+  if (!ctx->pending_out.empty()) {
+    for (auto& po : ctx->pending_out) SV_HIP(hipMemcpyAsync(po.host, po.dev, po.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SV_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->pending_out.clear();
+  }
+  return SEGVLAD_OK;
+}
+
+StageScope::StageScope(segvlad_ctx* c, const char* name) : ctx(c) {
+  if (!c->profiling) return;
+  t = &c->timers[name];
+  if (!t->ev0) {
+    (void)hipEventCreate(&t->ev0);
+    (void)hipEventCreate(&t->ev1);
+  }
+  t->launches = 0;
+  t->valid = true;
+  (void)hipEventRecord(t->ev0, c->stream);
+}
+StageScope::~StageScope() {
+  if (t) (void)hipEventRecord(t->ev1, ctx->stream);
+}
+
+#define CHECK_CTX()                 \
+  if (!ctx) return SEGVLAD_ERR_ARG; \
+  sv_begin(ctx)
+
+extern "C" {
+
+int segvlad_version(void) { return 100; }
+
+int segvlad_create(segvlad_ctx** out, int device_id) {
+  if (!out) return SEGVLAD_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return SEGVLAD_ERR_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return SEGVLAD_ERR_HIP;
+  segvlad_ctx* c = new (std::nothrow) segvlad_ctx();
+  if (!c) return SEGVLAD_ERR_NOMEM;
+  c->device = device_id;
+  *out = c;
+  return SEGVLAD_OK;
+}
+
+int segvlad_destroy(segvlad_ctx* ctx) {
+  if (!ctx) return SEGVLAD_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DevBuf* bufs[] = {&ctx->vocab,    &ctx->vocab_bt, &ctx->pca_mean, &ctx->pca_comps, &ctx->pca_scale, &ctx->db_rows,
+                    &ctx->db_norms, &ctx->db_img,   &ctx->s_xt,     &ctx->s_labels,  &ctx->s_rnorm,   &ctx->s_gap,
+                    &ctx->s_colmask, &ctx->s_gscale, &ctx->s_segimg, &ctx->s_segoff, &ctx->s_adjoff,  &ctx->s_dist,
+                    &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff};
+  for (DevBuf* b : bufs) b->release();
+  for (auto& b : ctx->stage) b.release();
+  for (auto& kv : ctx->timers) {
+    if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
+    if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);
+  }
+  delete ctx;
+  return SEGVLAD_OK;
+}
+
+const char* segvlad_last_error(const segvlad_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int segvlad_set_stream(segvlad_ctx* ctx, void* hip_stream) {
+  if (!ctx) return SEGVLAD_ERR_ARG;
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return SEGVLAD_OK;
+}
+
+int segvlad_synchronize(segvlad_ctx* ctx) {
+  CHECK_CTX();
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  return SEGVLAD_OK;
+}
+
+int segvlad_set_profiling(segvlad_ctx* ctx, int on) {
+  if (!ctx) return SEGVLAD_ERR_ARG;
+  ctx->profiling = on != 0;
+  return SEGVLAD_OK;
+}
+
+int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* launches_out) {
+  CHECK_CTX();
+  if (!stage || !ms_out) return ctx->fail(SEGVLAD_ERR_ARG, "stage_ms: null argument");
+  auto it = ctx->timers.find(stage);
+  if (it == ctx->timers.end() || !it->second.valid) return ctx->fail(SEGVLAD_ERR_STATE, "stage '%s' has not run with profiling on", stage);
+  SV_HIP(hipEventSynchronize(it->second.ev1));
+  SV_HIP(hipEventElapsedTime(ms_out, it->second.ev0, it->second.ev1));
+  if (launches_out) *launches_out = it->second.launches;
+  return SEGVLAD_OK;
+}
+
+// ---- vocabulary ----------------------------------------------------------------------------------
+int segvlad_set_vocab(segvlad_ctx* ctx, const float* C, int K, int D) {
+  CHECK_CTX();
+  if (!C || K <= 0 || D <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "set_vocab: need C, K>0, D>0");
+  if (D % 4) return ctx->fail(SEGVLAD_ERR_ARG, "set_vocab: D=%d must be a multiple of 4", D);
+  if (K > 128) return ctx->fail(SEGVLAD_ERR_LIMIT, "set_vocab: K=%d > 128 clusters is not supported by this build", K);
+  int Kpad = (K <= 32) ? 32 : (K <= 64) ? 64 : 128;
+  const size_t bytes = (size_t)K * D * sizeof(float);
+  SV_HIP(ctx->vocab.reserve(bytes));
+  if (sv_is_device_ptr(C))
+    SV_HIP(hipMemcpyAsync(ctx->vocab.p, C, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  else
+    SV_HIP(hipMemcpyAsync(ctx->vocab.p, C, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ctx->K = K;
+  ctx->D = D;
+  ctx->Kpad = Kpad;
+  SV_TRY(sv_launch_vocab_prepare(ctx));
+  return sv_finish(ctx);
+}
+
+// ---- incidence / centroids -------------------------------------------------------------------------
+int segvlad_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                      uint64_t* inc_bits) {
+  CHECK_CTX();
+  if (S < 0 || Hm <= 0 || Wm <= 0 || H <= 0 || W <= 0 || patch <= 0 || H / patch <= 0 || W / patch <= 0)
+    return ctx->fail(SEGVLAD_ERR_ARG, "incidence: bad geometry S=%d masks %dx%d image %dx%d patch %d", S, Hm, Wm, H, W, patch);
+  if (S == 0) return SEGVLAD_OK;
+  if (!masks || !inc_bits) return ctx->fail(SEGVLAD_ERR_ARG, "incidence: null pointer");
+  const int N = (H / patch) * (W / patch), nw = (N + 63) / 64;
+  const void* dm;
+  void* dout;
+  SV_TRY(sv_in(ctx, masks, (size_t)S * Hm * Wm, &dm));
+  SV_TRY(sv_out(ctx, inc_bits, (size_t)S * nw * 8, &dout));
+  {
+    StageScope sc(ctx, "incidence");
+    SV_TRY(sv_launch_incidence(ctx, (const uint8_t*)dm, S, Hm, Wm, H, W, patch, (uint64_t*)dout));
+    sc.count();
+  }
+  return sv_finish(ctx);
+}
+
+int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* centroids) {
+  CHECK_CTX();
+  if (S < 0 || Hm <= 0 || Wm <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "mask_centroids: bad geometry");
+  if (S == 0) return SEGVLAD_OK;
+  if (!masks || !centroids) return ctx->fail(SEGVLAD_ERR_ARG, "mask_centroids: null pointer");
+  const void* dm;
+  void* dout;
+  SV_TRY(sv_in(ctx, masks, (size_t)S * Hm * Wm, &dm));
+  SV_TRY(sv_out(ctx, centroids, (size_t)S * 2 * sizeof(double), &dout));
+  SV_TRY(sv_launch_centroids(ctx, (const uint8_t*)dm, S, Hm, Wm, (double*)dout));
+  return sv_finish(ctx);
+}
+
+// ---- segment VLAD -----------------------------------------------------------------------------------
+int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                   const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out, float* gap_out,
+                   float* block_norms_out) {
+  CHECK_CTX();
+  if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images: call segvlad_set_vocab first");
+  if (B < 0 || N <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "images: B=%d N=%d", B, N);
+  if (B == 0) return SEGVLAD_OK;
+  if (!tokens || !seg_offsets) return ctx->fail(SEGVLAD_ERR_ARG, "images: null pointer");
+  if (sv_is_device_ptr(seg_offsets)) return ctx->fail(SEGVLAD_ERR_ARG, "images: seg_offsets must be host memory");
+  const int K = ctx->K, D = ctx->D;
+  const int nw = (N + 63) / 64;
+  int S_max = 0;
+  std::vector<int64_t> adj_off(B + 1, 0);
+  if (seg_offsets[0] != 0) return ctx->fail(SEGVLAD_ERR_ARG, "images: seg_offsets[0] must be 0");
+  for (int b = 0; b < B; ++b) {
+    const int s = seg_offsets[b + 1] - seg_offsets[b];
+    if (s < 0) return ctx->fail(SEGVLAD_ERR_ARG, "images: seg_offsets must be non-decreasing");
+    if (s > S_max) S_max = s;
+    adj_off[b + 1] = adj_off[b] + (int64_t)s * s;
+  }
+  const int S_tot = seg_offsets[B];
+  if (S_tot > 0 && (!inc_bits || !out)) return ctx->fail(SEGVLAD_ERR_ARG, "images: null inc_bits/out");
+  const int SC = S_max > 0 ? (S_max + 63) / 64 : 1;
+
+  const void *d_tok, *d_inc = nullptr, *d_adj = nullptr;
+  void *d_out = nullptr, *d_lab = nullptr, *d_gap = nullptr, *d_bn = nullptr;
+  SV_TRY(sv_in(ctx, tokens, (size_t)B * D * N * sizeof(float), &d_tok));
+  if (S_tot > 0) SV_TRY(sv_in(ctx, inc_bits, (size_t)S_tot * nw * 8, &d_inc));
+  if (adj && S_tot > 0) SV_TRY(sv_in(ctx, adj, (size_t)adj_off[B], &d_adj));
+  if (S_tot > 0) SV_TRY(sv_out(ctx, out, (size_t)S_tot * K * D * sizeof(float), &d_out));
+  if (labels_out) SV_TRY(sv_out(ctx, labels_out, (size_t)B * N, &d_lab));
+  if (gap_out) SV_TRY(sv_out(ctx, gap_out, (size_t)B * N * sizeof(float), &d_gap));
+  if (block_norms_out && S_tot > 0) SV_TRY(sv_out(ctx, block_norms_out, (size_t)S_tot * K * sizeof(float), &d_bn));
+
+  SV_HIP(ctx->s_xt.reserve((size_t)B * N * D * sizeof(float)));
+  SV_HIP(ctx->s_rnorm.reserve((size_t)B * N * sizeof(float)));
+  if (!d_lab) {
+    SV_HIP(ctx->s_labels.reserve((size_t)B * N));
+    d_lab = ctx->s_labels.p;
+  }
+  SV_HIP(ctx->s_colmask.reserve((size_t)B * N * SC * 8));
+  SV_HIP(ctx->s_gscale.reserve((size_t)(S_tot + 1) * sizeof(float)));
+  SV_HIP(ctx->s_segoff.reserve((size_t)(B + 1) * sizeof(int32_t)));
+  SV_HIP(ctx->s_adjoff.reserve((size_t)(B + 1) * sizeof(int64_t)));
+  SV_HIP(hipMemcpyAsync(ctx->s_segoff.p, seg_offsets, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  SV_HIP(hipMemcpyAsync(ctx->s_adjoff.p, adj_off.data(), (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  // (pageable sources: the runtime stages them before hipMemcpyAsync returns, so the local vector
+  //  and the caller's array may be reused as soon as this call returns)
+
+  {
+    StageScope sc(ctx, "assign");
+    SV_TRY(sv_launch_assign(ctx, (const float*)d_tok, B, N, ctx->s_xt.as<float>(), (uint8_t*)d_lab, ctx->s_rnorm.as<float>(),
+                            (float*)d_gap));
+    sc.count();
+  }
+  if (S_tot > 0) {
+    {
+      StageScope sc(ctx, "prep");
+      SV_TRY(sv_launch_prep(ctx, (const uint8_t*)d_lab, (const uint64_t*)d_inc, ctx->s_segoff.as<int32_t>(),
+                            ctx->s_adjoff.as<int64_t>(), (const uint8_t*)d_adj, B, N, S_max, SC, ctx->s_colmask.as<uint64_t>(),
+                            ctx->s_gscale.as<float>()));
+      sc.count();
+    }
+    {
+      StageScope sc(ctx, "aggregate");
+      SV_TRY(sv_launch_aggregate(ctx, ctx->s_xt.as<float>(), ctx->s_rnorm.as<float>(), (const uint8_t*)d_lab,
+                                 ctx->s_colmask.as<uint64_t>(), ctx->s_segoff.as<int32_t>(), ctx->s_gscale.as<float>(), B, N,
+                                 SC, (float*)d_out, (float*)d_bn));
+      sc.count();
+    }
+  }
+  return sv_finish(ctx);
+}
+
+// ---- PCA ------------------------------------------------------------------------------------------------
+__global__ void pca_scale_kernel(const float* var, int P, int whiten, float* scale) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < P) scale[j] = whiten ? (float)(1.0 / sqrt((double)var[j])) : 1.f;
+}
+
+int segvlad_pca_set(segvlad_ctx* ctx, const float* mean, const float* comps, const float* expl_var, int P, int KD,
+                    int whiten) {
+  CHECK_CTX();
+  if (!comps || P <= 0 || KD <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "pca_set: need comps, P>0, KD>0");
+  if (whiten && !expl_var) return ctx->fail(SEGVLAD_ERR_ARG, "pca_set: whiten needs explained_variance");
+  SV_HIP(ctx->pca_comps.reserve((size_t)P * KD * sizeof(float)));
+  SV_HIP(ctx->pca_mean.reserve((size_t)KD * sizeof(float)));
+  SV_HIP(ctx->pca_scale.reserve((size_t)P * sizeof(float)));
+  SV_HIP(hipMemcpyAsync(ctx->pca_comps.p, comps, (size_t)P * KD * sizeof(float), hipMemcpyDefault, ctx->stream));
+  if (mean)
+    SV_HIP(hipMemcpyAsync(ctx->pca_mean.p, mean, (size_t)KD * sizeof(float), hipMemcpyDefault, ctx->stream));
+  else
+    SV_HIP(hipMemsetAsync(ctx->pca_mean.p, 0, (size_t)KD * sizeof(float), ctx->stream));
+  const void* dvar = nullptr;
+  if (whiten) SV_TRY(sv_in(ctx, expl_var, (size_t)P * sizeof(float), &dvar));
+  hipLaunchKernelGGL(pca_scale_kernel, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, (const float*)dvar, P, whiten,
+                     ctx->pca_scale.as<float>());
+  SV_HIP(hipGetLastError());
+  ctx->P = P;
+  ctx->KD = KD;
+  ctx->whiten = whiten;
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  return sv_finish(ctx);
+}
+
+int segvlad_pca_apply(segvlad_ctx* ctx, const float* X, int n, float* Y, int l2norm) {
+  CHECK_CTX();
+  if (ctx->P == 0) return ctx->fail(SEGVLAD_ERR_STATE, "pca_apply: call segvlad_pca_set first");
+  if (n < 0) return ctx->fail(SEGVLAD_ERR_ARG, "pca_apply: n<0");
+  if (n == 0) return SEGVLAD_OK;
+  if (!X || !Y) return ctx->fail(SEGVLAD_ERR_ARG, "pca_apply: null pointer");
+  const void* dx;
+  void* dy;
+  SV_TRY(sv_in(ctx, X, (size_t)n * ctx->KD * sizeof(float), &dx));
+  SV_TRY(sv_out(ctx, Y, (size_t)n * ctx->P * sizeof(float), &dy));
+  {
+    StageScope sc(ctx, "pca");
+    SV_TRY(sv_launch_gemm_nt(ctx, 0, (const float*)dx, ctx->pca_comps.as<float>(), (float*)dy, n, ctx->P, ctx->KD, ctx->P,
+                             ctx->pca_mean.as<float>(), ctx->pca_scale.as<float>(), nullptr, nullptr));
+    sc.count();
+    if (l2norm) {
+      SV_TRY(sv_launch_normalize_rows(ctx, (const float*)dy, n, ctx->P, (float*)dy));
+      sc.count();
+    }
+  }
+  return sv_finish(ctx);
+}
+
+int segvlad_normalize_rows(segvlad_ctx* ctx, const float* X, int n, int d, float* Y) {
+  CHECK_CTX();
+  if (n < 0 || d <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "normalize_rows: bad shape");
+  if (n == 0) return SEGVLAD_OK;
+  if (!X || !Y) return ctx->fail(SEGVLAD_ERR_ARG, "normalize_rows: null pointer");
+  const void* dx;
+  void* dy;
+  SV_TRY(sv_in(ctx, X, (size_t)n * d * sizeof(float), &dx));
+  SV_TRY(sv_out(ctx, Y, (size_t)n * d * sizeof(float), &dy));
+  SV_TRY(sv_launch_normalize_rows(ctx, (const float*)dx, n, d, (float*)dy));
+  return sv_finish(ctx);
+}
+
+// ---- database / search ---------------------------------------------------------------------------------------
+int segvlad_db_reset(segvlad_ctx* ctx) {
+  CHECK_CTX();
+  ctx->db_n = 0;
+  ctx->db_d = 0;
+  ctx->db_has_img = false;
+  return SEGVLAD_OK;
+}
+
+int segvlad_db_add(segvlad_ctx* ctx, const float* R, int n, int d, const int32_t* img_of_seg) {
+  CHECK_CTX();
+  if (n < 0 || d <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "db_add: bad shape");
+  if (ctx->db_n > 0 && d != ctx->db_d) return ctx->fail(SEGVLAD_ERR_ARG, "db_add: d=%d but the index holds d=%d", d, ctx->db_d);
+  if (ctx->db_n > 0 && ctx->db_has_img != (img_of_seg != nullptr))
+    return ctx->fail(SEGVLAD_ERR_ARG, "db_add: img_of_seg must be given for all rows or none");
+  if (n == 0) return SEGVLAD_OK;
+  if (!R) return ctx->fail(SEGVLAD_ERR_ARG, "db_add: null rows");
+  const int64_t n_new = ctx->db_n + n;
+  // grow (keeping old contents)
+  auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
+    if (new_bytes <= b.cap) return hipSuccess;
+    DevBuf nb;
+    hipError_t e = nb.reserve(new_bytes + new_bytes / 2);
+    if (e != hipSuccess) return e;
+    if (old_bytes) {
+      e = hipMemcpyAsync(nb.p, b.p, old_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e != hipSuccess) return e;
+      e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) return e;
+    }
+    b.release();
+    b = nb;
+    return hipSuccess;
+  };
+  SV_HIP(grow(ctx->db_rows, (size_t)ctx->db_n * d * 4, (size_t)n_new * d * 4));
+  SV_HIP(grow(ctx->db_norms, (size_t)ctx->db_n * 4, (size_t)n_new * 4));
+  float* dst = ctx->db_rows.as<float>() + (size_t)ctx->db_n * d;
+  SV_HIP(hipMemcpyAsync(dst, R, (size_t)n * d * 4, hipMemcpyDefault, ctx->stream));
+  if (img_of_seg) {
+    SV_HIP(grow(ctx->db_img, (size_t)ctx->db_n * 4, (size_t)n_new * 4));
+    SV_HIP(hipMemcpyAsync(ctx->db_img.as<int32_t>() + ctx->db_n, img_of_seg, (size_t)n * 4, hipMemcpyDefault, ctx->stream));
+    ctx->db_has_img = true;
+  }
+  SV_TRY(sv_launch_row_sumsq(ctx, dst, n, d, ctx->db_norms.as<float>() + ctx->db_n));
+  ctx->db_n = n_new;
+  ctx->db_d = d;
+  return sv_finish(ctx);
+}
+
+int segvlad_db_size(segvlad_ctx* ctx, int64_t* n_rows, int* d) {
+  if (!ctx) return SEGVLAD_ERR_ARG;
+  if (n_rows) *n_rows = ctx->db_n;
+  if (d) *d = ctx->db_d;
+  return SEGVLAD_OK;
+}
+
+int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_out, int64_t* idx_out) {
+  CHECK_CTX();
+  if (nq < 0 || k < 1 || k > 1024) return ctx->fail(SEGVLAD_ERR_ARG, "search: need nq>=0 and 1<=k<=1024 (k=%d)", k);
+  if (nq == 0) return SEGVLAD_OK;
+  if (!Q || !d2_out || !idx_out) return ctx->fail(SEGVLAD_ERR_ARG, "search: null pointer");
+  if (ctx->db_d == 0) return ctx->fail(SEGVLAD_ERR_STATE, "search: the index is empty and has no dimension yet");
+  const int d = ctx->db_d;
+  const int64_t n = ctx->db_n;
+  const void* dq;
+  void *dd2, *didx;
+  SV_TRY(sv_in(ctx, Q, (size_t)nq * d * 4, &dq));
+  SV_TRY(sv_out(ctx, d2_out, (size_t)nq * k * 4, &dd2));
+  SV_TRY(sv_out(ctx, idx_out, (size_t)nq * k * 8, &didx));
+  SV_HIP(ctx->s_qnorm.reserve((size_t)nq * 4));
+  SV_TRY(sv_launch_row_sumsq(ctx, (const float*)dq, nq, d, ctx->s_qnorm.as<float>()));
+  // distance-matrix workspace: chunk the queries so that chunk x n floats <= ~2 GiB
+  const int64_t ld = (n + 3) & ~3ll;
+  int64_t chunk = ld > 0 ? (int64_t)(2ll << 30) / (ld * 4) : nq;
+  if (chunk < 128) chunk = 128;
+  if (chunk > nq) chunk = nq;
+  SV_HIP(ctx->s_dist.reserve((size_t)chunk * (ld > 0 ? ld : 1) * 4));
+  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+    const int m = (int)((nq - q0 < chunk) ? (nq - q0) : chunk);
+    {
+      StageScope sc(ctx, "knn_gemm");
+      SV_TRY(sv_launch_gemm_nt(ctx, 1, (const float*)dq + (size_t)q0 * d, ctx->db_rows.as<float>(), ctx->s_dist.as<float>(), m,
+                               (int)n, d, ld, nullptr, nullptr, ctx->s_qnorm.as<float>() + q0, ctx->db_norms.as<float>()));
+      sc.count();
+    }
+    {
+      StageScope sc(ctx, "knn_select");
+      SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld, m, n, k, (float*)dd2 + (size_t)q0 * k,
+                                   (int64_t*)didx + (size_t)q0 * k, k, 0));
+      sc.count();
+    }
+  }
+  return sv_finish(ctx);
+}
+
+int segvlad_merge_topk(segvlad_ctx* ctx, const float* d2_parts, const int64_t* idx_parts, int nq, int parts, int k,
+                       float* d2_out, int64_t* idx_out) {
+  CHECK_CTX();
+  if (nq < 0 || parts < 1 || k < 1) return ctx->fail(SEGVLAD_ERR_ARG, "merge_topk: bad shape");
+  if (nq == 0) return SEGVLAD_OK;
+  if (!d2_parts || !idx_parts || !d2_out || !idx_out) return ctx->fail(SEGVLAD_ERR_ARG, "merge_topk: null pointer");
+  const int cand = parts * k;
+  const void *dd, *di;
+  void *od, *oi;
+  SV_TRY(sv_in(ctx, d2_parts, (size_t)nq * cand * 4, &dd));
+  SV_TRY(sv_in(ctx, idx_parts, (size_t)nq * cand * 8, &di));
+  SV_TRY(sv_out(ctx, d2_out, (size_t)nq * k * 4, &od));
+  SV_TRY(sv_out(ctx, idx_out, (size_t)nq * k * 8, &oi));
+  SV_TRY(sv_launch_merge_topk(ctx, (const float*)dd, (const int64_t*)di, nq, cand, k, (float*)od, (int64_t*)oi));
+  return sv_finish(ctx);
+}
+
+int segvlad_sims_from_d2(segvlad_ctx* ctx, const float* d2, const int64_t* idx, int nq, int k_in, int k_keep,
+                         float* sims_out, int64_t* idx_out) {
+  CHECK_CTX();
+  if (nq < 0 || k_in < 1 || k_keep < 1 || k_keep > k_in) return ctx->fail(SEGVLAD_ERR_ARG, "sims_from_d2: bad shape");
+  if (nq == 0) return SEGVLAD_OK;
+  if (!d2 || !idx || !sims_out || !idx_out) return ctx->fail(SEGVLAD_ERR_ARG, "sims_from_d2: null pointer");
+  const void *dd, *di;
+  void *os, *oi;
+  SV_TRY(sv_in(ctx, d2, (size_t)nq * k_in * 4, &dd));
+  SV_TRY(sv_in(ctx, idx, (size_t)nq * k_in * 8, &di));
+  SV_TRY(sv_out(ctx, sims_out, (size_t)nq * k_keep * 4, &os));
+  SV_TRY(sv_out(ctx, idx_out, (size_t)nq * k_keep * 8, &oi));
+  SV_TRY(sv_launch_sims(ctx, (const float*)dd, (const int64_t*)di, nq, k_in, k_keep, (float*)os, (int64_t*)oi));
+  return sv_finish(ctx);
+}
+
+int segvlad_minmax(segvlad_ctx* ctx, const float* sims, int64_t count, float* minmax_out) {
+  CHECK_CTX();
+  if (count < 0 || !minmax_out) return ctx->fail(SEGVLAD_ERR_ARG, "minmax: bad arguments");
+  const void* ds = sims;
+  void* dout;
+  if (count > 0) {
+    if (!sims) return ctx->fail(SEGVLAD_ERR_ARG, "minmax: null sims");
+    SV_TRY(sv_in(ctx, sims, (size_t)count * 4, &ds));
+  }
+  SV_TRY(sv_out(ctx, minmax_out, 2 * sizeof(float), &dout));
+  SV_TRY(sv_launch_minmax(ctx, (const float*)ds, count, (float*)dout));
+  return sv_finish(ctx);
+}
+
+int segvlad_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const int32_t* img_of_seg,
+                 int64_t n_ref_seg, const int32_t* qseg_offsets, int n_img, int k, float smin, float smax, int n_top, int mode,
+                 int32_t* pred_out, double* score_out) {
+  CHECK_CTX();
+  if (n_img < 0 || k < 1 || n_top < 1) return ctx->fail(SEGVLAD_ERR_ARG, "vote: bad shape");
+  if (mode != SEGVLAD_VOTE_WT_BORDA_IM && mode != SEGVLAD_VOTE_COUNT) return ctx->fail(SEGVLAD_ERR_ARG, "vote: unknown mode %d", mode);
+  if (n_img == 0) return SEGVLAD_OK;
+  if (!idx || !qseg_offsets || !pred_out) return ctx->fail(SEGVLAD_ERR_ARG, "vote: null pointer");
+  if (mode == SEGVLAD_VOTE_WT_BORDA_IM && !sims) return ctx->fail(SEGVLAD_ERR_ARG, "vote: weighted mode needs sims");
+  if (sv_is_device_ptr(qseg_offsets)) return ctx->fail(SEGVLAD_ERR_ARG, "vote: qseg_offsets must be host memory");
+  const int nq = qseg_offsets[n_img];
+  int64_t n_ref = ctx->db_n;
+  const void* dimg = nullptr;
+  if (img_of_seg) {
+    if (n_ref_seg <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "vote: an explicit img_of_seg map needs n_ref_seg > 0");
+    n_ref = n_ref_seg;
+    SV_TRY(sv_in(ctx, img_of_seg, (size_t)n_ref * 4, &dimg));
+  } else {
+    if (!ctx->db_has_img) return ctx->fail(SEGVLAD_ERR_STATE, "vote: no img_of_seg map: give it to segvlad_db_add");
+    dimg = ctx->db_img.p;
+  }
+  const void *di, *ds = nullptr;
+  void *op, *os = nullptr;
+  SV_TRY(sv_in(ctx, idx, (size_t)nq * k * 8, &di));
+  if (sims) SV_TRY(sv_in(ctx, sims, (size_t)nq * k * 4, &ds));
+  SV_TRY(sv_out(ctx, pred_out, (size_t)n_img * n_top * 4, &op));
+  if (score_out) SV_TRY(sv_out(ctx, score_out, (size_t)n_img * n_top * 8, &os));
+  SV_HIP(ctx->s_voteoff.reserve((size_t)(n_img + 1) * 4 + 32));
+  SV_HIP(hipMemcpyAsync(ctx->s_voteoff.p, qseg_offsets, (size_t)(n_img + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  float* mm = reinterpret_cast<float*>(ctx->s_voteoff.as<char>() + (((size_t)(n_img + 1) * 4 + 7) & ~7ull));
+  StageScope sc(ctx, "vote");
+  if (mode == SEGVLAD_VOTE_WT_BORDA_IM) {
+    if (std::isnan(smin) || std::isnan(smax)) {
+      SV_TRY(sv_launch_minmax(ctx, (const float*)ds, (int64_t)nq * k, mm));
+      sc.count(3);
+    } else {
+      const float h[2] = {smin, smax};
+      SV_HIP(hipMemcpyAsync(mm, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+      SV_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  SV_TRY(sv_launch_vote(ctx, (const int64_t*)di, (const float*)ds, (const int32_t*)dimg, n_ref, ctx->s_voteoff.as<int32_t>(),
+                        qseg_offsets, n_img, k, mm, n_top, mode, (int32_t*)op, (double*)os));
+  sc.count();
+  return sv_finish(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// Context, scratch management and launch declarations shared by the SegVLAD HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/segvlad.h"
+
+#define SV_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      return ctx->fail(SEGVLAD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                       __FILE__, __LINE__);                                                       \
+    }                                                                                             \
+  } while (0)
+
+#define SV_TRY(expr)          \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != SEGVLAD_OK) return _r; \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      if (e != hipSuccess) return e;
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct StageTimer {
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int launches = 0;
+  bool valid = false;
+};
+
+struct segvlad_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  bool profiling = false;
+  std::map<std::string, StageTimer> timers;
+
+  // vocabulary
+  int K = 0, D = 0, Kpad = 0;
+  DevBuf vocab;      // [K][D] raw centres
+  DevBuf vocab_bt;   // normalised centres in MFMA-B order [D/2][Kpad/32][64]
+
+  // PCA model
+  int P = 0, KD = 0, whiten = 0;
+  DevBuf pca_mean, pca_comps, pca_scale;  // scale = 1/sqrt(var) or 1
+
+  // database (exact kNN)
+  int db_d = 0;
+  int64_t db_n = 0;
+  DevBuf db_rows, db_norms, db_img;
+  bool db_has_img = false;
+
+  // scratch (grow-only, reused across calls)
+  DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
+  DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff;
+  // staging for host<->device pointers: a small ring, indexed by use inside one call
+  std::vector<DevBuf> stage;
+  struct Pending { void* host; void* dev; size_t bytes; };
+  std::vector<Pending> pending_out;
+  int stage_used = 0;
+
+  int fail(int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+};
+
+// ---- pointer staging ---------------------------------------------------------------------------
+bool sv_is_device_ptr(const void* p);
+// returns a device pointer holding `bytes` of *p (copy enqueued on ctx->stream if p is host memory)
+int sv_in(segvlad_ctx* ctx, const void* p, size_t bytes, const void** dev);
+// returns a device pointer to write into; if p is host memory the D2H copy happens in sv_finish()
+int sv_out(segvlad_ctx* ctx, void* p, size_t bytes, void** dev);
+// flushes pending host outputs (synchronises the stream only if there are any) and resets staging
+int sv_finish(segvlad_ctx* ctx);
+void sv_begin(segvlad_ctx* ctx);
+
+struct StageScope {
+  segvlad_ctx* ctx;
+  StageTimer* t = nullptr;
+  StageScope(segvlad_ctx* c, const char* name);
+  ~StageScope();
+  void count(int n = 1) { if (t) t->launches += n; }
+};
+
+// ---- kernel launchers (defined in the *_kernels.hip units) ---------------------------------------
+// vlad_kernels.hip
+int sv_launch_vocab_prepare(segvlad_ctx* ctx);
+int sv_launch_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                        uint64_t* inc_bits);
+int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* out);
+int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float* xt, uint8_t* labels, float* rnorm,
+                     float* gap);
+int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_bits, const int32_t* seg_off_dev,
+                   const int64_t* adj_off_dev, const uint8_t* adj, int B, int N, int S_max, int SC, uint64_t* colmask,
+                   float* gscale);
+int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
+                        const uint64_t* colmask, const int32_t* seg_off_dev, const float* gscale, int B, int N, int SC,
+                        float* out, float* block_norms);
+
+// gemm_kernels.hip
+int sv_launch_row_sumsq(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* out);
+int sv_launch_normalize_rows(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* Y);
+// C[M][N] = epilogue(A[M][Kd] . B[N][Kd]^T)
+//   mode 0 (PCA):  A' = A - a_sub (a_sub [Kd] or null); C = acc * col_scale[n]
+//   mode 1 (L2):   C = row_add[m] + col_add[n] - 2 acc
+int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
+                      int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
+                      const float* col_add);
+
+// select_kernels.hip
+int sv_launch_select_topk(segvlad_ctx* ctx, const float* dist, int64_t ld, int nq, int64_t n, int k, float* d2_out,
+                          int64_t* idx_out, int64_t out_ld, int64_t id_base);
+int sv_launch_merge_topk(segvlad_ctx* ctx, const float* d2_parts, const int64_t* idx_parts, int nq, int cand, int k,
+                         float* d2_out, int64_t* idx_out);
+int sv_launch_sims(segvlad_ctx* ctx, const float* d2, const int64_t* idx, int nq, int k_in, int k_keep, float* sims,
+                   int64_t* idx_out);
+int sv_launch_minmax(segvlad_ctx* ctx, const float* sims, int64_t count, float* minmax_dev);
+
+// vote_kernels.hip
+int sv_launch_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const int32_t* img_of_seg,
+                   int64_t n_ref_seg, const int32_t* qoff_dev, const int32_t* qoff_host, int n_img, int k,
+                   const float* minmax_dev, int n_top, int mode, int32_t* pred, double* score);

@@ -1,0 +1,216 @@
+// fp32 MFMA "NT" GEMM for gfx950: C[M][N] = epilogue(A[M][Kd] . B[N][Kd]^T), both operands row-major
+// with the reduction dimension contiguous (descriptor rows), exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+//   mode 0 (PCA apply, func_vpr.py:1434-1438): A' = A - a_sub[k];  C = acc * col_scale[n]
+//   mode 1 (exact L2,  place_rec_main.py:53-56): C = row_add[m] + col_add[n] - 2 acc
+//
+// Tile 128x128x32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles.  Operands are staged k-major in
+// LDS ([k][row], +4 pad) so that an MFMA operand read is 32 consecutive dwords per half-wave
+// (conflict-free ds_read_b32); the next k-tile is prefetched into registers while the current one
+// is multiplied.
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = 132;
+
+__device__ __forceinline__ float4 ld4_guard(const float* base, int64_t row, int64_t nrows, int k, int Kd, int64_t ld,
+                                            bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < nrows) {
+    const float* p = base + row * ld + k;
+    if (vec && k + 3 < Kd) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      if (k < Kd) v.x = p[0];
+      if (k + 1 < Kd) v.y = p[1];
+      if (k + 2 < Kd) v.z = p[2];
+      if (k + 3 < Kd) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                      float* __restrict__ C, int M, int N, int Kd, int64_t ldc,
+                                                      const float* __restrict__ a_sub,
+                                                      const float* __restrict__ col_scale,
+                                                      const float* __restrict__ row_add,
+                                                      const float* __restrict__ col_add, int tiles_m) {
+  __shared__ float As[BK * LDT];
+  __shared__ float Bs[BK * LDT];
+  // tile order: m fastest so that the workgroups sharing a B panel (the big operand: database /
+  // PCA components) are adjacent in dispatch order
+  const int tile = blockIdx.x;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int wm = w >> 1, wn = w & 1;
+  const bool vec = ((Kd & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
+  // loader mapping: thread -> (row = tid/8 + 32 j, k quad = (tid & 7) * 4), j = 0..3
+  const int lrow = tid >> 3, lk = (tid & 7) << 2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = ld4_guard(A, m0 + lrow + 32 * j, M, k0 + lk, Kd, Kd, vec);
+      rb[j] = ld4_guard(Bm, n0 + lrow + 32 * j, N, k0 + lk, Kd, Kd, vec);
+    }
+    if (MODE == 0 && a_sub != nullptr) {
+      float4 s = ld4_guard(a_sub, 0, 1, k0 + lk, Kd, 0, vec && ((reinterpret_cast<uintptr_t>(a_sub) & 15) == 0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // rows beyond M stay zero-filled; they are never stored
+        ra[j].x -= s.x;
+        ra[j].y -= s.y;
+        ra[j].z -= s.z;
+        ra[j].w -= s.w;
+      }
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = lrow + 32 * j;
+      As[(lk + 0) * LDT + r] = ra[j].x;
+      As[(lk + 1) * LDT + r] = ra[j].y;
+      As[(lk + 2) * LDT + r] = ra[j].z;
+      As[(lk + 3) * LDT + r] = ra[j].w;
+      Bs[(lk + 0) * LDT + r] = rb[j].x;
+      Bs[(lk + 1) * LDT + r] = rb[j].y;
+      Bs[(lk + 2) * LDT + r] = rb[j].z;
+      Bs[(lk + 3) * LDT + r] = rb[j].w;
+    }
+  };
+
+  const int ntiles = (Kd + BK - 1) / BK;
+  gload(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();  // previous tile's LDS reads are done
+    sstore();
+    __syncthreads();
+    if (kt + 1 < ntiles) gload((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const float* ap = As + (2 * ks + kk) * LDT + wm * 64 + i;
+      const float* bp = Bs + (2 * ks + kk) * LDT + wn * 64 + i;
+      const float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+      acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+      acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+      acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+      acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int64_t col = n0 + wn * 64 + nt * 32 + i;
+    if (col >= N) continue;
+    const float cs = (MODE == 0) ? (col_scale ? col_scale[col] : 1.f) : col_add[col];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row < M) {
+          float v;
+          if (MODE == 0)
+            v = acc[mt][nt][r] * cs;
+          else
+            v = (row_add[row] + cs) - 2.f * acc[mt][nt][r];
+          C[row * ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
+                      int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
+                      const float* col_add) {
+  if (M <= 0 || N <= 0) return SEGVLAD_OK;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "gemm: too many tiles");
+  if (mode == 0)
+    hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A, Bm, C, M, N, Kd, ldc, a_sub,
+                       col_scale, row_add, col_add, tiles_m);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A, Bm, C, M, N, Kd, ldc, a_sub,
+                       col_scale, row_add, col_add, tiles_m);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row sum of squares / row normalisation: one wave per row, 16 B/lane streaming
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float row_sumsq(const float* x, int d, int lane) {
+  float s = 0.f;
+  if (((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int j = lane; j < (d >> 2); j += 64) {
+      const float4 v = x4[j];
+      s = fmaf(v.x, v.x, s);
+      s = fmaf(v.y, v.y, s);
+      s = fmaf(v.z, v.z, s);
+      s = fmaf(v.w, v.w, s);
+    }
+  } else {
+    for (int j = lane; j < d; j += 64) s = fmaf(x[j], x[j], s);
+  }
+  return wave_sum(s);
+}
+
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ X, int64_t n, int d,
+                                                        float* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float s = row_sumsq(X + row * d, d, lane);
+  if (lane == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ X, int64_t n, int d,
+                                                             float* __restrict__ Y) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = X + row * d;
+  float* y = Y + row * d;
+  const float nrm = sqrtf(row_sumsq(x, d, lane));  // no epsilon: func_vpr.py:1675
+  for (int j = lane; j < d; j += 64) y[j] = x[j] / nrm;
+}
+
+int sv_launch_row_sumsq(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* out) {
+  if (n <= 0) return SEGVLAD_OK;
+  hipLaunchKernelGGL(row_sumsq_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, X, n, d, out);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+int sv_launch_normalize_rows(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* Y) {
+  if (n <= 0) return SEGVLAD_OK;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, X, n, d, Y);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}

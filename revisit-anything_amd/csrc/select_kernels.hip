@@ -1,0 +1,301 @@
+// Exact top-k selection over a row of squared distances (faiss.IndexFlatL2.search semantics:
+// ascending, place_rec_main.py:56-60), shard merge, "2 - d^2" slice (place_rec_main.py:78-81) and the
+// global min/max (func_vpr.py:212-213).
+//
+// select_topk_kernel: one workgroup per query row.  MSB-first 8-bit radix select on the order-
+// preserving integer image of the distances finds the k-th smallest key (histograms in LDS, with
+// wave-aggregated atomics: distances share their exponent byte, so a naive LDS histogram would
+// serialise 64-way); one more pass collects the k candidates, a bitonic sort on (key, index) orders
+// them.  Ties are resolved towards the lower index, like a stable argsort.
+#include "ctx.h"
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// wave-aggregated histogram increment: lanes that share a bin elect one leader per round
+__device__ __forceinline__ void hist_add(uint32_t* hist, bool active, uint32_t bin) {
+  uint64_t todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t lb = __shfl(bin, leader);
+    const uint64_t same = __ballot(active && bin == lb) & todo;
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void bitonic_sort_lds(T* a, int n /*pow2*/, int tid, int nthreads) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (n >> 1); t += nthreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const T x = a[lo], y = a[hi];
+        if ((y < x) == up) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void select_topk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k,
+                                                          int kpad, float* __restrict__ d2_out,
+                                                          int64_t* __restrict__ idx_out, int64_t out_ld,
+                                                          int64_t id_base) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* cand = reinterpret_cast<uint64_t*>(smem);  // [kpad]
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_digit, s_krem, s_ceq, s_nless, s_neq;
+  __shared__ uint32_t wcnt[4];
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const float* x = dist + row * ld;
+  const int kk = (int)((int64_t)k < n ? k : n);
+
+  uint32_t prefix = 0, mask = 0, krem = (uint32_t)kk, ceq = 0;
+  if (kk > 0) {
+    for (int pass = 3; pass >= 0; --pass) {
+      hist[tid] = 0;
+      __syncthreads();
+      const int shift = 8 * pass;
+      for (int64_t j0 = 0; j0 < n; j0 += 256) {
+        const int64_t j = j0 + tid;
+        bool act = j < n;
+        uint32_t key = act ? f2key(x[j]) : 0u;
+        act = act && ((key & mask) == prefix);
+        hist_add(hist, act, (key >> shift) & 255u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0, dsel = 255;
+        for (uint32_t b = 0; b < 256; ++b) {
+          const uint32_t h = hist[b];
+          if (cum + h >= krem) {
+            dsel = b;
+            break;
+          }
+          cum += h;
+        }
+        s_digit = dsel;
+        s_krem = krem - cum;
+        s_ceq = hist[dsel];
+      }
+      __syncthreads();
+      prefix |= s_digit << shift;
+      mask |= 255u << shift;
+      krem = s_krem;
+      ceq = s_ceq;
+      __syncthreads();
+    }
+  }
+  // prefix = k-th smallest key; krem = how many elements equal to it belong to the top-k; ceq = how many exist
+  for (int j = tid; j < kpad; j += 256) cand[j] = ~0ull;
+  if (tid == 0) {
+    s_nless = 0;
+    s_neq = 0;
+  }
+  __syncthreads();
+  if (kk > 0) {
+    const uint32_t nless = (uint32_t)kk - krem;
+    if (ceq == krem) {
+      // common case: every element equal to the threshold is taken -> unordered collection
+      for (int64_t j0 = 0; j0 < n; j0 += 256) {
+        const int64_t j = j0 + tid;
+        if (j < n) {
+          const uint32_t key = f2key(x[j]);
+          if (key <= prefix) {
+            const uint32_t slot = atomicAdd(&s_nless, 1u);
+            cand[slot] = ((uint64_t)key << 32) | (uint32_t)j;
+          }
+        }
+      }
+    } else {
+      // boundary ties: take the krem LOWEST indices among the equal elements (ordered scan)
+      for (int64_t j0 = 0; j0 < n; j0 += 256) {
+        const int64_t j = j0 + tid;
+        const bool in = j < n;
+        const uint32_t key = in ? f2key(x[j]) : ~0u;
+        if (in && key < prefix) {
+          const uint32_t slot = atomicAdd(&s_nless, 1u);
+          cand[slot] = ((uint64_t)key << 32) | (uint32_t)j;
+        }
+        const bool eq = in && key == prefix;
+        // ordered rank of this equal element: previous chunks (s_neq) + lower threads of this chunk
+        const uint64_t bal = __ballot(eq);
+        if ((tid & 63) == 0) wcnt[tid >> 6] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = s_neq;
+        for (int ww = 0; ww < (tid >> 6); ++ww) before += wcnt[ww];
+        before += (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if (eq && before < krem) cand[nless + before] = ((uint64_t)key << 32) | (uint32_t)j;
+        __syncthreads();
+        if (tid == 0) s_neq += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  bitonic_sort_lds(cand, kpad, tid, 256);
+  for (int j = tid; j < k; j += 256) {
+    float d = INFINITY;
+    int64_t id = -1;
+    if (j < kk) {
+      const uint64_t c = cand[j];
+      d = key2f((uint32_t)(c >> 32));
+      id = id_base + (int64_t)(uint32_t)c;
+    }
+    d2_out[row * out_ld + j] = d;
+    idx_out[row * out_ld + j] = id;
+  }
+}
+
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+int sv_launch_select_topk(segvlad_ctx* ctx, const float* dist, int64_t ld, int nq, int64_t n, int k, float* d2_out,
+                          int64_t* idx_out, int64_t out_ld, int64_t id_base) {
+  if (nq <= 0) return SEGVLAD_OK;
+  if (n >= (1ll << 32)) return ctx->fail(SEGVLAD_ERR_LIMIT, "select: more than 2^32-1 rows per shard");
+  const int kpad = next_pow2(k < 2 ? 2 : k);
+  hipLaunchKernelGGL(select_topk_kernel, dim3(nq), dim3(256), (size_t)kpad * 8, ctx->stream, dist, ld, n, k, kpad, d2_out,
+                     idx_out, out_ld, id_base);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of per-shard lists: sort (key, id) pairs; id -1 (empty slot) sorts last
+// ------------------------------------------------------------------------------------------------
+struct KeyId {
+  uint32_t key;
+  uint32_t pad;
+  int64_t id;
+  __device__ bool operator<(const KeyId& o) const { return key < o.key || (key == o.key && id < o.id); }
+};
+
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ d2p, const int64_t* __restrict__ idp,
+                                                         int cand, int cpad, int k, float* __restrict__ d2_out,
+                                                         int64_t* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  KeyId* a = reinterpret_cast<KeyId*>(smem);
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  for (int j = tid; j < cpad; j += 256) {
+    KeyId e;
+    e.key = ~0u;
+    e.pad = 0;
+    e.id = INT64_MAX;
+    if (j < cand) {
+      const int64_t id = idp[row * cand + j];
+      if (id >= 0) {
+        e.key = f2key(d2p[row * cand + j]);
+        e.id = id;
+      }
+    }
+    a[j] = e;
+  }
+  bitonic_sort_lds(a, cpad, tid, 256);
+  for (int j = tid; j < k; j += 256) {
+    float d = INFINITY;
+    int64_t id = -1;
+    if (j < cand && a[j].id != INT64_MAX) {
+      d = key2f(a[j].key);
+      id = a[j].id;
+    }
+    d2_out[row * k + j] = d;
+    idx_out[row * k + j] = id;
+  }
+}
+
+int sv_launch_merge_topk(segvlad_ctx* ctx, const float* d2_parts, const int64_t* idx_parts, int nq, int cand, int k,
+                         float* d2_out, int64_t* idx_out) {
+  if (nq <= 0) return SEGVLAD_OK;
+  const int cpad = next_pow2(cand < 2 ? 2 : cand);
+  const size_t lds = (size_t)cpad * sizeof(KeyId);
+  if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "merge: %d candidates per query exceed the LDS sort (max 8192)", cand);
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), lds, ctx->stream, d2_parts, idx_parts, cand, cpad, k, d2_out,
+                     idx_out);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void sims_kernel(const float* __restrict__ d2, const int64_t* __restrict__ idx, int64_t total, int k_in,
+                            int k_keep, float* __restrict__ sims, int64_t* __restrict__ idx_out) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= total) return;
+  const int64_t q = o / k_keep;
+  const int r = (int)(o - q * k_keep);
+  sims[o] = 2.0f - d2[q * k_in + r];
+  idx_out[o] = idx[q * k_in + r];
+}
+
+int sv_launch_sims(segvlad_ctx* ctx, const float* d2, const int64_t* idx, int nq, int k_in, int k_keep, float* sims,
+                   int64_t* idx_out) {
+  const int64_t total = (int64_t)nq * k_keep;
+  if (total <= 0) return SEGVLAD_OK;
+  hipLaunchKernelGGL(sims_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d2, idx, total, k_in,
+                     k_keep, sims, idx_out);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// global min/max: integer atomics on the order-preserving key (exact, order-independent)
+// ------------------------------------------------------------------------------------------------
+__global__ void minmax_init_kernel(uint32_t* mm) {
+  mm[0] = ~0u;
+  mm[1] = 0u;
+}
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, int64_t n, uint32_t* mm) {
+  uint32_t lo = ~0u, hi = 0u;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+    const uint32_t key = f2key(x[j]);
+    lo = min(lo, key);
+    hi = max(hi, key);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[0], lo);
+    atomicMax(&mm[1], hi);
+  }
+}
+__global__ void minmax_final_kernel(const uint32_t* mm, float* out) {
+  out[0] = key2f(mm[0]);
+  out[1] = key2f(mm[1]);
+}
+
+int sv_launch_minmax(segvlad_ctx* ctx, const float* sims, int64_t count, float* minmax_dev) {
+  SV_HIP(ctx->s_minmax.reserve(2 * sizeof(uint32_t)));
+  uint32_t* mm = ctx->s_minmax.as<uint32_t>();
+  hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, ctx->stream, mm);
+  if (count > 0) {
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sims, count, mm);
+  }
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1), 0, ctx->stream, mm, minmax_dev);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}

@@ -1,0 +1,546 @@
+// Segment-VLAD kernels for gfx950 (MI355X).  Reference semantics: func_vpr.py:1065-1210.
+//
+//   incidence_kernel   masks -> token-incidence bit rows            (func_vpr.py:1088-1092)
+//   centroid_kernel    mask centroids for the Delaunay adjacency     (func_vpr.py:1314)
+//   assign_kernel      tokens [D][N] -> labels, 1/||x||, top-2 gap, and the token-major copy
+//                      Xt [N][D] that the aggregation streams          (func_vpr.py:1085,1145-1146)
+//   prep_kernel        neighbour union (adj . inc) > 0, column masks, 1/sqrt(#non-empty blocks)
+//                                                                      (func_vpr.py:1199-1200,1205)
+//   aggregate_kernel   per (image, cluster): masked residual sums on the fp32 MFMA, intra-norm,
+//                      global norm, packed store                      (func_vpr.py:1151,1195-1205)
+//
+// Wave = 64 lanes.  The two GEMM-shaped stages run on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// row of D-fragment register r for lane half kk (v_mfma_f32_32x32x2_f32 C/D layout)
+__device__ __forceinline__ int frag_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
+
+// ------------------------------------------------------------------------------------------------
+// vocabulary: c^ = C / max(||C||, 1e-12), stored in MFMA B-operand order
+//   bt[((dp * NT) + nt) * 64 + l] = c^[32 nt + (l & 31)][2 dp + (l >> 5)]   (0 outside K x D)
+// ------------------------------------------------------------------------------------------------
+__global__ void vocab_norm_kernel(const float* __restrict__ C, int K, int D, float* __restrict__ inv) {
+  const int k = blockIdx.x;
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float v = C[(size_t)k * D + d];
+    s = fmaf(v, v, s);
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) inv[k] = 1.0f / fmaxf(sqrtf(red[0]), 1e-12f);
+}
+
+__global__ void vocab_bt_kernel(const float* __restrict__ C, const float* __restrict__ inv, int K, int D, int NT,
+                                int npairs, float* __restrict__ bt) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)npairs * NT * 64;
+  if (idx >= total) return;
+  const int l = idx & 63;
+  const int nt = (idx >> 6) % NT;
+  const int dp = (idx >> 6) / NT;
+  const int k = 32 * nt + (l & 31), d = 2 * dp + (l >> 5);
+  bt[idx] = (k < K && d < D) ? C[(size_t)k * D + d] * inv[k] : 0.f;
+}
+
+int sv_launch_vocab_prepare(segvlad_ctx* ctx) {
+  const int K = ctx->K, D = ctx->D, NT = ctx->Kpad / 32;
+  const int npairs = ((D + 63) / 64) * 32;
+  SV_HIP(ctx->vocab_bt.reserve((size_t)npairs * NT * 64 * sizeof(float)));
+  SV_HIP(ctx->s_misc.reserve((size_t)K * sizeof(float)));
+  hipLaunchKernelGGL(vocab_norm_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->vocab.as<float>(), K, D,
+                     ctx->s_misc.as<float>());
+  const size_t total = (size_t)npairs * NT * 64;
+  hipLaunchKernelGGL(vocab_bt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->vocab.as<float>(), ctx->s_misc.as<float>(), K, D, NT, npairs, ctx->vocab_bt.as<float>());
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// incidence: one wave per (segment, 64-token word); lane = token.  The up-sampled pixel block of a
+// token is walked through its distinct SOURCE rows/cols (nearest: src = min(floor(dst*scale), in-1)).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void incidence_kernel(const uint8_t* __restrict__ masks, int Hm, int Wm, int H, int W,
+                                                        int patch, int dh, int dw, float sh, float sw,
+                                                        uint64_t* __restrict__ inc, int nw) {
+  const int s = blockIdx.x;
+  const int word = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (word >= nw) return;
+  const int lane = threadIdx.x & 63;
+  const int N = dh * dw;
+  const int t = word * 64 + lane;
+  bool any = false;
+  if (t < N) {
+    const int ty = t / dw, tx = t - ty * dw;
+    const int i0 = ty * patch, i1 = (ty == dh - 1) ? H - 1 : i0 + patch - 1;
+    const int j0 = tx * patch, j1 = (tx == dw - 1) ? W - 1 : j0 + patch - 1;
+    const uint8_t* m = masks + (size_t)s * Hm * Wm;
+    int pr = -1;
+    for (int i = i0; i <= i1 && !any; ++i) {
+      int r = min((int)floorf((float)i * sh), Hm - 1);
+      if (r == pr) continue;
+      pr = r;
+      const uint8_t* row = m + (size_t)r * Wm;
+      int pc = -1;
+      for (int j = j0; j <= j1; ++j) {
+        int c = min((int)floorf((float)j * sw), Wm - 1);
+        if (c == pc) continue;
+        pc = c;
+        if (row[c]) { any = true; break; }
+      }
+    }
+  }
+  const uint64_t b = __ballot(any);
+  if (lane == 0) inc[(size_t)s * nw + word] = b;
+}
+
+int sv_launch_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                        uint64_t* inc_bits) {
+  const int dh = H / patch, dw = W / patch;
+  const int N = dh * dw, nw = (N + 63) / 64;
+  const float sh = (float)Hm / (float)H, sw = (float)Wm / (float)W;
+  if (S == 0) return SEGVLAD_OK;
+  hipLaunchKernelGGL(incidence_kernel, dim3(S, (nw + 3) / 4), dim3(256), 0, ctx->stream, masks, Hm, Wm, H, W, patch, dh,
+                     dw, sh, sw, inc_bits, nw);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// centroids: exact integer sums of the non-zero (row, col), divided in fp64 -> bit-identical to
+// np.nonzero(mask).mean(1)[::-1]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void centroid_kernel(const uint8_t* __restrict__ masks, int Hm, int Wm,
+                                                       double* __restrict__ out) {
+  const int s = blockIdx.x;
+  const uint8_t* m = masks + (size_t)s * Hm * Wm;
+  unsigned long long sr = 0, sc = 0, cnt = 0;
+  const int total = Hm * Wm;
+  for (int p = threadIdx.x; p < total; p += 256) {
+    if (m[p]) {
+      const int r = p / Wm;
+      sr += r;
+      sc += p - r * Wm;
+      ++cnt;
+    }
+  }
+  __shared__ unsigned long long red[3][256];
+  red[0][threadIdx.x] = sr;
+  red[1][threadIdx.x] = sc;
+  red[2][threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double c = (double)red[2][0];
+    out[2 * s + 0] = (double)red[1][0] / c;  // x = mean col
+    out[2 * s + 1] = (double)red[0][0] / c;  // y = mean row
+  }
+}
+
+int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* out) {
+  if (S == 0) return SEGVLAD_OK;
+  hipLaunchKernelGGL(centroid_kernel, dim3(S), dim3(256), 0, ctx->stream, masks, Hm, Wm, out);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// assign: workgroup = (image, 64-token tile), 4 waves split D in 64-wide chunks.
+//   A operand  (32 tokens x 2 d):  lane (i = l&31, kk = l>>5) loads T[d0+kk][t0+2i .. 2i+1]  (8 B/lane,
+//              256 B contiguous per half-wave) -> M-tile 0 = even tokens, M-tile 1 = odd tokens
+//   B operand  (2 d x 32 centres): pre-swizzled bt, 256 B contiguous per wave-load
+// The raw values are also staged through a wave-private LDS tile and written token-major (Xt).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ T, int N, int D, int K,
+                                                     const float* __restrict__ bt, float* __restrict__ Xt,
+                                                     uint8_t* __restrict__ labels, float* __restrict__ rnorm,
+                                                     float* __restrict__ gap) {
+  __shared__ float lds[4 * 64 * 65];
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const float* Tb = T + (size_t)b * D * N;
+  float* tile = lds + w * (64 * 65);
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
+  float ss0 = 0.f, ss1 = 0.f;
+  const int ta = t0 + 2 * i;
+  const bool v0 = ta < N, v1 = ta + 1 < N;
+  const bool evenN = (N & 1) == 0;
+  const int nchunks = (D + 63) >> 6;
+  for (int ch = w; ch < nchunks; ch += 4) {
+    const int dbase = ch << 6;
+#pragma unroll 8
+    for (int st = 0; st < 32; ++st) {
+      const int d = dbase + 2 * st + kk;
+      float x0 = 0.f, x1 = 0.f;
+      if (d < D) {
+        const float* p = Tb + (size_t)d * N + ta;
+        if (v1 && evenN) {
+          const float2 v = *reinterpret_cast<const float2*>(p);
+          x0 = v.x;
+          x1 = v.y;
+        } else {
+          if (v0) x0 = p[0];
+          if (v1) x1 = p[1];
+        }
+      }
+      ss0 = fmaf(x0, x0, ss0);
+      ss1 = fmaf(x1, x1, ss1);
+      const float* bp = bt + ((size_t)((dbase >> 1) + st) * NT) * 64 + l;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float bv = bp[n * 64];
+        acc[0][n] = MFMA32(x0, bv, acc[0][n]);
+        acc[1][n] = MFMA32(x1, bv, acc[1][n]);
+      }
+      tile[(2 * i) * 65 + 2 * st + kk] = x0;
+      tile[(2 * i + 1) * 65 + 2 * st + kk] = x1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int idx = it * 64 + l;
+      const int tok = idx >> 4, c4 = (idx & 15) << 2;
+      if (t0 + tok < N && dbase + c4 < D) {
+        const float* q = tile + tok * 65 + c4;
+        float4 v = make_float4(q[0], q[1], q[2], q[3]);
+        *reinterpret_cast<float4*>(Xt + ((size_t)b * N + t0 + tok) * D + dbase + c4) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // ---- combine the four D-slices (fixed order w = 0..3: deterministic) ---------------------------
+  ss0 += __shfl_xor(ss0, 32);
+  ss1 += __shfl_xor(ss1, 32);
+  __syncthreads();
+  constexpr int KP = NT * 32;
+  float* sc = lds;                    // [64][KP+1]
+  float* ssum = lds + 64 * (KP + 1);  // [4][64]
+  if (kk == 0) {
+    ssum[w * 64 + 2 * i] = ss0;
+    ssum[w * 64 + 2 * i + 1] = ss1;
+  }
+  for (int rnd = 0; rnd < 4; ++rnd) {
+    if (w == rnd) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tok = 2 * frag_row(r, kk) + mt;
+            float* p = &sc[tok * (KP + 1) + n * 32 + i];
+            *p = (rnd == 0) ? acc[mt][n][r] : (*p + acc[mt][n][r]);
+          }
+    }
+    __syncthreads();
+  }
+  if (tid < 64 && t0 + tid < N) {
+    const float s2 = ((ssum[tid] + ssum[64 + tid]) + ssum[128 + tid]) + ssum[192 + tid];
+    const float rn = 1.0f / fmaxf(sqrtf(s2), 1e-12f);
+    float best = -INFINITY, second = -INFINITY;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+      const float v = sc[tid * (KP + 1) + k];
+      if (v > best) {
+        second = best;
+        best = v;
+        bi = k;
+      } else if (v > second) {
+        second = v;
+      }
+    }
+    const size_t o = (size_t)b * N + t0 + tid;
+    labels[o] = (uint8_t)bi;
+    rnorm[o] = rn;
+    if (gap) gap[o] = (K > 1) ? (best - second) * rn : INFINITY;
+  }
+}
+
+int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float* xt, uint8_t* labels, float* rnorm,
+                     float* gap) {
+  const int NT = ctx->Kpad / 32;
+  dim3 grid((N + 63) / 64, B), block(256);
+  const float* bt = ctx->vocab_bt.as<float>();
+  switch (NT) {
+    case 1:
+      hipLaunchKernelGGL(assign_kernel<1>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      break;
+    case 2:
+      hipLaunchKernelGGL(assign_kernel<2>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      break;
+    case 4:
+      hipLaunchKernelGGL(assign_kernel<4>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      break;
+    default:
+      return ctx->fail(SEGVLAD_ERR_LIMIT, "K=%d: supported cluster counts are 1..64 and 97..128 (Kpad in {32,64,128})", ctx->K);
+  }
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: one workgroup per image.
+//   inc2[s] = OR_{u : adj[s][u]} inc[u]                       (adj . inc) > 0
+//   colmask[t][sc] bit (s - 64 sc) = inc2[s][t]               column form consumed by the aggregation
+//   gscale[s] = 1/sqrt(#clusters k with a token t: label_t = k and inc2[s][t])
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ labels, const uint64_t* __restrict__ inc,
+                                                   const int32_t* __restrict__ seg_off,
+                                                   const int64_t* __restrict__ adj_off, const uint8_t* __restrict__ adj,
+                                                   int N, int K, int S_max, int SC, uint64_t* __restrict__ colmask,
+                                                   float* __restrict__ gscale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int nw = (N + 63) >> 6;
+  const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
+  uint64_t* inc2 = reinterpret_cast<uint64_t*>(smem);  // [S_max][nw]
+  uint64_t* lbits = inc2 + (size_t)S_max * nw;         // [K][nw]
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < S * nw; idx += 256) {
+    const int s = idx / nw, w = idx - s * nw;
+    uint64_t v = 0;
+    if (adj) {
+      const uint8_t* a = adj + adj_off[b] + (size_t)s * S;
+      for (int u = 0; u < S; ++u)
+        if (a[u]) v |= inc[(size_t)(s0 + u) * nw + w];
+    } else {
+      v = inc[(size_t)(s0 + s) * nw + w];
+    }
+    inc2[idx] = v;
+  }
+  for (int idx = tid; idx < K * nw; idx += 256) lbits[idx] = 0;
+  __syncthreads();
+  for (int t = tid; t < N; t += 256) {
+    const int lab = labels[(size_t)b * N + t];
+    atomicOr(reinterpret_cast<unsigned long long*>(&lbits[lab * nw + (t >> 6)]), 1ull << (t & 63));
+  }
+  for (int t = tid; t < N; t += 256) {
+    const int w = t >> 6, bit = t & 63;
+    for (int sc = 0; sc < SC; ++sc) {
+      uint64_t m = 0;
+      const int lo = sc * 64, hi = min(S, lo + 64);
+      for (int s = lo; s < hi; ++s) m |= ((inc2[s * nw + w] >> bit) & 1ull) << (s - lo);
+      colmask[((size_t)b * N + t) * SC + sc] = m;
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += 256) {
+    int nnz = 0;
+    for (int k = 0; k < K; ++k) {
+      uint64_t any = 0;
+      for (int w = 0; w < nw; ++w) any |= inc2[s * nw + w] & lbits[k * nw + w];
+      nnz += (any != 0);
+    }
+    gscale[s0 + s] = nnz > 0 ? (float)(1.0 / sqrt((double)nnz)) : 0.f;
+  }
+}
+
+int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_bits, const int32_t* seg_off_dev,
+                   const int64_t* adj_off_dev, const uint8_t* adj, int B, int N, int S_max, int SC, uint64_t* colmask,
+                   float* gscale) {
+  const int nw = (N + 63) / 64;
+  const size_t lds = ((size_t)S_max + ctx->K) * nw * sizeof(uint64_t);
+  if (lds > 160 * 1024)
+    return ctx->fail(SEGVLAD_ERR_LIMIT, "prep: (S_max=%d + K=%d) x %d token words needs %zu B of LDS (limit 160 KiB)", S_max,
+                     ctx->K, nw, lds);
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, ctx->stream, labels, inc_bits, seg_off_dev, adj_off_dev, adj, N,
+                     ctx->K, S_max, SC, colmask, gscale);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// aggregate: workgroup = (cluster k, image b); wave w owns d in [128 w, 128 w + 128).
+//   V[s][k][d] = sum_{t in L_k} inc2[s][t] * (x_t[d] * rn_t - C[k][d])
+// as an MFMA product  (32 segments x 2 tokens) . (2 tokens x 32 d):
+//   A[i][kk] = bit (32 mt + i) of colmask[t_kk]   (0/1 exact)
+//   B[kk][j] = fma(Xt[t_kk][dcol + 4 j + q], rn, -C[k][...])   q = N-tile; one 16-B load feeds 4 N-tiles
+// then ||V[s,k,:]|| (LDS reduction across the waves), scale by gscale[s]/max(norm,1e-12), store packed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
+                                                        const uint8_t* __restrict__ labels,
+                                                        const uint64_t* __restrict__ colmask,
+                                                        const float* __restrict__ C, const int32_t* __restrict__ seg_off,
+                                                        const float* __restrict__ gscale, int N, int D, int K, int SC,
+                                                        int Ncap, float* __restrict__ out,
+                                                        float* __restrict__ block_norms) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int nwaves = blockDim.x >> 6;
+  const int PW = nwaves * 8 + 1;
+  uint64_t* mskl = reinterpret_cast<uint64_t*>(smem);         // [Ncap]
+  int* tokl = reinterpret_cast<int*>(mskl + Ncap);            // [Ncap]
+  float* rnl = reinterpret_cast<float*>(tokl + Ncap);         // [Ncap]
+  float* part = rnl + Ncap;                                   // [64][PW]
+  float* alpha = part + 64 * PW;                              // [64]
+  int* wcount = reinterpret_cast<int*>(alpha + 64);           // [16]
+
+  // ---- L_k: ordered compaction of the tokens assigned to cluster k --------------------------------
+  int base = 0;
+  for (int r0 = 0; r0 < N; r0 += blockDim.x) {
+    const int t = r0 + tid;
+    const bool flag = (t < N) && (labels[(size_t)b * N + t] == k);
+    const uint64_t bal = __ballot(flag);
+    const int wp = __popcll(bal & ((1ull << l) - 1ull));
+    if (l == 0) wcount[w] = __popcll(bal);
+    __syncthreads();
+    int off = base, tot = 0;
+    for (int ww = 0; ww < nwaves; ++ww) {
+      const int c = wcount[ww];
+      if (ww < w) off += c;
+      tot += c;
+    }
+    if (flag) {
+      tokl[off + wp] = t;
+      rnl[off + wp] = rnorm[(size_t)b * N + t];
+    }
+    base += tot;
+    __syncthreads();
+  }
+  const int n = base;
+  if (tid == 0 && (n & 1)) {  // pad to an even count with a zero-weight entry
+    tokl[n] = 0;
+    rnl[n] = 0.f;
+  }
+  const int npairs = (n + 1) >> 1;
+  const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
+  const int dcol = w * 128 + 4 * i;
+  const bool dvalid = dcol < D;
+  float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dvalid) c4 = *reinterpret_cast<const float4*>(C + (size_t)k * D + dcol);
+  const float* Xb = Xt + (size_t)b * N * D + dcol;
+  const size_t KD = (size_t)K * D;
+  const int SCb = (S + 63) >> 6;
+
+  for (int sc = 0; sc < SCb; ++sc) {
+    for (int j = tid; j < n; j += blockDim.x) mskl[j] = colmask[((size_t)b * N + tokl[j]) * SC + sc];
+    if (tid == 0 && (n & 1)) mskl[n] = 0;
+    __syncthreads();
+    const int Sc = min(64, S - 64 * sc);
+    const bool two = Sc > 32;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
+
+#pragma unroll 2
+    for (int p = 0; p < npairs; ++p) {
+      const int j = 2 * p + kk;
+      const int t = tokl[j];
+      const float rn = rnl[j];
+      const uint64_t m = mskl[j];
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dvalid) x = *reinterpret_cast<const float4*>(Xb + (size_t)t * D);
+      const float b0 = fmaf(x.x, rn, -c4.x), b1 = fmaf(x.y, rn, -c4.y);
+      const float b2 = fmaf(x.z, rn, -c4.z), b3 = fmaf(x.w, rn, -c4.w);
+      const float a0 = ((m >> i) & 1ull) ? 1.f : 0.f;
+      acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+      acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+      acc[0][2] = MFMA32(a0, b2, acc[0][2]);
+      acc[0][3] = MFMA32(a0, b3, acc[0][3]);
+      if (two) {
+        const float a1 = ((m >> (32 + i)) & 1ull) ? 1.f : 0.f;
+        acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+        acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+        acc[1][2] = MFMA32(a1, b2, acc[1][2]);
+        acc[1][3] = MFMA32(a1, b3, acc[1][3]);
+      }
+    }
+    // ---- block norms: quad reduce in registers, then across lanes/waves through LDS ----------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (mt == 1 && !two) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = acc[mt][0][r] * acc[mt][0][r];
+        p = fmaf(acc[mt][1][r], acc[mt][1][r], p);
+        p = fmaf(acc[mt][2][r], acc[mt][2][r], p);
+        p = fmaf(acc[mt][3][r], acc[mt][3][r], p);
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        if ((l & 3) == 0) part[(32 * mt + frag_row(r, kk)) * PW + w * 8 + (i >> 2)] = p;
+      }
+    }
+    __syncthreads();
+    if (tid < Sc) {
+      float sum = 0.f;
+      const int cnt = nwaves * 8;
+      for (int c = 0; c < cnt; ++c) sum += part[tid * PW + c];
+      const float nrm = sqrtf(sum);
+      const int sg = s0 + 64 * sc + tid;
+      alpha[tid] = gscale[sg] / fmaxf(nrm, 1e-12f);
+      if (block_norms) block_norms[(size_t)sg * K + k] = nrm;
+    }
+    __syncthreads();
+    if (dvalid) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !two) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * mt + frag_row(r, kk);
+          if (row < Sc) {
+            const float a = alpha[row];
+            float4 v = make_float4(acc[mt][0][r] * a, acc[mt][1][r] * a, acc[mt][2][r] * a, acc[mt][3][r] * a);
+            *reinterpret_cast<float4*>(out + (size_t)(s0 + 64 * sc + row) * KD + (size_t)k * D + dcol) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
+                        const uint64_t* colmask, const int32_t* seg_off_dev, const float* gscale, int B, int N, int SC,
+                        float* out, float* block_norms) {
+  const int D = ctx->D, K = ctx->K;
+  const int nwaves = (D + 127) / 128;
+  if (nwaves > 12)
+    return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: D=%d exceeds the 1536-wide workgroup of this build", D);
+  const int Ncap = (N + 2) & ~1;
+  const int PW = nwaves * 8 + 1;
+  const size_t lds = (size_t)Ncap * 16 + (size_t)(64 * PW + 64) * sizeof(float) + 16 * sizeof(int);
+  if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: N=%d tokens need %zu B of LDS (limit 160 KiB)", N, lds);
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(aggregate_kernel, dim3(K, B), dim3(nwaves * 64), lds, ctx->stream, xt, rnorm, labels, colmask,
+                     ctx->vocab.as<float>(), seg_off_dev, gscale, N, D, K, SC, Ncap, out, block_norms);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}

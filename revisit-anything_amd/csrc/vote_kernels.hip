@@ -1,0 +1,175 @@
+// Similarity-weighted image vote (get_matches "max_seg_topk_wt_borda_Im" + weighted_borda_count,
+// func_vpr.py:61-77, 207-224) and the integer variant ("max_seg_topk", func_vpr.py:118-125).
+//
+// One workgroup per query image.  The reference walks the (rank, segment) entries rank-major and
+// adds python floats (fp64) into a dict keyed by reference IMAGE id, then sorts the keys by score,
+// descending and stable (ties keep first-appearance order).  To reproduce the fp64 sums bit for bit
+// the entries are sorted by (image id, visiting order) in LDS and every distinct image is summed
+// sequentially, in visiting order, by one thread.  The weights are formed in fp32 exactly as NumPy
+// does: (s - s_min) / (s_max - s_min) with the GLOBAL extrema.
+#include "ctx.h"
+
+struct Run {
+  double score;
+  uint32_t first;  // visiting order of the first appearance
+  int32_t img;
+};
+
+__device__ __forceinline__ void bitonic_u64(uint64_t* a, int n, int tid, int nthreads) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (n >> 1); t += nthreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const uint64_t x = a[lo], y = a[hi];
+        if ((y < x) == up) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// better(a, b): a ranks before b
+__device__ __forceinline__ bool better(double sa, uint32_t ta, double sb, uint32_t tb) {
+  return sa > sb || (sa == sb && ta < tb);
+}
+
+__global__ __launch_bounds__(256) void vote_kernel(const int64_t* __restrict__ idx, const float* __restrict__ sims,
+                                                   const int32_t* __restrict__ img_of_seg, int64_t n_ref_seg,
+                                                   const int32_t* __restrict__ qoff, int k,
+                                                   const float* __restrict__ minmax, int n_top, int mode,
+                                                   Run* __restrict__ runs_scratch, int64_t runs_stride,
+                                                   int32_t* __restrict__ pred, double* __restrict__ score) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  __shared__ uint32_t s_nruns;
+  __shared__ double r_score[256];
+  __shared__ uint32_t r_tie[256];
+  __shared__ int r_pos[256];
+  const int tid = threadIdx.x;
+  const int qi = blockIdx.x;
+  const int q0 = qoff[qi], Sq = qoff[qi + 1] - q0;
+  const int E = Sq * k;
+  int Epad = 2;
+  while (Epad < E) Epad <<= 1;
+  const float smin = minmax[0], smax = minmax[1];
+  const float den = smax - smin;
+
+  // visiting order o = rank * Sq + seg  (rank-major, then segment: func_vpr.py:216 zips the transposed lists)
+  for (int o = tid; o < Epad; o += 256) {
+    uint64_t key = ~0ull;
+    if (o < E) {
+      const int rank = o / Sq, seg = o - rank * Sq;
+      const int64_t m = idx[(int64_t)(q0 + seg) * k + rank];
+      if (m >= 0 && m < n_ref_seg) key = ((uint64_t)(uint32_t)img_of_seg[m] << 32) | (uint32_t)o;
+    }
+    keys[o] = key;
+  }
+  if (tid == 0) s_nruns = 0;
+  bitonic_u64(keys, Epad, tid, 256);
+
+  Run* runs = runs_scratch + (int64_t)qi * runs_stride;
+  for (int p = tid; p < E; p += 256) {
+    const uint64_t key = keys[p];
+    if (key == ~0ull) continue;
+    const uint32_t img = (uint32_t)(key >> 32);
+    if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == img) continue;  // not a run start
+    double acc = 0.0;
+    uint32_t cnt = 0;
+    int e = p;
+    while (e < E) {
+      const uint64_t ke = keys[e];
+      if (ke == ~0ull || (uint32_t)(ke >> 32) != img) break;
+      if (mode == SEGVLAD_VOTE_WT_BORDA_IM) {
+        const uint32_t o = (uint32_t)ke;
+        const int rank = o / Sq, seg = o - rank * Sq;
+        const float s = sims[(int64_t)(q0 + seg) * k + rank];
+        const float wgt = (s - smin) / den;
+        acc += (double)wgt;
+      }
+      ++cnt;
+      ++e;
+    }
+    Run r;
+    r.score = (mode == SEGVLAD_VOTE_WT_BORDA_IM) ? acc : (double)cnt;
+    r.first = (mode == SEGVLAD_VOTE_WT_BORDA_IM) ? (uint32_t)key : img;  // COUNT ties: lower image id
+    r.img = (int32_t)img;
+    runs[atomicAdd(&s_nruns, 1u)] = r;
+  }
+  __syncthreads();
+  const int R = (int)s_nruns;
+  __threadfence_block();
+  // n_top rounds of arg-best; a taken run gets score = -inf
+  for (int round = 0; round < n_top; ++round) {
+    double bs = -INFINITY;
+    uint32_t bt = ~0u;
+    int bp = -1;
+    for (int j = tid; j < R; j += 256) {
+      const Run r = runs[j];
+      if (r.score == -INFINITY) continue;
+      if (bp < 0 || better(r.score, r.first, bs, bt)) {
+        bs = r.score;
+        bt = r.first;
+        bp = j;
+      }
+    }
+    r_score[tid] = bs;
+    r_tie[tid] = bt;
+    r_pos[tid] = bp;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        const int pb = r_pos[tid + o];
+        if (pb >= 0 && (r_pos[tid] < 0 || better(r_score[tid + o], r_tie[tid + o], r_score[tid], r_tie[tid]))) {
+          r_score[tid] = r_score[tid + o];
+          r_tie[tid] = r_tie[tid + o];
+          r_pos[tid] = pb;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int bpos = r_pos[0];
+      if (bpos >= 0) {
+        pred[(int64_t)qi * n_top + round] = runs[bpos].img;
+        if (score) score[(int64_t)qi * n_top + round] = runs[bpos].score;
+        runs[bpos].score = -INFINITY;
+      } else {
+        pred[(int64_t)qi * n_top + round] = -1;
+        if (score) score[(int64_t)qi * n_top + round] = 0.0;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int sv_launch_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const int32_t* img_of_seg,
+                   int64_t n_ref_seg, const int32_t* qoff_dev, const int32_t* qoff_host, int n_img, int k,
+                   const float* minmax_dev, int n_top, int mode, int32_t* pred, double* score) {
+  if (n_img <= 0) return SEGVLAD_OK;
+  int maxS = 0;
+  for (int i = 0; i < n_img; ++i) {
+    const int s = qoff_host[i + 1] - qoff_host[i];
+    if (s < 0) return ctx->fail(SEGVLAD_ERR_ARG, "vote: qseg_offsets must be non-decreasing");
+    if (s > maxS) maxS = s;
+  }
+  const int64_t E = (int64_t)maxS * k;
+  int Epad = 2;
+  while (Epad < E) Epad <<= 1;
+  const size_t lds = (size_t)Epad * 8;
+  if (lds > 128 * 1024)
+    return ctx->fail(SEGVLAD_ERR_LIMIT, "vote: %d segments x k=%d entries per query image exceed the 16384-entry LDS sort", maxS, k);
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t stride = E > 0 ? E : 1;
+  SV_HIP(ctx->s_misc.reserve((size_t)n_img * stride * sizeof(Run)));
+  hipLaunchKernelGGL(vote_kernel, dim3(n_img), dim3(256), lds, ctx->stream, idx, sims, img_of_seg, n_ref_seg, qoff_dev, k,
+                     minmax_dev, n_top, mode, ctx->s_misc.as<Run>(), stride, pred, score);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}

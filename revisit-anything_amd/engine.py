@@ -1,0 +1,270 @@
+"""SegVLADEngine: thin object wrapper over the C-ABI (include/segvlad.h) for PyTorch-ROCm host code.
+
+PyTorch is plumbing here: device memory (tensors handed over as raw pointers), the current HIP
+stream, and -- in sharded.py -- torch.distributed.  All arithmetic happens in libsegvlad_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SegVLADError
+
+
+def _ptr(x) -> int:
+    """Raw address of a torch tensor (host or device) or a NumPy array; None -> NULL."""
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr()
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return x.ctypes.data
+    raise TypeError(f"unsupported buffer type {type(x)}")
+
+
+def _as(x, dtype_np, dtype_t):
+    """Coerce to a contiguous array/tensor of the wanted dtype without moving it between host/device."""
+    if isinstance(x, torch.Tensor):
+        return x.to(dtype_t).contiguous()
+    return np.ascontiguousarray(x, dtype=dtype_np)
+
+
+class SegVLADEngine:
+    """One context per (device, stream user).  Not thread-safe (the C context is not re-entrant)."""
+
+    def __init__(self, device: int | str | torch.device = 0):
+        if not torch.cuda.is_available():
+            raise SegVLADError("SegVLADEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.device = dev
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.segvlad_create(C.byref(h), dev.index or 0)
+        if rc != 0:
+            raise SegVLADError(f"segvlad_create(device={dev.index}) failed with {rc}")
+        self._h = h
+        self.K = self.D = 0
+        self.P = self.KD = 0
+        self._keep = []  # tensors that must outlive async kernels of the last call
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.segvlad_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.segvlad_last_error(self._h)
+            raise SegVLADError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}")
+
+    def _stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.segvlad_set_stream(self._h, C.c_void_p(s))
+
+    def _empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def synchronize(self):
+        self._stream()
+        self._check(self.lib.segvlad_synchronize(self._h), "synchronize")
+
+    def set_profiling(self, on: bool):
+        self.lib.segvlad_set_profiling(self._h, int(on))
+
+    def stage_ms(self, stage: str):
+        ms, n = C.c_float(), C.c_int()
+        self._stream()
+        self._check(self.lib.segvlad_stage_ms(self._h, stage.encode(), C.byref(ms), C.byref(n)), f"stage_ms({stage})")
+        return ms.value, n.value
+
+    # ---- vocabulary -------------------------------------------------------------------------------
+    def set_vocab(self, c_centers):
+        c = _as(c_centers, np.float32, torch.float32)
+        K, D = c.shape
+        self._stream()
+        self._check(self.lib.segvlad_set_vocab(self._h, _ptr(c), K, D), "set_vocab")
+        if isinstance(c, torch.Tensor) and c.is_cuda:
+            torch.cuda.current_stream(self.device).synchronize()
+        self.K, self.D = int(K), int(D)
+
+    # ---- masks ------------------------------------------------------------------------------------
+    def incidence(self, masks, H: int, W: int, patch: int = 14) -> torch.Tensor:
+        """masks [S,Hm,Wm] bool/uint8 (tensor or ndarray) -> int64 tensor [S, ceil(N/64)] holding u64 bit rows."""
+        m = masks.to(torch.uint8).contiguous() if isinstance(masks, torch.Tensor) else np.ascontiguousarray(masks).astype(np.uint8)
+        S, Hm, Wm = m.shape
+        N = (H // patch) * (W // patch)
+        out = self._empty((S, (N + 63) // 64), torch.int64)
+        self._stream()
+        self._check(self.lib.segvlad_incidence(self._h, _ptr(m), S, Hm, Wm, H, W, patch, _ptr(out)), "incidence")
+        self._keep = [m]
+        return out
+
+    def mask_centroids(self, masks) -> torch.Tensor:
+        m = masks.to(torch.uint8).contiguous() if isinstance(masks, torch.Tensor) else np.ascontiguousarray(masks).astype(np.uint8)
+        S, Hm, Wm = m.shape
+        out = self._empty((S, 2), torch.float64)
+        self._stream()
+        self._check(self.lib.segvlad_mask_centroids(self._h, _ptr(m), S, Hm, Wm, _ptr(out)), "mask_centroids")
+        self._keep = [m]
+        return out
+
+    # ---- segment VLAD -----------------------------------------------------------------------------
+    def seg_vlad(self, tokens, inc_bits, seg_offsets: Sequence[int], adj=None, want_labels=False, want_gap=False,
+                 want_block_norms=False, out: Optional[torch.Tensor] = None):
+        """tokens [B,D,N] fp32; inc_bits [S_tot,nw] (int64 storage of u64); seg_offsets [B+1];
+        adj: None | uint8 buffer with the concatenated per-image [S_b,S_b] matrices.
+        Returns dict(out=[S_tot,K*D] fp32 device tensor, labels?, gap?, block_norms?)."""
+        if self.K == 0:
+            raise SegVLADError("seg_vlad: set_vocab first")
+        t = _as(tokens, np.float32, torch.float32)
+        if t.ndim == 2:
+            t = t[None]
+        B, D, N = t.shape
+        if D != self.D:
+            raise ValueError(f"tokens have D={D}, vocabulary has D={self.D}")
+        so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+        assert so.shape == (B + 1,)
+        S_tot = int(so[-1])
+        ib = inc_bits if isinstance(inc_bits, torch.Tensor) else np.ascontiguousarray(inc_bits)
+        a = None
+        if adj is not None:
+            a = adj.to(torch.uint8).contiguous() if isinstance(adj, torch.Tensor) else np.ascontiguousarray(adj).astype(np.uint8)
+        if out is None:
+            out = self._empty((S_tot, self.K * self.D), torch.float32)
+        res = {"out": out}
+        lab = self._empty((B, N), torch.uint8) if want_labels else None
+        gap = self._empty((B, N), torch.float32) if want_gap else None
+        bn = self._empty((S_tot, self.K), torch.float32) if want_block_norms else None
+        self._stream()
+        self._check(self.lib.segvlad_images(self._h, _ptr(t), B, N, _ptr(ib), _ptr(so), _ptr(a), _ptr(out), _ptr(lab),
+                                            _ptr(gap), _ptr(bn)), "images")
+        self._keep = [t, ib, a]
+        if want_labels:
+            res["labels"] = lab
+        if want_gap:
+            res["gap"] = gap
+        if want_block_norms:
+            res["block_norms"] = bn
+        return res
+
+    # ---- PCA --------------------------------------------------------------------------------------
+    def pca_set(self, mean, components, explained_variance=None, whiten=True):
+        comps = _as(components, np.float32, torch.float32)
+        P, KD = comps.shape
+        mean = None if mean is None else _as(mean, np.float32, torch.float32)
+        var = None if explained_variance is None else _as(explained_variance, np.float32, torch.float32)
+        self._stream()
+        self._check(self.lib.segvlad_pca_set(self._h, _ptr(mean), _ptr(comps), _ptr(var), P, KD, int(bool(whiten))), "pca_set")
+        self.P, self.KD = int(P), int(KD)
+
+    def pca_apply(self, X, l2norm=False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _as(X, np.float32, torch.float32)
+        n, KD = x.shape
+        if KD != self.KD:
+            raise ValueError(f"X has {KD} columns, PCA model expects {self.KD}")
+        if out is None:
+            out = self._empty((n, self.P), torch.float32)
+        self._stream()
+        self._check(self.lib.segvlad_pca_apply(self._h, _ptr(x), n, _ptr(out), int(l2norm)), "pca_apply")
+        self._keep = [x]
+        return out
+
+    def normalize_rows(self, X) -> torch.Tensor:
+        x = _as(X, np.float32, torch.float32)
+        n, d = x.shape
+        out = self._empty((n, d), torch.float32)
+        self._stream()
+        self._check(self.lib.segvlad_normalize_rows(self._h, _ptr(x), n, d, _ptr(out)), "normalize_rows")
+        self._keep = [x]
+        return out
+
+    # ---- exact kNN --------------------------------------------------------------------------------
+    def db_reset(self):
+        self._check(self.lib.segvlad_db_reset(self._h), "db_reset")
+
+    def db_add(self, R, img_of_seg=None):
+        r = _as(R, np.float32, torch.float32)
+        n, d = r.shape
+        im = None if img_of_seg is None else _as(img_of_seg, np.int32, torch.int32)
+        self._stream()
+        self._check(self.lib.segvlad_db_add(self._h, _ptr(r), n, d, _ptr(im)), "db_add")
+        if isinstance(r, torch.Tensor) and r.is_cuda:
+            torch.cuda.current_stream(self.device).synchronize()  # the index copied the rows: r may now be freed
+
+    def db_size(self):
+        n, d = C.c_int64(), C.c_int()
+        self.lib.segvlad_db_size(self._h, C.byref(n), C.byref(d))
+        return n.value, d.value
+
+    def search(self, Q, k: int):
+        q = _as(Q, np.float32, torch.float32)
+        nq = q.shape[0]
+        d2 = self._empty((nq, k), torch.float32)
+        idx = self._empty((nq, k), torch.int64)
+        self._stream()
+        self._check(self.lib.segvlad_search(self._h, _ptr(q), nq, k, _ptr(d2), _ptr(idx)), "search")
+        self._keep = [q]
+        return d2, idx
+
+    def merge_topk(self, d2_parts, idx_parts, parts: int, k: int):
+        d = _as(d2_parts, np.float32, torch.float32)
+        i = _as(idx_parts, np.int64, torch.int64)
+        nq = d.shape[0]
+        assert d.shape[1] == parts * k and i.shape == d.shape
+        od = self._empty((nq, k), torch.float32)
+        oi = self._empty((nq, k), torch.int64)
+        self._stream()
+        self._check(self.lib.segvlad_merge_topk(self._h, _ptr(d), _ptr(i), nq, parts, k, _ptr(od), _ptr(oi)), "merge_topk")
+        self._keep = [d, i]
+        return od, oi
+
+    def sims_from_d2(self, d2, idx, k_keep: int):
+        d = _as(d2, np.float32, torch.float32)
+        i = _as(idx, np.int64, torch.int64)
+        nq, k_in = d.shape
+        s = self._empty((nq, k_keep), torch.float32)
+        oi = self._empty((nq, k_keep), torch.int64)
+        self._stream()
+        self._check(self.lib.segvlad_sims_from_d2(self._h, _ptr(d), _ptr(i), nq, k_in, k_keep, _ptr(s), _ptr(oi)), "sims_from_d2")
+        self._keep = [d, i]
+        return s, oi
+
+    def minmax(self, sims) -> torch.Tensor:
+        s = _as(sims, np.float32, torch.float32)
+        out = self._empty((2,), torch.float32)
+        self._stream()
+        self._check(self.lib.segvlad_minmax(self._h, _ptr(s), s.numel() if isinstance(s, torch.Tensor) else s.size, _ptr(out)), "minmax")
+        self._keep = [s]
+        return out
+
+    def vote(self, idx, sims, qseg_offsets, n_top=5, mode=_lib.VOTE_WT_BORDA_IM, img_of_seg=None, smin=float("nan"),
+             smax=float("nan"), want_scores=True):
+        i = _as(idx, np.int64, torch.int64)
+        s = None if sims is None else _as(sims, np.float32, torch.float32)
+        qo = np.ascontiguousarray(qseg_offsets, dtype=np.int32)
+        n_img = len(qo) - 1
+        k = i.shape[1]
+        im = None if img_of_seg is None else _as(img_of_seg, np.int32, torch.int32)
+        n_ref = 0 if im is None else int(im.shape[0])
+        pred = self._empty((n_img, n_top), torch.int32)
+        sc = self._empty((n_img, n_top), torch.float64) if want_scores else None
+        self._stream()
+        self._check(self.lib.segvlad_vote(self._h, _ptr(i), _ptr(s), _ptr(im), n_ref, _ptr(qo), n_img, k, smin, smax, n_top,
+                                          int(mode), _ptr(pred), _ptr(sc)), "vote")
+        self._keep = [i, s, im]
+        return pred, sc

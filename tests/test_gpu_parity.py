@@ -1,0 +1,353 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the committed golden
+vectors.  Bit-exact for integer/bit/index outputs; fp32-vs-fp64 tolerances are written at each
+assert.  Run with `-m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device (no CPU fallback exists)"
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    e = SegVLADEngine(0)
+    yield e
+    e.close()
+
+
+def O():
+    from oracle import segvlad_oracle
+
+    return segvlad_oracle
+
+
+def synth():
+    from revisit_anything_amd import synth as s
+
+    return s
+
+
+def cos_rows(a, b):
+    num = (a * b).sum(1)
+    den = np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1)
+    out = np.ones_like(num)
+    nz = den > 0
+    out[nz] = num[nz] / den[nz]
+    return out
+
+
+def cat_adj(adjs):
+    return np.concatenate([np.asarray(a, dtype=np.uint8).reshape(-1) for a in adjs]) if adjs else None
+
+
+# ------------------------------------------------------------------------------------------------
+def test_native_library_is_loaded(eng):
+    from revisit_anything_amd import _lib
+
+    assert os.path.exists(_lib.lib_path())
+    with open("/proc/self/maps") as f:
+        assert "libsegvlad_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("name", ["same", "x2", "x2clip", "nonint", "down"])
+def test_incidence_golden(eng, name):
+    z = np.load(os.path.join(G, "incidence_cases.npz"))
+    S, Hm, Wm, H, W = (int(v) for v in z[f"{name}_shape"])
+    m = np.unpackbits(z[f"{name}_masks"], axis=1)[:, :Hm * Wm].reshape(S, Hm, Wm).astype(np.uint8)
+    bits = eng.incidence(m, H, W).cpu().numpy().view(np.uint64)
+    N = (H // 14) * (W // 14)
+    assert np.array_equal(O().unpack_bits_u64(bits, N), z[f"{name}_inc"])  # bit-exact
+
+
+def test_incidence_ref_geometry_and_device_input(eng):
+    import torch
+
+    masks = synth().make_blob_masks(50, 240, 320, seed=11)
+    want = O().incidence(masks, 480, 640)
+    md = torch.from_numpy(masks.astype(np.uint8)).to(eng.device)
+    bits = eng.incidence(md, 480, 640).cpu().numpy().view(np.uint64)
+    assert np.array_equal(O().unpack_bits_u64(bits, 34 * 45), want)
+    # pad bits above N must be zero
+    assert (bits[:, -1] >> np.uint64(1530 - 23 * 64)).max() == 0
+
+
+def test_mask_centroids_bit_exact(eng):
+    masks = synth().make_blob_masks(20, 60, 80, seed=3)
+    c = eng.mask_centroids(masks).cpu().numpy()
+    assert np.array_equal(c, O().mask_centroids([m for m in masks]))  # exact integer sums, one fp64 division
+
+
+# ------------------------------------------------------------------------------------------------
+def run_vlad(eng, tokens_list, inc_list, adj_list, C, **kw):
+    eng.set_vocab(C)
+    B = len(tokens_list)
+    toks = np.stack(tokens_list)
+    N = toks.shape[2]
+    offs = np.concatenate([[0], np.cumsum([i.shape[0] for i in inc_list])]).astype(np.int32)
+    bits = np.concatenate([O().pack_bits_u64(i) for i in inc_list]) if offs[-1] else np.zeros((0, (N + 63) // 64), np.uint64)
+    adj = None
+    if adj_list is not None:
+        adj = cat_adj([a if a is not None else np.eye(i.shape[0], dtype=bool) for a, i in zip(adj_list, inc_list)])
+    r = eng.seg_vlad(toks, bits.view(np.int64), offs, adj, **kw)
+    return {k: v.cpu().numpy() for k, v in r.items()}, offs
+
+
+def test_vlad_tiny_golden(eng):
+    z = np.load(os.path.join(G, "vlad_tiny.npz"))
+    D, K, H, W, S = (int(z[k]) for k in "DKHWS")
+    C = synth().make_vocab(K, D, seed=1001)
+    tok = synth().make_tokens(C, (H // 14) * (W // 14), seed=2001, noise=0.3)
+    inc = z["inc"]
+    for order in (0, 1, 3):
+        adj = None if order == 0 else [z[f"adj_o{order}"]]
+        r, _ = run_vlad(eng, [tok], [inc], adj, C, want_labels=True, want_gap=True)
+        assert np.array_equal(r["labels"][0], z["labels"].astype(np.uint8))
+        ref = z[f"vlad_o{order}"]
+        assert np.abs(r["out"] - ref).max() < 2e-6          # fp32 device vs fp64 reference, unit-norm rows
+        assert (1 - cos_rows(r["out"].astype(np.float64), ref)).max() < 1e-6
+
+
+def test_vlad_ref_shape_golden(eng):
+    z = np.load(os.path.join(G, "vlad_ref_shape.npz"))
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    tok = synth().make_tokens(voc, 34 * 45, seed=2002)
+    inc = np.unpackbits(z["inc"], axis=1)[:, :1530].astype(bool)
+    r, _ = run_vlad(eng, [tok], [inc], [z["adj"]], voc, want_labels=True, want_block_norms=True)
+    assert np.array_equal(r["labels"][0], z["labels"])
+    out = r["out"].astype(np.float64)
+    assert np.abs(out[:, ::61] - z["sub"]).max() < 1e-6
+    assert np.abs(out[:, :256] - z["head"]).max() < 1e-6
+    assert np.abs(out[:, -256:] - z["tail"]).max() < 1e-6
+    Gm = np.random.Generator(np.random.PCG64(777)).standard_normal((32 * 1536, 16))
+    assert np.abs(out @ Gm - z["proj"]).max() < 1e-4
+    # full-tensor check against the oracle (cosine 1-1e-6 per SURVEY App. D 1)
+    ref, aux = O().seg_vlad(tok, inc, voc, z["adj"], return_aux=True)
+    assert (1 - cos_rows(out, ref)).max() < 1e-6
+    assert np.abs(out - ref).max() < 1e-6
+    assert np.allclose(r["block_norms"], aux["block_norms"], rtol=1e-5, atol=1e-6)
+
+
+def test_vlad_k64_golden(eng):
+    z = np.load(os.path.join(G, "vlad_k64.npz"))
+    D, K, S, N = (int(z[k]) for k in ("D", "K", "S", "N"))
+    C = synth().make_vocab(K, D, seed=1003)
+    tok = synth().make_tokens(C, N, seed=2004, noise=0.2)
+    r, _ = run_vlad(eng, [tok], [z["inc"]], [z["adj"]], C, want_labels=True)  # S=66 > 64: two segment chunks
+    assert np.array_equal(r["labels"][0], z["labels"].astype(np.uint8))
+    assert np.abs(r["out"] - z["vlad"]).max() < 2e-6
+
+
+def test_vlad_adversarial_tie_audit(eng):
+    """Isotropic tokens: near-tied assignments.  Labels must equal the oracle's wherever the oracle's
+    fp64 top-2 gap exceeds fp32 rounding; the device's own gap output must flag the rest."""
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    tok = synth().make_tokens(voc, 34 * 45, seed=2003, adversarial=True)
+    masks = synth().make_masks(50, 240, 320, seed=2102)
+    inc = O().incidence(masks, 480, 640)
+    r, _ = run_vlad(eng, [tok], [inc], None, voc, want_labels=True, want_gap=True)
+    labels, gap = O().assign_labels(O().normalize_tokens_f32(tok), voc)
+    ok = gap > 1e-6
+    assert np.array_equal(r["labels"][0][ok], labels[ok].astype(np.uint8))
+    assert np.allclose(r["gap"][0][ok], gap[ok], atol=2e-6)
+    if np.array_equal(r["labels"][0], labels.astype(np.uint8)):
+        ref = O().seg_vlad(tok, inc, voc, None)
+        assert (1 - cos_rows(r["out"].astype(np.float64), ref)).max() < 1e-6
+
+
+def test_vlad_ragged_batch_and_edge_cases(eng):
+    """Batch of images with different segment counts (0, 1, 3, 40, 70), empty segments, empty clusters."""
+    D, K, N = 64, 32, 15 * 20
+    C = synth().make_vocab(K, D, seed=77)
+    rng = np.random.Generator(np.random.PCG64(78))
+    toks, incs, adjs = [], [], []
+    for b, S in enumerate([0, 1, 3, 40, 70]):
+        toks.append(synth().make_tokens(C[:5] if b == 2 else C, N, seed=900 + b, noise=0.3))  # b==2: only 5 clusters used
+        inc = rng.random((S, N)) < 0.2
+        if S > 2:
+            inc[1] = False                        # a segment covering no token
+        incs.append(inc)
+        a = (rng.random((S, S)) < 0.1) | np.eye(S, dtype=bool)
+        adjs.append(a)
+    toks[2] = synth().make_tokens(C, N, seed=902, noise=0.3)
+    r, offs = run_vlad(eng, toks, incs, adjs, C, want_labels=True)
+    for b in range(5):
+        ref, aux = O().seg_vlad(toks[b], incs[b], C, adjs[b], return_aux=True)
+        got = r["out"][offs[b]:offs[b + 1]]
+        assert np.array_equal(r["labels"][b], aux["labels"].astype(np.uint8))
+        assert got.shape == ref.shape
+        if ref.size:
+            assert np.abs(got - ref).max() < 2e-6
+    # identity adjacency == adj=None
+    r2, _ = run_vlad(eng, toks, incs, None, C)
+    r3, _ = run_vlad(eng, toks, incs, [np.eye(i.shape[0], dtype=bool) for i in incs], C)
+    assert np.array_equal(r2["out"], r3["out"])
+    # zero rows for token-less segments without a neighbourhood
+    assert np.all(r2["out"][offs[3] + 1] == 0)
+
+
+def test_vlad_odd_token_count_and_d768(eng):
+    voc = np.load(os.path.join(G, "vocab_nv_k32_d768.npy"))
+    N = 37 * 37  # odd: exercises the unaligned 8-byte token loads
+    tok = synth().make_tokens(voc, N, seed=31, noise=0.1)
+    rng = np.random.Generator(np.random.PCG64(32))
+    inc = rng.random((9, N)) < 0.3
+    r, _ = run_vlad(eng, [tok], [inc], None, voc, want_labels=True)
+    ref, aux = O().seg_vlad(tok, inc, voc, None, return_aux=True)
+    assert np.array_equal(r["labels"][0], aux["labels"].astype(np.uint8))
+    assert np.abs(r["out"] - ref).max() < 1e-6
+
+
+def test_vlad_deterministic(eng):
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    tok = synth().make_tokens(voc, 300, seed=5)
+    inc = np.random.Generator(np.random.PCG64(6)).random((50, 300)) < 0.3
+    a, _ = run_vlad(eng, [tok, tok], [inc, inc], None, voc)
+    b, _ = run_vlad(eng, [tok, tok], [inc, inc], None, voc)
+    assert np.array_equal(a["out"], b["out"])            # run twice, compare bits
+    assert np.array_equal(a["out"][:50], a["out"][50:])  # batch position does not matter
+
+
+# ------------------------------------------------------------------------------------------------
+def test_pca_golden_and_normalize(eng):
+    z = np.load(os.path.join(G, "pca_small.npz"))
+    eng.pca_set(z["mean"], z["components"], z["explained_variance"], whiten=True)
+    Y = eng.pca_apply(z["X"].astype(np.float32)).cpu().numpy()
+    assert np.abs(Y - z["Y"]).max() < 5e-5 * np.abs(z["Y"]).max()
+    Yn = eng.pca_apply(z["X"].astype(np.float32), l2norm=True).cpu().numpy()
+    assert np.abs(Yn - O().normalize_feat(z["Y"])).max() < 1e-5
+
+
+def test_pca_large_shape(eng):
+    mean, comps, var = synth().make_pca_model(2048 * 3, 200, seed=5)   # P not a multiple of the tile
+    X = np.random.Generator(np.random.PCG64(6)).standard_normal((333, 2048 * 3)).astype(np.float32) / 78.0
+    eng.pca_set(mean, comps, var, whiten=True)
+    Y = eng.pca_apply(X).cpu().numpy()
+    ref = O().pca_transform(X, mean, comps, var, True)
+    assert np.abs(Y - ref).max() < 2e-4 * np.abs(ref).max()
+
+
+def test_knn_exact_against_oracle(eng):
+    rng = np.random.Generator(np.random.PCG64(100))
+    R = rng.standard_normal((3000, 256)).astype(np.float32)
+    R /= np.linalg.norm(R, axis=1, keepdims=True)
+    Q = rng.standard_normal((257, 256)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    eng.db_reset()
+    eng.db_add(R[:1000])
+    eng.db_add(R[1000:])   # incremental add like index.add called twice
+    d2, idx = eng.search(Q, 200)
+    d2, idx = d2.cpu().numpy(), idx.cpu().numpy()
+    rd2, ridx = O().knn_l2(R, Q, 200)
+    assert np.abs(d2 - rd2).max() < 1e-5                # squared L2 of unit vectors, fp32 GEMM
+    assert np.all(np.diff(d2, axis=1) >= 0)             # ascending
+    # ids equal wherever neighbouring reference distances are separated by more than fp32 noise
+    sep = np.minimum(np.diff(rd2, axis=1, prepend=-1), np.diff(rd2, axis=1, append=9)) > 1e-5
+    assert np.array_equal(idx[sep], ridx[sep])
+    assert (idx == ridx).mean() > 0.995
+    # the set of the 200 nearest is the same except at the k-boundary
+    assert np.mean([len(set(a) & set(b)) for a, b in zip(idx, ridx)]) > 199.5
+
+
+def test_knn_ties_and_small_db(eng):
+    R = np.zeros((5, 8), np.float32)
+    R[:, 0] = [1, 1, 2, 1, 3]      # rows 0,1,3 identical -> ties resolved by lower id
+    Q = np.zeros((2, 8), np.float32)
+    Q[0, 0] = 1
+    Q[1, 0] = 2.9
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = eng.search(Q, 7)     # k > n: padded with (+inf, -1) like faiss
+    d2, idx = d2.cpu().numpy(), idx.cpu().numpy()
+    assert idx[0].tolist() == [0, 1, 3, 2, 4, -1, -1]
+    assert np.allclose(d2[0][:5], [0, 0, 0, 1, 4]) and np.isinf(d2[0][5:]).all()
+    assert idx[1].tolist()[:2] == [4, 2]
+    d2b, idxb = eng.search(Q, 2)   # boundary tie: exactly 2 of the 3 equal rows, lowest ids
+    assert idxb.cpu().numpy()[0].tolist() == [0, 1]
+
+
+def test_merge_topk_equals_single_shard(eng):
+    rng = np.random.Generator(np.random.PCG64(101))
+    R = rng.standard_normal((2000, 64)).astype(np.float32)
+    Q = rng.standard_normal((40, 64)).astype(np.float32)
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = (t.cpu().numpy() for t in eng.search(Q, 50))
+    parts = [(0, 700), (700, 1400), (1400, 2000)]
+    dp, ip = [], []
+    for a, b in parts:
+        eng.db_reset()
+        eng.db_add(R[a:b])
+        d, i = eng.search(Q, 50)
+        dp.append(d.cpu().numpy())
+        ip.append(i.cpu().numpy() + a)
+    dm, im = eng.merge_topk(np.concatenate(dp, 1), np.concatenate(ip, 1), 3, 50)
+    assert np.array_equal(im.cpu().numpy(), idx)          # merged ids == single-shard ids, bit for bit
+    assert np.array_equal(dm.cpu().numpy(), d2)
+    om, oi = O().merge_topk(dp, ip, 50)
+    assert np.array_equal(oi, idx)
+
+
+def test_vote_golden_bit_exact(eng):
+    z = np.load(os.path.join(G, "vote_cases.npz"))
+    off = z["off"].astype(np.int32)
+    segRange = [np.arange(off[i], off[i + 1]) for i in range(len(off) - 1)]
+    imInds = z["imInds"].astype(np.int32)
+    for n in (1, 5):
+        pred, sc = eng.vote(z["matches"], z["sims"], off, n_top=n, img_of_seg=imInds)
+        assert np.array_equal(pred.cpu().numpy(), z[f"wt_n{n}"])          # identical image ids
+    _, rs = O().get_matches_wt_borda_im(z["matches"], len(segRange), z["sims"], segRange, z["imInds"], n=5, return_scores=True)
+    got = sc.cpu().numpy()
+    for i, row in enumerate(rs):
+        assert np.array_equal(got[i][:len(row)], np.array(row))            # fp64 scores bit-identical
+    # integer mode: counts exact; ids compared where the oracle's n-th count is unique
+    from revisit_anything_amd._lib import VOTE_COUNT
+    pred, sc = eng.vote(z["matches"], None, off, n_top=5, mode=VOTE_COUNT, img_of_seg=imInds)
+    pred, sc = pred.cpu().numpy(), sc.cpu().numpy()
+    _, counts = O().get_matches_max_seg_topk(z["matches"], len(segRange), segRange, z["imInds"], n=5)
+    for i, bc in enumerate(counts):
+        top = np.sort(bc)[::-1][:5]
+        assert np.array_equal(sc[i][:len(top[top > 0])], top[top > 0].astype(np.float64))
+        for j in range(5):
+            if pred[i, j] >= 0:
+                assert bc[pred[i, j]] == sc[i, j]
+        # documented rule: (count desc, image id asc)
+        order = np.lexsort((np.arange(len(bc)), -bc))[:5]
+        order = order[bc[order] > 0]
+        assert pred[i][:len(order)].tolist() == order.tolist()
+    # hand-made tie case: first appearance decides
+    pred, _ = eng.vote(z["tie_matches"], z["tie_sims"], np.array([0, 2], np.int32), n_top=4, img_of_seg=z["tie_imInds"].astype(np.int32))
+    assert pred.cpu().numpy()[0].tolist() == z["tie_pred"].tolist()
+
+
+def test_e2e_small_golden(eng):
+    """recall_segloc chain on the device: normalise -> add -> search 200 -> keep 50 -> 2-d2 -> vote -> recall."""
+    z = np.load(os.path.join(G, "e2e_small.npz"))
+    n_img, S, d, n_q = (int(z[k]) for k in ("n_img", "S", "d", "n_q"))
+    R, img = synth().make_planted_db(n_img, S, d, seed=3000)
+    Q, tau, off = synth().make_planted_queries(R, n_img, S, n_q, seed=4000, sigma_q=3.0)
+    sr = np.random.Generator(np.random.PCG64(1)).uniform(0.5, 2.0, size=(R.shape[0], 1))
+    sq = np.random.Generator(np.random.PCG64(2)).uniform(0.5, 2.0, size=(Q.shape[0], 1))
+    Rn = eng.normalize_rows((R.astype(np.float64) * sr).astype(np.float32))
+    Qn = eng.normalize_rows((Q.astype(np.float64) * sq).astype(np.float32))
+    eng.db_reset()
+    eng.db_add(Rn, img)
+    d2, idx = eng.search(Qn, 200)
+    sims, m50 = eng.sims_from_d2(d2, idx, 50)
+    assert np.abs(sims.cpu().numpy() - z["sims_50"]).max() < 1e-4           # "2 - d^2" within 1e-4 (north_star)
+    same = (m50.cpu().numpy() == z["matches_50"]).mean()
+    assert same > 0.99
+    pred, _ = eng.vote(m50, sims, off, n_top=5)
+    pred = pred.cpu().numpy()
+    assert np.array_equal(pred[:, 0], z["preds"][:, 0])                        # identical top-1 image ids
+    gt = [[int(t)] for t in tau]
+    gt[5] = []
+    rec = O().calc_recall([list(p[p >= 0]) for p in pred], gt, 5)
+    assert np.allclose(rec, z["recalls"])
