@@ -82,6 +82,13 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
                    const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out,
                    float* gap_out, float* block_norms_out);
 
+/* ---- the K-parametric entry: vlad_matmuls_per_cluster(num_c, masks, res, clus_labels, adjMat)
+ *      func_vpr.py:1181-1210.  res [N][D] fp32 residuals (token-major, as the reference passes them),
+ *      labels [N] u8 (< num_c <= 256), inc_bits [S][ceil(N/64)], adj [S][S] bytes or NULL,
+ *      out [S][num_c*D] fp32.  Independent of the vocabulary held by the context.                  */
+int segvlad_cluster_aggregate(segvlad_ctx* ctx, int num_c, const float* res, const uint8_t* labels, int N, int D,
+                              const uint64_t* inc_bits, int S, const uint8_t* adj, float* out);
+
 /* ---- PCA apply: pickle.load + PCA.transform                          func_vpr.py:1419-1443
  *      Y = ((X - mean) @ comps^T) / sqrt(expl_var) when whiten!=0.  comps [P][KD] fp32.          */
 int segvlad_pca_set(segvlad_ctx* ctx, const float* mean, const float* comps, const float* expl_var, int P, int KD,

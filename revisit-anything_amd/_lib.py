@@ -27,6 +27,8 @@ SIGNATURES = {
     "segvlad_mask_centroids": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "segvlad_images": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_void_p,
                                   _f32p, _f32p]),
+    "segvlad_cluster_aggregate": (C.c_int, [c_ctx_p, C.c_int, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                             C.c_void_p, _f32p]),
     "segvlad_pca_set": (C.c_int, [c_ctx_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
     "segvlad_pca_apply": (C.c_int, [c_ctx_p, _f32p, C.c_int, _f32p, C.c_int]),
     "segvlad_normalize_rows": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, _f32p]),
@@ -69,6 +71,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if not os.path.exists(path):
         raise SegVLADError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                            "There is no CPU fallback.")
+    # torch ships its own libamdhip64: import it FIRST so that this library binds to the HIP runtime
+    # PyTorch-ROCm already initialised (one runtime per process; streams/pointers are then shared)
+    import torch  # noqa: F401
+
     try:
         lib = C.CDLL(path)
     except OSError as e:

@@ -274,18 +274,59 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
     {
       StageScope sc(ctx, "prep");
       SV_TRY(sv_launch_prep(ctx, (const uint8_t*)d_lab, (const uint64_t*)d_inc, ctx->s_segoff.as<int32_t>(),
-                            ctx->s_adjoff.as<int64_t>(), (const uint8_t*)d_adj, B, N, S_max, SC, ctx->s_colmask.as<uint64_t>(),
-                            ctx->s_gscale.as<float>()));
+                            ctx->s_adjoff.as<int64_t>(), (const uint8_t*)d_adj, B, N, K, S_max, SC,
+                            ctx->s_colmask.as<uint64_t>(), ctx->s_gscale.as<float>()));
       sc.count();
     }
     {
       StageScope sc(ctx, "aggregate");
       SV_TRY(sv_launch_aggregate(ctx, ctx->s_xt.as<float>(), ctx->s_rnorm.as<float>(), (const uint8_t*)d_lab,
-                                 ctx->s_colmask.as<uint64_t>(), ctx->s_segoff.as<int32_t>(), ctx->s_gscale.as<float>(), B, N,
-                                 SC, (float*)d_out, (float*)d_bn));
+                                 ctx->s_colmask.as<uint64_t>(), ctx->vocab.as<float>(), K, D, ctx->s_segoff.as<int32_t>(),
+                                 ctx->s_gscale.as<float>(), B, N, SC, (float*)d_out, (float*)d_bn));
       sc.count();
     }
   }
+  return sv_finish(ctx);
+}
+
+// ---- K-parametric aggregation of given residuals + labels (vlad_matmuls_per_cluster) --------------------
+__global__ void fill_ones_kernel(float* p, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) p[j] = 1.f;
+}
+
+int segvlad_cluster_aggregate(segvlad_ctx* ctx, int num_c, const float* res, const uint8_t* labels, int N, int D,
+                              const uint64_t* inc_bits, int S, const uint8_t* adj, float* out) {
+  CHECK_CTX();
+  if (num_c <= 0 || num_c > 256 || N <= 0 || D <= 0 || (D % 4) || S < 0)
+    return ctx->fail(SEGVLAD_ERR_ARG, "cluster_aggregate: bad shape num_c=%d N=%d D=%d S=%d", num_c, N, D, S);
+  if (S == 0) return SEGVLAD_OK;
+  if (!res || !labels || !inc_bits || !out) return ctx->fail(SEGVLAD_ERR_ARG, "cluster_aggregate: null pointer");
+  const int nw = (N + 63) / 64, SC = (S + 63) / 64;
+  const void *d_res, *d_lab, *d_inc, *d_adj = nullptr;
+  void* d_out;
+  SV_TRY(sv_in(ctx, res, (size_t)N * D * 4, &d_res));
+  SV_TRY(sv_in(ctx, labels, (size_t)N, &d_lab));
+  SV_TRY(sv_in(ctx, inc_bits, (size_t)S * nw * 8, &d_inc));
+  if (adj) SV_TRY(sv_in(ctx, adj, (size_t)S * S, &d_adj));
+  SV_TRY(sv_out(ctx, out, (size_t)S * num_c * D * 4, &d_out));
+  SV_HIP(ctx->s_rnorm.reserve((size_t)N * 4));
+  SV_HIP(ctx->s_colmask.reserve((size_t)N * SC * 8));
+  SV_HIP(ctx->s_gscale.reserve((size_t)(S + 1) * 4));
+  SV_HIP(ctx->s_segoff.reserve(2 * sizeof(int32_t)));
+  SV_HIP(ctx->s_adjoff.reserve(2 * sizeof(int64_t)));
+  const int32_t so[2] = {0, S};
+  const int64_t ao[2] = {0, (int64_t)S * S};
+  SV_HIP(hipMemcpyAsync(ctx->s_segoff.p, so, sizeof(so), hipMemcpyHostToDevice, ctx->stream));
+  SV_HIP(hipMemcpyAsync(ctx->s_adjoff.p, ao, sizeof(ao), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(fill_ones_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, ctx->s_rnorm.as<float>(), N);
+  SV_TRY(sv_launch_prep(ctx, (const uint8_t*)d_lab, (const uint64_t*)d_inc, ctx->s_segoff.as<int32_t>(),
+                        ctx->s_adjoff.as<int64_t>(), (const uint8_t*)d_adj, 1, N, num_c, S, SC, ctx->s_colmask.as<uint64_t>(),
+                        ctx->s_gscale.as<float>()));
+  SV_TRY(sv_launch_aggregate(ctx, (const float*)d_res, ctx->s_rnorm.as<float>(), (const uint8_t*)d_lab,
+                             ctx->s_colmask.as<uint64_t>(), nullptr, num_c, D, ctx->s_segoff.as<int32_t>(),
+                             ctx->s_gscale.as<float>(), 1, N, SC, (float*)d_out, nullptr));
+  SV_HIP(hipStreamSynchronize(ctx->stream));  // so[] / ao[] live on this frame
   return sv_finish(ctx);
 }
 

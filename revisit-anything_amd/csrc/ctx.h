@@ -120,11 +120,12 @@ int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
 int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float* xt, uint8_t* labels, float* rnorm,
                      float* gap);
 int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_bits, const int32_t* seg_off_dev,
-                   const int64_t* adj_off_dev, const uint8_t* adj, int B, int N, int S_max, int SC, uint64_t* colmask,
-                   float* gscale);
+                   const int64_t* adj_off_dev, const uint8_t* adj, int B, int N, int K, int S_max, int SC,
+                   uint64_t* colmask, float* gscale);
+// centres == nullptr: the inputs are residuals already (x * rnorm - 0)
 int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
-                        const uint64_t* colmask, const int32_t* seg_off_dev, const float* gscale, int B, int N, int SC,
-                        float* out, float* block_norms);
+                        const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
+                        const float* gscale, int B, int N, int SC, float* out, float* block_norms);
 
 // gemm_kernels.hip
 int sv_launch_row_sumsq(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* out);

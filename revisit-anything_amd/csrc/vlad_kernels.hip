@@ -364,17 +364,17 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ l
 }
 
 int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_bits, const int32_t* seg_off_dev,
-                   const int64_t* adj_off_dev, const uint8_t* adj, int B, int N, int S_max, int SC, uint64_t* colmask,
-                   float* gscale) {
+                   const int64_t* adj_off_dev, const uint8_t* adj, int B, int N, int K, int S_max, int SC,
+                   uint64_t* colmask, float* gscale) {
   const int nw = (N + 63) / 64;
-  const size_t lds = ((size_t)S_max + ctx->K) * nw * sizeof(uint64_t);
+  const size_t lds = ((size_t)S_max + K) * nw * sizeof(uint64_t);
   if (lds > 160 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "prep: (S_max=%d + K=%d) x %d token words needs %zu B of LDS (limit 160 KiB)", S_max,
-                     ctx->K, nw, lds);
+                     K, nw, lds);
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, ctx->stream, labels, inc_bits, seg_off_dev, adj_off_dev, adj, N,
-                     ctx->K, S_max, SC, colmask, gscale);
+                     K, S_max, SC, colmask, gscale);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
   const int dcol = w * 128 + 4 * i;
   const bool dvalid = dcol < D;
   float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (dvalid) c4 = *reinterpret_cast<const float4*>(C + (size_t)k * D + dcol);
+  if (dvalid && C != nullptr) c4 = *reinterpret_cast<const float4*>(C + (size_t)k * D + dcol);
   const float* Xb = Xt + (size_t)b * N * D + dcol;
   const size_t KD = (size_t)K * D;
   const int SCb = (S + 63) >> 6;
@@ -526,9 +526,8 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
 }
 
 int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
-                        const uint64_t* colmask, const int32_t* seg_off_dev, const float* gscale, int B, int N, int SC,
-                        float* out, float* block_norms) {
-  const int D = ctx->D, K = ctx->K;
+                        const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
+                        const float* gscale, int B, int N, int SC, float* out, float* block_norms) {
   const int nwaves = (D + 127) / 128;
   if (nwaves > 12)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: D=%d exceeds the 1536-wide workgroup of this build", D);
@@ -540,7 +539,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, c
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
   hipLaunchKernelGGL(aggregate_kernel, dim3(K, B), dim3(nwaves * 64), lds, ctx->stream, xt, rnorm, labels, colmask,
-                     ctx->vocab.as<float>(), seg_off_dev, gscale, N, D, K, SC, Ncap, out, block_norms);
+                     centres, seg_off_dev, gscale, N, D, K, SC, Ncap, out, block_norms);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

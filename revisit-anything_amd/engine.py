@@ -162,6 +162,23 @@ class SegVLADEngine:
             res["block_norms"] = bn
         return res
 
+    def cluster_aggregate(self, num_c: int, res, labels, inc_bits, adj=None) -> torch.Tensor:
+        """vlad_matmuls_per_cluster surface: res [N,D] fp32 residuals, labels [N] (< num_c), inc_bits [S,nw]."""
+        r = _as(res, np.float32, torch.float32)
+        N, D = r.shape
+        lab = _as(labels, np.uint8, torch.uint8)
+        ib = inc_bits if isinstance(inc_bits, torch.Tensor) else np.ascontiguousarray(inc_bits)
+        S = ib.shape[0]
+        a = None
+        if adj is not None:
+            a = adj.to(torch.uint8).contiguous() if isinstance(adj, torch.Tensor) else np.ascontiguousarray(adj).astype(np.uint8)
+        out = self._empty((S, num_c * D), torch.float32)
+        self._stream()
+        self._check(self.lib.segvlad_cluster_aggregate(self._h, num_c, _ptr(r), _ptr(lab), N, D, _ptr(ib), S, _ptr(a), _ptr(out)),
+                    "cluster_aggregate")
+        self._keep = [r, lab, ib, a]
+        return out
+
     # ---- PCA --------------------------------------------------------------------------------------
     def pca_set(self, mean, components, explained_variance=None, whiten=True):
         comps = _as(components, np.float32, torch.float32)

@@ -1,0 +1,100 @@
+"""Batched SegVLAD pipeline on one GPU: the reference's per-image driver loop
+(place_rec_main.py:244-276 / 309-341: masks -> imInds -> adjacency -> seg-VLAD -> [PCA per batch] -> concat)
+restated as batch calls over device-resident inputs, followed by the ``recall_segloc`` chain
+(place_rec_main.py:44-96).  Host work is limited to what the reference also does on the host
+(Qhull Delaunay via scipy) plus launch bookkeeping."""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import SegVLADEngine
+from .func_vpr import adjacency_from_centroids
+
+_POOL: Optional[ThreadPoolExecutor] = None
+
+
+def _pool(workers: int) -> ThreadPoolExecutor:
+    global _POOL
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(max_workers=workers)
+    return _POOL
+
+
+def adjacency_batch(centroids: np.ndarray, seg_offsets: Sequence[int], order: int, workers: int = 8) -> np.ndarray:
+    """Concatenated per-image [S_b,S_b] uint8 adjacency blocks from the centroids [S_tot,2]
+    (func_vpr.py:1315-1345 per image; Qhull releases the GIL, so images run on a thread pool)."""
+    B = len(seg_offsets) - 1
+
+    def one(b):
+        c = centroids[seg_offsets[b]:seg_offsets[b + 1]]
+        return adjacency_from_centroids(c, order).numpy().astype(np.uint8).reshape(-1)
+
+    if B == 0:
+        return np.zeros(0, np.uint8)
+    parts = list(_pool(workers).map(one, range(B))) if B > 1 else [one(0)]
+    return np.concatenate(parts)
+
+
+class SegVLADPipeline:
+    def __init__(self, engine: SegVLADEngine, H: int, W: int, patch: int = 14, order: int = 3, use_pca: bool = True,
+                 adj_workers: int = 8):
+        self.eng = engine
+        self.H, self.W, self.patch = H, W, patch
+        self.order = order
+        self.use_pca = use_pca
+        self.adj_workers = adj_workers
+        self.N = (H // patch) * (W // patch)
+
+    # ---- a2..a9: images -> (normalised) segment descriptors ------------------------------------------
+    def describe(self, tokens: torch.Tensor, masks: torch.Tensor, seg_offsets: np.ndarray, adj=None,
+                 l2norm: bool = True) -> torch.Tensor:
+        """tokens [B,D,N] fp32 (device), masks [S_tot,Hm,Wm] uint8 (device), seg_offsets [B+1] (host).
+        adj: precomputed concatenated adjacency (uint8) or None to derive it (order>0) from the masks.
+        Returns [S_tot, P] (PCA'd, row-normalised when l2norm) or [S_tot, K*D]."""
+        eng = self.eng
+        bits = eng.incidence(masks, self.H, self.W, self.patch)
+        if self.order and adj is None:
+            cent = eng.mask_centroids(masks).cpu().numpy()  # D2H of S_tot x 2 doubles (synchronises)
+            adj = adjacency_batch(cent, seg_offsets, self.order, self.adj_workers)
+        elif not self.order:
+            adj = None
+        desc = eng.seg_vlad(tokens, bits, seg_offsets, adj)["out"]
+        if self.use_pca:
+            desc = eng.pca_apply(desc, l2norm=l2norm)
+        return desc
+
+    # ---- a10: index ------------------------------------------------------------------------------------
+    def index_reset(self):
+        self.eng.db_reset()
+
+    def index_add(self, desc: torch.Tensor, img_of_seg):
+        self.eng.db_add(desc, img_of_seg)
+
+    # ---- a10..a12: descriptors -> ranked reference images ----------------------------------------------
+    def retrieve(self, qdesc: torch.Tensor, qseg_offsets: np.ndarray, k_search: int = 200, k_vote: int = 50, n_top: int = 5,
+                 mode: int = _lib.VOTE_WT_BORDA_IM, want_scores: bool = False):
+        """search k_search (place_rec_main.py:56) -> keep k_vote and 2-d^2 (:78-81) -> vote (:84)."""
+        d2, idx = self.eng.search(qdesc, k_search)
+        sims, m = self.eng.sims_from_d2(d2, idx, k_vote)
+        pred, sc = self.eng.vote(m, sims, qseg_offsets, n_top=n_top, mode=mode, want_scores=want_scores)
+        return pred, sc, m, sims
+
+
+def recall_at(preds: np.ndarray, gt: List[Sequence[int]], n: int) -> List[float]:
+    """calc_recall (func_vpr.py:396-422) without the print: first correct rank, queries with empty GT skipped."""
+    rec = np.zeros(n)
+    num = 0
+    for i, g in enumerate(gt):
+        if len(g) == 0:
+            continue
+        num += 1
+        for j in range(min(n, preds.shape[1])):
+            if preds[i, j] in g:
+                rec[j] += 1
+                break
+    return (np.cumsum(rec) / max(num, 1)).tolist()

@@ -1,0 +1,111 @@
+"""Row-sharded exact segment index over the GPUs of one node (one process per GPU).
+
+The reference is single-process; sharding is the build's own layer:
+
+* the reference-segment rows are split into contiguous blocks, rank r keeps rows
+  [row_start[r], row_start[r+1]) and answers queries against its block only;
+* every rank sees the full query batch, computes its local top-k (distance, GLOBAL segment id),
+  then ONE all_gather (RCCL over xGMI when the backend is "nccl") exchanges the per-shard lists:
+  nq * k * 12 B per rank;
+* every rank merges the world*k candidates per query segment to the global top-k -- by distance,
+  ties by lower global id, i.e. exactly what a single index over all rows returns -- and votes.
+
+The compute is delegated to a backend object with the SegVLADEngine interface (db_reset, db_add,
+search, merge_topk, sims_from_d2, vote); the distributed plumbing below is backend-agnostic so
+that it can be exercised with gloo on CPU (tests/test_sharded_gloo.py) with a checker backend.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows: int, world: int) -> np.ndarray:
+    """Contiguous, balanced row blocks: row_start[r] = floor(r * n / world)."""
+    return np.array([(r * n_rows) // world for r in range(world + 1)], dtype=np.int64)
+
+
+def shard_images(n_images: int, world: int) -> np.ndarray:
+    """Contiguous image blocks (a reference image's segments never straddle two ranks)."""
+    return np.array([(r * n_images) // world for r in range(world + 1)], dtype=np.int64)
+
+
+class ShardedSegmentIndex:
+    def __init__(self, backend, rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                 device: Optional[torch.device] = None):
+        self.be = backend
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank(group) if self.distributed else 0)
+        self.world = world if world is not None else (dist.get_world_size(group) if self.distributed else 1)
+        self.device = device if device is not None else getattr(backend, "device", torch.device("cpu"))
+        self.row_start = np.zeros(self.world + 1, dtype=np.int64)
+        self.n_local = 0
+        self.img_of_seg_global: Optional[torch.Tensor] = None
+
+    # ---- build --------------------------------------------------------------------------------------
+    def build(self, local_rows, local_img_of_seg):
+        """local_rows [n_local, d] (this rank's block, in global row order), local_img_of_seg [n_local]
+        with GLOBAL reference-image ids.  Exchanges the block sizes and the (small) segment->image map."""
+        self.be.db_reset()
+        n_local = int(local_rows.shape[0])
+        counts = [n_local]
+        if self.world > 1:
+            t = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+            allc = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(allc, t, group=self.group)
+            counts = [int(c.item()) for c in allc]
+        self.row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.n_local = n_local
+        img = torch.as_tensor(np.asarray(local_img_of_seg) if not isinstance(local_img_of_seg, torch.Tensor) else local_img_of_seg)
+        img = img.to(torch.int32).to(self.device)
+        if self.world > 1:
+            mx = max(counts)
+            pad = torch.full((mx,), -1, dtype=torch.int32, device=self.device)
+            pad[:n_local] = img
+            parts = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(parts, pad, group=self.group)
+            img = torch.cat([p[:c] for p, c in zip(parts, counts)])
+        self.img_of_seg_global = img.contiguous()
+        if n_local:
+            self.be.db_add(local_rows, None)
+
+    @property
+    def n_total(self) -> int:
+        return int(self.row_start[-1])
+
+    # ---- query --------------------------------------------------------------------------------------
+    def search(self, Q, k: int):
+        """Global top-k over all shards: (d2 [nq,k] ascending, idx [nq,k] GLOBAL ids), identical on every rank."""
+        nq = int(Q.shape[0])
+        if self.n_local:
+            d2, idx = self.be.search(Q, k)
+            d2 = torch.as_tensor(d2).to(self.device)
+            idx = torch.as_tensor(idx).to(self.device)
+            idx = torch.where(idx >= 0, idx + int(self.row_start[self.rank]), idx)
+        else:
+            d2 = torch.full((nq, k), float("inf"), dtype=torch.float32, device=self.device)
+            idx = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
+        if self.world == 1:
+            return d2, idx
+        d2_parts = [torch.empty_like(d2) for _ in range(self.world)]
+        idx_parts = [torch.empty_like(idx) for _ in range(self.world)]
+        dist.all_gather(d2_parts, d2.contiguous(), group=self.group)
+        dist.all_gather(idx_parts, idx.contiguous(), group=self.group)
+        d2c = torch.cat(d2_parts, dim=1).contiguous()   # [nq, world*k], shard-major within a row
+        idc = torch.cat(idx_parts, dim=1).contiguous()
+        md, mi = self.be.merge_topk(d2c, idc, self.world, k)
+        return torch.as_tensor(md), torch.as_tensor(mi)
+
+    def retrieve(self, Q, qseg_offsets: Sequence[int], k_search: int = 200, k_vote: int = 50, n_top: int = 5, mode: int = 0,
+                 want_scores: bool = False):
+        """search -> keep k_vote, 2-d^2 -> vote with the global segment->image map.  The global min/max of the
+        vote (func_vpr.py:212-213) is taken over the merged (global) similarities, so it needs no extra collective."""
+        d2, idx = self.search(Q, k_search)
+        sims, m = self.be.sims_from_d2(d2, idx, k_vote)
+        pred, sc = self.be.vote(m, sims, np.asarray(qseg_offsets, dtype=np.int32), n_top=n_top, mode=mode,
+                                img_of_seg=self.img_of_seg_global, want_scores=want_scores)
+        return pred, sc, m, sims

@@ -1,0 +1,131 @@
+"""Host-side logic of the drop-in surface (no GPU): bookkeeping helpers, adjacency construction,
+bit packing, recall, config surface, shard arithmetic."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import segvlad_oracle as O
+from revisit_anything_amd import func_vpr, place_rec, synth
+from revisit_anything_amd.pipeline import adjacency_batch, recall_at
+from revisit_anything_amd.sharded import shard_bounds, shard_images
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_get_idx_single_fast_ignores_min_area():
+    masks = [np.zeros((4, 4), bool)] * 3
+    imInds, regInds, seg = func_vpr.getIdxSingleFast(7, masks, minArea=10 ** 9)
+    assert imInds.tolist() == [7, 7, 7] and regInds == [0, 1, 2] and len(seg) == 3
+    a, b, c = O.get_idx_single_fast(7, masks, minArea=10 ** 9)
+    assert np.array_equal(a, imInds) and b == regInds
+
+
+def test_preload_masks_natural_order():
+    store = {"img1.jpg": {"masks": {str(j): {"segmentation": np.full((2, 2), j)} for j in (10, 2, 1, 0, 11)}}}
+
+    class Leaf:
+        def __init__(self, a):
+            self.a = a
+
+        def __getitem__(self, key):
+            assert key == ()
+            return self.a
+
+    for k, v in store["img1.jpg"]["masks"].items():
+        v["segmentation"] = Leaf(v["segmentation"])
+    got = func_vpr.preload_masks(store, "img1.jpg")
+    assert [int(m[0, 0]) for m in got] == [0, 1, 2, 10, 11]
+
+
+def test_adjacency_from_centroids_matches_golden():
+    z = np.load(os.path.join(G, "adjacency_cases.npz"))
+    for S in (1, 2, 3, 4, 6, 12, 50):
+        m = np.unpackbits(z[f"S{S}_masks"], axis=1)[:, :60 * 80].reshape(S, 60, 80).astype(bool)
+        cords = O.mask_centroids([x for x in m])
+        for order in (1, 2, 3):
+            A = func_vpr.adjacency_from_centroids(cords, order)
+            assert A.dtype == torch.bool and np.array_equal(A.numpy(), z[f"S{S}_o{order}"])
+
+
+def test_adjacency_batch_concatenates_per_image_blocks():
+    offs = np.array([0, 5, 5, 8, 20])
+    cents = np.random.Generator(np.random.PCG64(4)).uniform(0, 100, size=(20, 2))
+    cat = adjacency_batch(cents, offs, order=2, workers=2)
+    pos = 0
+    for b in range(4):
+        S = offs[b + 1] - offs[b]
+        want = O.adjacency_from_centroids(cents[offs[b]:offs[b + 1]], 2).astype(np.uint8).reshape(-1)
+        assert np.array_equal(cat[pos:pos + S * S], want)
+        pos += S * S
+    assert pos == len(cat)
+
+
+def test_pack_incidence_bool_matches_oracle_layout():
+    b = np.random.Generator(np.random.PCG64(5)).random((7, 1530)) < 0.3
+    b[:, 63] = True   # exercises the sign bit of the int64 storage
+    w = func_vpr._pack_incidence_bool(torch.from_numpy(b)).numpy().view(np.uint64)
+    assert np.array_equal(w, O.pack_bits_u64(b))
+
+
+def test_offsets_from_ranges():
+    rng = [np.arange(0, 3), np.arange(3, 3), np.arange(3, 10)]
+    off, order, contiguous = func_vpr._offsets_from_ranges(rng, 3)
+    assert off.tolist() == [0, 3, 3, 10] and contiguous
+    off, order, contiguous = func_vpr._offsets_from_ranges([np.array([4, 5]), np.array([0, 1, 2, 3])], 2)
+    assert not contiguous and order.tolist() == [4, 5, 0, 1, 2, 3]
+
+
+def test_calc_recall_matches_golden(capsys):
+    z = np.load(os.path.join(G, "recall_cases.npz"))
+    gt = [[int(x) for x in row if x >= 0] for row in z["gt"]]
+    r = func_vpr.calc_recall([list(p) for p in z["preds"]], gt, 5)
+    assert np.allclose(r, z["recalls"], rtol=0, atol=0)
+    assert "POSITIVES/TOTAL" in capsys.readouterr().out
+    assert np.allclose(recall_at(z["preds"], gt, 5), z["recalls"])
+
+
+def test_map_helpers():
+    qr = func_vpr.convert_to_queries_results_for_map([[1, 2, 3], [9, 8]], [[3, 1], [7]])
+    assert qr == [[True, False, True], [False, False]]
+    assert abs(func_vpr.calculate_ap(qr[0]) - (1.0 + 2 / 3) / 2) < 1e-12 and func_vpr.calculate_ap(qr[1]) == 0
+    assert abs(func_vpr.calculate_map(qr) - (1.0 + 2 / 3) / 4) < 1e-12
+
+
+def test_weighted_borda_count_and_first_k_unique():
+    assert func_vpr.first_k_unique_indices([3, 3, 1, 3, 2, 1], 2) == [3, 1]
+    r = func_vpr.weighted_borda_count([(1, 0.5), (2, 0.5)], [(2, 0.25), (3, 0.75)])
+    assert r == [2, 3, 1] or r == [3, 2, 1]
+    assert func_vpr.weighted_borda_count([(5, 1.0), (6, 1.0)]) == [5, 6]   # stable: first appearance wins ties
+
+
+def test_gt_rules_and_config_surface(tmp_path):
+    gt = place_rec.get_gt("17places", ims2_q=list(range(3)))
+    assert gt[0][0] == -15 and gt[2][-1] == 17 and len(gt[1]) == 31
+    assert place_rec.get_gt("AmsterTime", ims1_r=["a", "b"]) == [[0], [1]]
+    exp = place_rec.default_experiment(3, True)
+    for key in ("global_method_name", "minArea", "order", "pca", "pca_model_pkl", "pca_model_pkl_map", "results_pkl_suffix"):
+        assert key in exp
+    ds = place_rec.default_dataset("17places")
+    for key in ("cfg", "masks_h5_filename_r", "masks_h5_filename_q", "dino_h5_filename_r", "dino_h5_filename_q",
+                "data_subpath1_r", "data_subpath2_q", "map_vlad_cluster", "domain_vlad_cluster"):
+        assert key in ds
+    p = tmp_path / "cfg.py"
+    p.write_text("workdir_data='/x'\ndatasets={'d':{'cfg':{'rmin':0,'desired_width':640,'desired_height':480}}}\nexperiments={'e':{'order':3,'pca':True}}\n")
+    d, e, w = place_rec.load_global_config(str(p))
+    assert d["d"]["cfg"]["desired_width"] == 640 and e["e"]["pca"] and w == "/x"
+
+
+def test_shard_arithmetic():
+    b = shard_bounds(10, 3)
+    assert b.tolist() == [0, 3, 6, 10]
+    assert shard_images(20000, 8)[-1] == 20000 and np.all(np.diff(shard_images(20000, 8)) == 2500)
+    assert shard_bounds(2, 4).tolist() == [0, 0, 1, 1, 2]   # empty shards are legal
+
+
+def test_synth_generators_are_seed_stable():
+    C = synth.make_vocab(8, 16, seed=1)
+    assert np.array_equal(C, synth.make_vocab(8, 16, seed=1))
+    assert np.allclose(np.linalg.norm(synth.make_tokens(C, 10, seed=2), axis=0), 1, atol=1e-6)
+    R, img = synth.make_planted_db(8, 3, 16, seed=3)
+    assert R.shape == (24, 16) and img.tolist()[:4] == [0, 0, 0, 1]

@@ -1,0 +1,121 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding / all_gather / merge / vote
+plumbing of ShardedSegmentIndex with a checker backend built on the oracle (tests may use the oracle;
+the product never does).  Invariant: merged ids/scores == single-index ids/scores, bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """SegVLADEngine-shaped test double (NumPy oracle inside)."""
+
+    def __init__(self):
+        from oracle import segvlad_oracle as O
+
+        self.O = O
+        self.device = torch.device("cpu")
+        self.R = None
+
+    def db_reset(self):
+        self.R = None
+
+    def db_add(self, R, img):
+        R = np.asarray(R, dtype=np.float32)
+        self.R = R if self.R is None else np.concatenate([self.R, R])
+
+    def search(self, Q, k):
+        d2, idx = self.O.knn_l2(self.R, np.asarray(Q, dtype=np.float32), k)
+        return torch.from_numpy(d2), torch.from_numpy(idx)
+
+    def merge_topk(self, d2c, idc, parts, k):
+        d2c, idc = d2c.numpy(), idc.numpy()
+        dp = [d2c[:, p * k:(p + 1) * k] for p in range(parts)]
+        ip = [idc[:, p * k:(p + 1) * k] for p in range(parts)]
+        d, i = self.O.merge_topk(dp, ip, k)
+        return torch.from_numpy(d), torch.from_numpy(i)
+
+    def sims_from_d2(self, d2, idx, k_keep):
+        return (2 - d2[:, :k_keep]).to(torch.float32), idx[:, :k_keep]
+
+    def vote(self, m, sims, qoff, n_top=5, mode=0, img_of_seg=None, want_scores=False, **kw):
+        rng = [np.arange(qoff[i], qoff[i + 1]) for i in range(len(qoff) - 1)]
+        p, sc = self.O.get_matches_wt_borda_im(m.numpy(), len(rng), sims.numpy(), rng, img_of_seg.numpy().astype(np.int64),
+                                               n=n_top, return_scores=True)
+        out = np.full((len(rng), n_top), -1, np.int32)
+        for i, row in enumerate(p):
+            out[i, :len(row)] = row
+        return torch.from_numpy(out), sc
+
+
+def make_problem():
+    from revisit_anything_amd import synth
+
+    n_img, S, d, n_q = 61, 7, 32, 9          # 427 rows: not divisible by the world size
+    R, img = synth.make_planted_db(n_img, S, d, seed=3000)
+    Q, tau, off = synth.make_planted_queries(R, n_img, S, n_q, seed=4000, sigma_q=2.0)
+    return R, img, Q, tau, off
+
+
+def worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from revisit_anything_amd.sharded import ShardedSegmentIndex, shard_images
+
+    R, img, Q, tau, off = make_problem()
+    ib = shard_images(61, world)
+    rows = slice(ib[rank] * 7, ib[rank + 1] * 7)
+    idx = ShardedSegmentIndex(OracleBackend())
+    idx.build(R[rows], img[rows])
+    assert idx.n_total == R.shape[0] and int(idx.row_start[rank]) == rows.start
+    assert np.array_equal(idx.img_of_seg_global.numpy(), img)
+    d2, ids = idx.search(Q, 20)
+    pred, sc, m, sims = idx.retrieve(Q, off, k_search=20, k_vote=10, n_top=3, want_scores=True)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d2=d2.numpy(), ids=ids.numpy(), pred=pred.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_equals_single_index(tmp_path):
+    world = 2
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle import segvlad_oracle as O
+
+    R, img, Q, tau, off = make_problem()
+    d2, ids = O.knn_l2(R, Q, 20)
+    sims = (2 - d2[:, :10]).astype(np.float32)
+    rng = [np.arange(off[i], off[i + 1]) for i in range(len(off) - 1)]
+    preds = O.get_matches_wt_borda_im(ids[:, :10], len(rng), sims, rng, img.astype(np.int64), n=3)
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["ids"], ids)        # merged ids == single-index ids, bit for bit
+        assert np.array_equal(z["d2"], d2)
+        for i, p in enumerate(preds):
+            assert z["pred"][i][:len(p)].tolist() == [int(x) for x in p]
+
+
+def test_single_process_fallback_has_no_collective():
+    from revisit_anything_amd.sharded import ShardedSegmentIndex
+
+    R, img, Q, tau, off = make_problem()
+    idx = ShardedSegmentIndex(OracleBackend(), rank=0, world=1)
+    idx.build(R, img)
+    d2, ids = idx.search(Q, 5)
+    from oracle import segvlad_oracle as O
+
+    assert np.array_equal(ids.numpy(), O.knn_l2(R, Q, 5)[1])
