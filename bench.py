@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""bench.py -- SegVLAD retrieval hot path on MI355X (see DESIGN.md section "Measurement").
+
+One STEP = one pass of the hot path over one batch of synthetic query images whose inputs (DINO
+token blocks [D][N] fp32 and SAM masks [S][Hm][Wm] u8) are already resident in HBM:
+
+    masks -> incidence -> centroids -> (host Qhull) adjacency^order -> segment-VLAD (K clusters)
+          -> PCA-whiten + L2  -> exact kNN (search 200) against the row-sharded segment DB
+          -> [N>1: all_gather of per-shard top-k + merge] -> keep 50, 2-d^2 -> weighted image vote
+
+Workload (BASELINE.json north_star / configs[3] shape, fits one GPU once PCA'd): 200 query images
+x 50 segments, 640x480 -> 34x45 = 1530 tokens, D=1536, K=64, PCA 1024, DB = 20 000 reference images
+x 50 = 1 M segments.  The DB is built (untimed) by the same VLAD+PCA kernels from synthetic reference
+images; queries are perturbed copies of reference images so Recall@1 is meaningful.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Strong scaling: the 1 M-segment DB and the 200-image query batch
+are fixed; rank r holds DB rows of reference images [r*n/N, (r+1)*n/N) and describes query images
+[r*200/N, (r+1)*200/N) before an all_gather of the 1024-d query descriptors.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from revisit_anything_amd import synth  # noqa: E402
+from revisit_anything_amd.engine import SegVLADEngine  # noqa: E402
+from revisit_anything_amd.pipeline import SegVLADPipeline, recall_at  # noqa: E402
+from revisit_anything_amd.sharded import ShardedSegmentIndex, shard_images  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--query-images", type=int, default=200)
+    p.add_argument("--db-images", type=int, default=20000)
+    p.add_argument("--segments", type=int, default=50)
+    p.add_argument("--clusters", type=int, default=64)
+    p.add_argument("--dim", type=int, default=1536)
+    p.add_argument("--height", type=int, default=480)
+    p.add_argument("--width", type=int, default=640)
+    p.add_argument("--pca-dim", type=int, default=1024)
+    p.add_argument("--order", type=int, default=3)
+    p.add_argument("--no-pca", action="store_true", help="raw K*D descriptors (only with a small --db-images)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--build-batch", type=int, default=100)
+    return p.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic images, generated on the GPU from per-batch seeds (torch) so that 20k reference images
+# never touch the host.  Reference images come in groups of 4 "same place" siblings.
+# ------------------------------------------------------------------------------------------------
+class ImageFactory:
+    def __init__(self, dev, C: torch.Tensor, N: int, S: int, Hm: int, Wm: int):
+        self.dev, self.C, self.N, self.S, self.Hm, self.Wm = dev, C, N, S, Hm, Wm
+        self.K, self.D = C.shape
+        self.yy = torch.arange(Hm, device=dev).view(1, Hm, 1)
+        self.xx = torch.arange(Wm, device=dev).view(1, 1, Wm)
+
+    def _gen(self, seed):
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(int(seed))
+        return g
+
+    def group(self, gid: int):
+        """Shared content of a sibling group: cluster ids, base noise, masks."""
+        g = self._gen(10_000_019 + gid)
+        z = torch.randint(0, self.K, (self.N,), device=self.dev, generator=g)
+        base = torch.randn(self.N, self.D, device=self.dev, generator=g)
+        S, Hm, Wm = self.S, self.Hm, self.Wm
+        h = torch.randint(8, 61, (S,), device=self.dev, generator=g)
+        w = torch.randint(8, 81, (S,), device=self.dev, generator=g)
+        y0 = (torch.rand(S, device=self.dev, generator=g) * (Hm - h + 1)).long()
+        x0 = (torch.rand(S, device=self.dev, generator=g) * (Wm - w + 1)).long()
+        m = (self.yy >= y0.view(S, 1, 1)) & (self.yy < (y0 + h).view(S, 1, 1)) & (self.xx >= x0.view(S, 1, 1)) & (self.xx < (x0 + w).view(S, 1, 1))
+        return z, base, m.to(torch.uint8)
+
+    def own_noise(self, img_id: int):
+        return torch.randn(self.N, self.D, device=self.dev, generator=self._gen(20_000_003 + img_id))
+
+    def tokens(self, z, base, own):
+        x = self.C[z] + 0.05 * (0.8 * base + 0.6 * own)
+        return torch.nn.functional.normalize(x, dim=1).t().contiguous()      # [D,N] as the reference stores it
+
+    def reference(self, img_id: int):
+        z, base, m = self.group(img_id // 4)
+        return self.tokens(z, base, self.own_noise(img_id)), m
+
+    def query(self, tau: int, qid: int):
+        z, base, m = self.group(tau // 4)
+        own = 0.7 * self.own_noise(tau) + 0.714 * torch.randn(self.N, self.D, device=self.dev, generator=self._gen(30_000_001 + qid))
+        return self.tokens(z, base, own), m
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    S, K, D = a.segments, a.clusters, a.dim
+    H, W = a.height, a.width
+    N = (H // 14) * (W // 14)
+    Hm, Wm = H // 2, W // 2              # SAM masks at half resolution (place_rec_SAM_DINO.py:61)
+    use_pca = not a.no_pca
+    P = a.pca_dim if use_pca else K * D
+    nQ, nR = a.query_images, a.db_images
+
+    eng = SegVLADEngine(local)
+    C_np = synth.make_vocab(K, D, seed=1000)
+    eng.set_vocab(C_np)
+    C = torch.from_numpy(C_np).to(dev)
+    if use_pca:
+        g = torch.Generator(device=dev)
+        g.manual_seed(5000)
+        comps = torch.randn(P, K * D, device=dev, generator=g) / (K * D) ** 0.5
+        mean = torch.randn(K * D, device=dev, generator=g) * (0.2 / (K * D) ** 0.5)
+        var = torch.logspace(-3, -6, P, device=dev)
+        eng.pca_set(mean, comps, var, whiten=True)
+        del comps
+    pipe = SegVLADPipeline(eng, H, W, 14, order=a.order, use_pca=use_pca)
+    fac = ImageFactory(dev, C, N, S, Hm, Wm)
+
+    # ---- queries: tau = seeded choice of reference images ---------------------------------------------
+    rq = np.random.Generator(np.random.PCG64(4000))
+    tau = rq.integers(0, nR, size=nQ)
+    qb = shard_images(nQ, world)
+    q_lo, q_hi = int(qb[rank]), int(qb[rank + 1])
+    nq_local = q_hi - q_lo
+    q_tok = torch.empty(nq_local, D, N, device=dev)
+    q_msk = torch.empty(nq_local * S, Hm, Wm, dtype=torch.uint8, device=dev)
+    for j, qi in enumerate(range(q_lo, q_hi)):
+        t, m = fac.query(int(tau[qi]), qi)
+        q_tok[j] = t
+        q_msk[j * S:(j + 1) * S] = m
+    q_off_local = (np.arange(nq_local + 1) * S).astype(np.int32)
+    q_off_all = (np.arange(nQ + 1) * S).astype(np.int32)
+
+    # ---- DB shard (untimed build through the same kernels) -----------------------------------------------
+    t_build0 = time.time()
+    ib = shard_images(nR, world)
+    r_lo, r_hi = int(ib[rank]), int(ib[rank + 1])
+    rows = torch.empty((r_hi - r_lo) * S, P, device=dev)
+    bb = a.build_batch
+    tok = torch.empty(bb, D, N, device=dev)
+    msk = torch.empty(bb * S, Hm, Wm, dtype=torch.uint8, device=dev)
+    for b0 in range(r_lo, r_hi, bb):
+        nb = min(bb, r_hi - b0)
+        for j in range(nb):
+            t, m = fac.reference(b0 + j)
+            tok[j] = t
+            msk[j * S:(j + 1) * S] = m
+        offs = (np.arange(nb + 1) * S).astype(np.int32)
+        d = pipe.describe(tok[:nb], msk[:nb * S], offs)
+        rows[(b0 - r_lo) * S:(b0 - r_lo + nb) * S] = d
+    del tok, msk
+    img_of_seg = torch.arange(r_lo, r_hi, device=dev, dtype=torch.int32).repeat_interleave(S)
+    index = ShardedSegmentIndex(eng, rank=rank, world=world, device=dev)
+    index.build(rows, img_of_seg)
+    rows_keep = rows if (world == 1 and not a.no_cpu_baseline) else None   # host copy source for the CPU-baseline leg
+    del rows
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build0
+
+    # ---- one step ---------------------------------------------------------------------------------------------
+    def step():
+        qd = pipe.describe(q_tok, q_msk, q_off_local)
+        if world > 1:
+            parts = [torch.empty((int(qb[r + 1] - qb[r]) * S, P), device=dev) for r in range(world)]
+            dist.all_gather(parts, qd.contiguous())
+            qd = torch.cat(parts)
+        return index.retrieve(qd, q_off_all, 200, 50, 5)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    eng.set_profiling(True)
+    eng.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    pred = out[0].cpu().numpy()
+    gt = [[int(t)] for t in tau]
+    recalls = recall_at(pred, gt, 5)
+
+    # ---- per-stage device time (HIP events on the engine stream, summed over the timed steps) ----------------
+    stages = {}
+    for s in ("incidence", "assign", "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote"):
+        try:
+            ms, n = eng.stage_ms(s)
+            stages[s] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps}
+        except Exception:
+            pass
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel ------------------------------------------------------------------------
+    n_local_rows = index.n_local
+    d_knn = P
+    dom = max(stages, key=lambda k: stages[k]["ms_per_step"]) if stages else None
+    roof = None
+    if dom in ("knn_gemm", "knn_select", "pca"):
+        # the exact-kNN stage (distance GEMM + selection) and the PCA projection are fp32-MFMA bound;
+        # the selection kernels are accounted to the kNN stage's GEMM as overhead, the roofline is quoted on the GEMM
+        key = "pca" if dom == "pca" else "knn_gemm"
+        if key == "knn_gemm":
+            flops_step = 2.0 * nQ * S * n_local_rows * d_knn          # 2 * B_q * N_r * d (algorithmic)
+            kern = "gemm_nt_kernel<2> (Q.R^T, fused ||q||^2+||r||^2-2qr + threshold-filter epilogue)"
+        else:
+            flops_step = 2.0 * nq_local * S * (K * D) * P              # 2 * S * K*D * P per image
+            kern = "gemm_nt_kernel<0> (PCA projection, fused mean-subtract + whitening scale)"
+        launches = stages[key]["launches_per_step"]
+        avg_ms = stages[key]["ms_per_step"] / max(launches, 1)
+        ach = flops_step / (stages[key]["ms_per_step"] * 1e-3) / 1e12
+        roof = {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                "dominant_stage": dom}
+    elif dom is not None:
+        bytes_img = 4 * D * N + 4 * S * K * D + S * N / 8 + S * S + S * Hm * Wm
+        ms = sum(stages[s]["ms_per_step"] for s in ("incidence", "assign", "prep", "aggregate") if s in stages)
+        ach = bytes_img * nq_local / (ms * 1e-3) / 1e9
+        roof = {"kernel": "segment-VLAD kernels (incidence+assign+prep+aggregate)", "bound": "hbm", "achieved": ach,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None, "dominant_stage": dom}
+    # secondary: the HBM-bound VLAD stage, always reported
+    vlad_ms = sum(stages[s]["ms_per_step"] for s in ("incidence", "assign", "prep", "aggregate") if s in stages)
+    bytes_img = 4 * D * N + 4 * S * K * D + S * N / 8 + S * S + S * Hm * Wm
+    vlad_roof = {"bound": "hbm", "achieved": bytes_img * nq_local / (vlad_ms * 1e-3) / 1e9 if vlad_ms else None,
+                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "alg_bytes_per_image": bytes_img}
+    if vlad_roof["achieved"]:
+        vlad_roof["frac"] = vlad_roof["achieved"] / PEAK_HBM_GBS
+
+    res = {
+        "metric": "query_images_per_sec", "value": nQ * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{nQ} query images x {S} seg vs {nR * S}-segment DB ({nR} ref images), {W}x{H} -> {N} tokens, "
+                               f"D={D}, K={K}, {'PCA ' + str(P) if use_pca else 'raw K*D'}, order {a.order}, search 200 / vote 50",
+                   "query_images": nQ, "db_segments": nR * S, "segments_per_image": S, "clusters": K, "desc_dim": D,
+                   "tokens": N, "pca_dim": P if use_pca else None, "order": a.order, "parallelism": f"db-row-shard x{world}"},
+        "recall_at_1": recalls[0], "recall_at_5": recalls[4], "db_build_s": t_build,
+        "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in stages.items()},
+        "roofline": roof, "roofline_vlad": vlad_roof,
+    }
+
+    if world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a, rows_keep, fac, tau, C_np, use_pca, P, N, S, K, D, H, W, pred)
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, db_rows, fac, tau, C_np, use_pca, P, N, S, K, D, H, W, pred):
+    """The oracle (NumPy restatement of the reference, 'port') timed on this box's host cores on a BOUNDED
+    sample of the same workload: 2 query images through adjacency+seg-VLAD+PCA, 1 image (50 segments) through
+    the exact kNN against the full DB (fp32 sgemm, what faiss IndexFlatL2 runs), the vote for those.  Also the
+    checker: the device predictions for the sampled images must equal the oracle's."""
+    from oracle import segvlad_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    n_s = 2
+    t_desc = 0.0
+    descs = []
+    for qi in range(n_s):
+        t, m = fac.query(int(tau[qi]), qi)
+        t, m = t.cpu().numpy(), m.cpu().numpy().astype(bool)
+        t0 = time.perf_counter()
+        inc = O.incidence(m, H, W)
+        adj = O.nbr_masks_agg_fast_single([x for x in m], a.order) if a.order else None
+        v = O.seg_vlad(t, inc, C_np, adj)
+        t_desc += time.perf_counter() - t0
+        descs.append(v)
+    # PCA transform of the sampled descriptors with the same synthetic model (regenerated on the host)
+    t_pca = 0.0
+    if use_pca:
+        g = torch.Generator(device=fac.dev)
+        g.manual_seed(5000)
+        comps = (torch.randn(P, K * D, device=fac.dev, generator=g) / (K * D) ** 0.5)
+        mean = (torch.randn(K * D, device=fac.dev, generator=g) * (0.2 / (K * D) ** 0.5)).cpu().numpy()
+        comps = comps.cpu().numpy()
+        var = torch.logspace(-3, -6, P).numpy()
+        t0 = time.perf_counter()
+        ys = [O.normalize_feat(O.pca_transform(v, mean, comps, var, True)) for v in descs]
+        t_pca = time.perf_counter() - t0
+        del comps
+    else:
+        ys = descs
+    # exact kNN of ONE image against the full DB on the host (fp32 sgemm like faiss)
+    Rh = db_rows.cpu().numpy()
+    n_db, d = Rh.shape
+    q = ys[0].astype(np.float32)
+    t0 = time.perf_counter()
+    rn = (Rh * Rh).sum(1)
+    d2 = (q * q).sum(1)[:, None] + rn[None, :] - 2.0 * (q @ Rh.T)
+    part = np.argpartition(d2, 200, axis=1)[:, :200]
+    pd = np.take_along_axis(d2, part, 1)
+    o = np.argsort(pd, axis=1, kind="stable")
+    idx = np.take_along_axis(part, o, 1)
+    dd = np.take_along_axis(pd, o, 1)
+    t_knn = time.perf_counter() - t0
+    sims = (2 - dd[:, :50]).astype(np.float32)
+    img = (np.arange(n_db) // S).astype(np.int64)
+    t0 = time.perf_counter()
+    p = O.get_matches_wt_borda_im(idx[:, :50], 1, sims, [np.arange(S)], img, n=5)
+    t_vote = time.perf_counter() - t0
+    per_img = t_desc / n_s + t_pca / n_s + t_knn + t_vote
+    return {"value": 1.0 / per_img, "unit": "images/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_s} query images for adjacency+seg-VLAD(+PCA), 1 image (50 segs) exact kNN vs the full {n_db}-row DB (fp32 sgemm), vote",
+            "seconds": {"seg_vlad_per_img": t_desc / n_s, "pca_per_img": t_pca / n_s, "knn_per_img": t_knn, "vote_per_img": t_vote},
+            "top1_matches_device": bool(int(p[0][0]) == int(pred[0][0]))}
+
+
+if __name__ == "__main__":
+    main()

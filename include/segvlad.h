@@ -136,10 +136,14 @@ int segvlad_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const 
                  int64_t n_ref_seg, const int32_t* qseg_offsets, int n_img, int k, float smin, float smax, int n_top, int mode,
                  int32_t* pred_out, double* score_out);
 
-/* ---- instrumentation: HIP-event time (ms) of the kernels enqueued by the last call of the named
- *      stage ("assign", "prep", "aggregate", "incidence", "pca", "knn_gemm", "knn_select", "vote").
- *      Only valid after segvlad_set_profiling(ctx, 1); returns <0 if the stage never ran.          */
+/* ---- instrumentation: with profiling on, every kernel group of a stage ("incidence", "assign",
+ *      "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote") is bracketed by a HIP event pair
+ *      on the context stream.  segvlad_stage_ms returns the SUM of the elapsed times (ms) and the number
+ *      of kernel launches recorded for the stage since the last segvlad_profile_reset; it returns
+ *      SEGVLAD_ERR_STATE if the stage has not run.  Replaces the (discarded) time.time() pair of
+ *      vlad_matmuls_per_cluster, func_vpr.py:1185,1207-1210.                                          */
 int segvlad_set_profiling(segvlad_ctx* ctx, int on);
+int segvlad_profile_reset(segvlad_ctx* ctx);
 int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* launches_out);
 
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ SIGNATURES = {
     "segvlad_vote": (C.c_int, [c_ctx_p, C.c_void_p, _f32p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                 C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "segvlad_set_profiling": (C.c_int, [c_ctx_p, C.c_int]),
+    "segvlad_profile_reset": (C.c_int, [c_ctx_p]),
     "segvlad_stage_ms": (C.c_int, [c_ctx_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 

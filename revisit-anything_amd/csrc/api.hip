@@ -78,16 +78,18 @@ int sv_finish(segvlad_ctx* ctx) {
 StageScope::StageScope(segvlad_ctx* c, const char* name) : ctx(c) {
   if (!c->profiling) return;
   t = &c->timers[name];
-  if (!t->ev0) {
-    (void)hipEventCreate(&t->ev0);
-    (void)hipEventCreate(&t->ev1);
+  if (t->used * 2 >= (int)t->ev.size()) {
+    hipEvent_t a = nullptr, b = nullptr;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    t->ev.push_back(a);
+    t->ev.push_back(b);
   }
-  t->launches = 0;
-  t->valid = true;
-  (void)hipEventRecord(t->ev0, c->stream);
+  slot = t->used++;
+  (void)hipEventRecord(t->ev[2 * slot], c->stream);
 }
 StageScope::~StageScope() {
-  if (t) (void)hipEventRecord(t->ev1, ctx->stream);
+  if (t) (void)hipEventRecord(t->ev[2 * slot + 1], ctx->stream);
 }
 
 #define CHECK_CTX()                 \
@@ -121,10 +123,9 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
-  for (auto& kv : ctx->timers) {
-    if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0);
-    if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1);
-  }
+  for (auto& kv : ctx->timers)
+    for (hipEvent_t e : kv.second.ev)
+      if (e) (void)hipEventDestroy(e);
   delete ctx;
   return SEGVLAD_OK;
 }
@@ -149,14 +150,31 @@ int segvlad_set_profiling(segvlad_ctx* ctx, int on) {
   return SEGVLAD_OK;
 }
 
+int segvlad_profile_reset(segvlad_ctx* ctx) {
+  if (!ctx) return SEGVLAD_ERR_ARG;
+  for (auto& kv : ctx->timers) {
+    kv.second.used = 0;
+    kv.second.launches = 0;
+  }
+  return SEGVLAD_OK;
+}
+
 int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* launches_out) {
   CHECK_CTX();
   if (!stage || !ms_out) return ctx->fail(SEGVLAD_ERR_ARG, "stage_ms: null argument");
   auto it = ctx->timers.find(stage);
-  if (it == ctx->timers.end() || !it->second.valid) return ctx->fail(SEGVLAD_ERR_STATE, "stage '%s' has not run with profiling on", stage);
-  SV_HIP(hipEventSynchronize(it->second.ev1));
-  SV_HIP(hipEventElapsedTime(ms_out, it->second.ev0, it->second.ev1));
-  if (launches_out) *launches_out = it->second.launches;
+  if (it == ctx->timers.end() || it->second.used == 0)
+    return ctx->fail(SEGVLAD_ERR_STATE, "stage '%s' has not run with profiling on", stage);
+  StageTimer& t = it->second;
+  double total = 0.0;
+  for (int i = 0; i < t.used; ++i) {
+    SV_HIP(hipEventSynchronize(t.ev[2 * i + 1]));
+    float ms = 0.f;
+    SV_HIP(hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]));
+    total += ms;
+  }
+  *ms_out = (float)total;
+  if (launches_out) *launches_out = t.launches;
   return SEGVLAD_OK;
 }
 
@@ -453,6 +471,36 @@ int segvlad_db_size(segvlad_ctx* ctx, int64_t* n_rows, int* d) {
   return SEGVLAD_OK;
 }
 
+// Exact search.  Small databases: distance matrix + radix select.  Large ones: a strided 1/16^L sample gives an
+// exact UPPER bound T0[q] of the k-th smallest distance; each finer level re-runs the distance GEMM with the
+// epilogue keeping only entries <= T[q] (about 16 k per query), whose exact top-k tightens T for the next level;
+// the last level covers every row, so the final top-k is exact (ties included: all entries <= T are candidates
+// and the final order is (distance, id)).  If a candidate list overflows (adversarial data) the chunk is redone
+// on the matrix path.
+static int search_matrix(segvlad_ctx* ctx, const float* dq, int m, int64_t n, int d, int k, const float* qn, float* dd2,
+                         int64_t* didx) {
+  const int64_t ld = (n + 3) & ~3ll;
+  int64_t rows = ld > 0 ? (int64_t)(2ll << 30) / (ld * 4) : m;
+  if (rows < 128) rows = 128;
+  if (rows > m) rows = m;
+  SV_HIP(ctx->s_dist.reserve((size_t)rows * (ld > 0 ? ld : 1) * 4));
+  for (int64_t q0 = 0; q0 < m; q0 += rows) {
+    const int mm = (int)((m - q0 < rows) ? (m - q0) : rows);
+    {
+      StageScope sc(ctx, "knn_gemm");
+      SV_TRY(sv_launch_gemm_nt(ctx, 1, dq + (size_t)q0 * d, ctx->db_rows.as<float>(), ctx->s_dist.as<float>(), mm, (int)n, d,
+                               ld, nullptr, nullptr, qn + q0, ctx->db_norms.as<float>()));
+      sc.count();
+    }
+    {
+      StageScope sc(ctx, "knn_select");
+      SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld, mm, n, k, dd2 + (size_t)q0 * k, didx + (size_t)q0 * k, k, 0));
+      sc.count();
+    }
+  }
+  return SEGVLAD_OK;
+}
+
 int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_out, int64_t* idx_out) {
   CHECK_CTX();
   if (nq < 0 || k < 1 || k > 1024) return ctx->fail(SEGVLAD_ERR_ARG, "search: need nq>=0 and 1<=k<=1024 (k=%d)", k);
@@ -468,27 +516,71 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_TRY(sv_out(ctx, idx_out, (size_t)nq * k * 8, &didx));
   SV_HIP(ctx->s_qnorm.reserve((size_t)nq * 4));
   SV_TRY(sv_launch_row_sumsq(ctx, (const float*)dq, nq, d, ctx->s_qnorm.as<float>()));
-  // distance-matrix workspace: chunk the queries so that chunk x n floats <= ~2 GiB
-  const int64_t ld = (n + 3) & ~3ll;
-  int64_t chunk = ld > 0 ? (int64_t)(2ll << 30) / (ld * 4) : nq;
-  if (chunk < 128) chunk = 128;
-  if (chunk > nq) chunk = nq;
-  SV_HIP(ctx->s_dist.reserve((size_t)chunk * (ld > 0 ? ld : 1) * 4));
-  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
-    const int m = (int)((nq - q0 < chunk) ? (nq - q0) : chunk);
-    {
-      StageScope sc(ctx, "knn_gemm");
-      SV_TRY(sv_launch_gemm_nt(ctx, 1, (const float*)dq + (size_t)q0 * d, ctx->db_rows.as<float>(), ctx->s_dist.as<float>(), m,
-                               (int)n, d, ld, nullptr, nullptr, ctx->s_qnorm.as<float>() + q0, ctx->db_norms.as<float>()));
+  const float* qn = ctx->s_qnorm.as<float>();
+
+  // level plan: strides 16^L, ..., 16, 1 with the coarsest sample <= 32768 rows (and >= 2048 > k)
+  constexpr int RATIO = 16, CAP = 8192;
+  int levels = 0;
+  int64_t stride0 = 1;
+  while (n / stride0 > 32768) {
+    stride0 *= RATIO;
+    ++levels;
+  }
+  if (levels == 0 || n / stride0 < 4 * (int64_t)k) {
+    SV_TRY(search_matrix(ctx, (const float*)dq, nq, n, d, k, qn, (float*)dd2, (int64_t*)didx));
+    return sv_finish(ctx);
+  }
+  const int chunk = 4096;
+  SV_HIP(ctx->s_cand_cnt.reserve((size_t)chunk * 4));
+  SV_HIP(ctx->s_cand_d2.reserve((size_t)chunk * CAP * 4));
+  SV_HIP(ctx->s_cand_id.reserve((size_t)chunk * CAP * 4));
+  SV_HIP(ctx->s_thr_d2.reserve((size_t)chunk * k * 4));
+  SV_HIP(ctx->s_thr_idx.reserve((size_t)chunk * k * 8));
+  SV_HIP(ctx->s_flag.reserve(64));
+  SV_HIP(hipMemsetAsync(ctx->s_flag.p, 0, 4, ctx->stream));
+  const float* R = ctx->db_rows.as<float>();
+  const float* rn = ctx->db_norms.as<float>();
+  const int64_t n0 = (n + stride0 - 1) / stride0;
+  const int64_t ld0 = (n0 + 3) & ~3ll;
+  SV_HIP(ctx->s_dist.reserve((size_t)chunk * ld0 * 4));
+  for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const int m = (nq - q0 < chunk) ? (nq - q0) : chunk;
+    const float* qp = (const float*)dq + (size_t)q0 * d;
+    float* thr = ctx->s_thr_d2.as<float>();
+    {  // level 0: exact top-k of the coarsest sample -> thr[q][k-1]
+      {
+        StageScope sc(ctx, "knn_gemm");
+        SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn + q0, rn, (int)stride0));
+        sc.count();
+      }
+      StageScope sc(ctx, "knn_select");
+      SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, k, thr, ctx->s_thr_idx.as<int64_t>(), k, 0));
       sc.count();
     }
-    {
+    int64_t stride = stride0;
+    for (int lv = 1; lv <= levels; ++lv) {
+      stride /= RATIO;
+      const int64_t ns = (n + stride - 1) / stride;
+      const bool last = (lv == levels);
+      SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
+      {
+        StageScope sc(ctx, "knn_gemm");
+        SV_TRY(sv_launch_l2_filter(ctx, qp, R, m, (int)ns, d, qn + q0, rn, (int)stride, thr + (k - 1), k,
+                                   ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
+        sc.count();
+      }
       StageScope sc(ctx, "knn_select");
-      SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld, m, n, k, (float*)dd2 + (size_t)q0 * k,
-                                   (int64_t*)didx + (size_t)q0 * k, k, 0));
+      // the filter pass has consumed thr; the select may overwrite it with the tighter thresholds
+      SV_TRY(sv_launch_select_cand(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(),
+                                   m, CAP, k, last ? (float*)dd2 + (size_t)q0 * k : thr, last ? (int64_t*)didx + (size_t)q0 * k : nullptr,
+                                   ctx->s_flag.as<uint32_t>()));
       sc.count();
     }
   }
+  uint32_t flag = 0;
+  SV_HIP(hipMemcpyAsync(&flag, ctx->s_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  if (flag) SV_TRY(search_matrix(ctx, (const float*)dq, nq, n, d, k, qn, (float*)dd2, (int64_t*)didx));
   return sv_finish(ctx);
 }
 

@@ -53,10 +53,13 @@ struct DevBuf {
   T* as() { return reinterpret_cast<T*>(p); }
 };
 
+// Accumulating stage timer: every StageScope records one (start, stop) event pair on the context
+// stream; segvlad_stage_ms() sums the elapsed times of all pairs recorded since the last
+// segvlad_profile_reset() (events are resolved lazily, nothing synchronises while timing).
 struct StageTimer {
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev;  // pairs: ev[2i], ev[2i+1]
+  int used = 0;                // number of pairs in use
   int launches = 0;
-  bool valid = false;
 };
 
 struct segvlad_ctx {
@@ -83,7 +86,7 @@ struct segvlad_ctx {
 
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
-  DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff;
+  DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -106,6 +109,7 @@ void sv_begin(segvlad_ctx* ctx);
 struct StageScope {
   segvlad_ctx* ctx;
   StageTimer* t = nullptr;
+  int slot = 0;
   StageScope(segvlad_ctx* c, const char* name);
   ~StageScope();
   void count(int n = 1) { if (t) t->launches += n; }
@@ -137,7 +141,19 @@ int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* B
                       int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
                       const float* col_add);
 
+// distance of every query to database rows 0, b_stride, 2*b_stride, ... (n_sample of them); column j of
+// `dist` is sample j
+int sv_launch_l2_strided(segvlad_ctx* ctx, const float* Q, const float* R, float* dist, int M, int n_sample, int Kd,
+                         int64_t ldc, const float* qn, const float* rn, int b_stride);
+// same distances, but entries <= thr[m*thr_ld] are appended to (cand_d2, cand_id)[m][0..cap) via cand_cnt[m]
+int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M, int n_sample, int Kd, const float* qn,
+                        const float* rn, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
+                        float* cand_d2, uint32_t* cand_id, int cap);
+
 // select_kernels.hip
+// top-k of per-query candidate lists (LDS sort on (distance, id)); lists longer than cap set *overflow
+int sv_launch_select_cand(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id,
+                          int nq, int cap, int k, float* d2_out, int64_t* idx_out, uint32_t* overflow);
 int sv_launch_select_topk(segvlad_ctx* ctx, const float* dist, int64_t ld, int nq, int64_t n, int k, float* d2_out,
                           int64_t* idx_out, int64_t out_ld, int64_t id_base);
 int sv_launch_merge_topk(segvlad_ctx* ctx, const float* d2_parts, const int64_t* idx_parts, int nq, int cand, int k,

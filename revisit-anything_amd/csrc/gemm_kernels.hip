@@ -3,6 +3,9 @@
 //
 //   mode 0 (PCA apply, func_vpr.py:1434-1438): A' = A - a_sub[k];  C = acc * col_scale[n]
 //   mode 1 (exact L2,  place_rec_main.py:53-56): C = row_add[m] + col_add[n] - 2 acc
+//   mode 2 (exact L2, filtered): the same distance, but instead of storing the matrix every entry
+//           with d2 <= thr[m] is appended to the per-query candidate list (atomic slot counter);
+//           B rows may be a strided sample (row j of the operand = database row j * b_stride).
 //
 // Tile 128x128x32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles.  Operands are staged k-major in
 // LDS ([k][row], +4 pad) so that an MFMA operand read is 32 consecutive dwords per half-wave
@@ -38,7 +41,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                                                       const float* __restrict__ a_sub,
                                                       const float* __restrict__ col_scale,
                                                       const float* __restrict__ row_add,
-                                                      const float* __restrict__ col_add, int tiles_m) {
+                                                      const float* __restrict__ col_add, int tiles_m,
+                                                      int b_stride, const float* __restrict__ thr, int64_t thr_ld,
+                                                      uint32_t* __restrict__ cand_cnt, float* __restrict__ cand_d2,
+                                                      uint32_t* __restrict__ cand_id, int cap) {
   __shared__ float As[BK * LDT];
   __shared__ float Bs[BK * LDT];
   // tile order: m fastest so that the workgroups sharing a B panel (the big operand: database /
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ra[j] = ld4_guard(A, m0 + lrow + 32 * j, M, k0 + lk, Kd, Kd, vec);
-      rb[j] = ld4_guard(Bm, n0 + lrow + 32 * j, N, k0 + lk, Kd, Kd, vec);
+      rb[j] = ld4_guard(Bm, n0 + lrow + 32 * j, N, k0 + lk, Kd, (int64_t)Kd * b_stride, vec);
     }
     if (MODE == 0 && a_sub != nullptr) {
       float4 s = ld4_guard(a_sub, 0, 1, k0 + lk, Kd, 0, vec && ((reinterpret_cast<uintptr_t>(a_sub) & 15) == 0));
@@ -119,40 +125,73 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   for (int nt = 0; nt < 2; ++nt) {
     const int64_t col = n0 + wn * 64 + nt * 32 + i;
     if (col >= N) continue;
-    const float cs = (MODE == 0) ? (col_scale ? col_scale[col] : 1.f) : col_add[col];
+    const float cs = (MODE == 0) ? (col_scale ? col_scale[col] : 1.f) : col_add[col * b_stride];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (row < M) {
-          float v;
-          if (MODE == 0)
-            v = acc[mt][nt][r] * cs;
-          else
-            v = (row_add[row] + cs) - 2.f * acc[mt][nt][r];
-          C[row * ldc + col] = v;
+          if (MODE == 0) {
+            C[row * ldc + col] = acc[mt][nt][r] * cs;
+          } else {
+            const float v = (row_add[row] + cs) - 2.f * acc[mt][nt][r];
+            if (MODE == 1) {
+              C[row * ldc + col] = v;
+            } else if (v <= thr[row * thr_ld]) {
+              const uint32_t slot = atomicAdd(&cand_cnt[row], 1u);
+              if (slot < (uint32_t)cap) {
+                cand_d2[row * cap + slot] = v;
+                cand_id[row * cap + slot] = (uint32_t)(col * b_stride);
+              }
+            }
+          }
         }
       }
     }
   }
 }
 
-int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
-                      int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
-                      const float* col_add) {
+static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
+                       int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
+                       const float* col_add, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
+                       float* cand_d2, uint32_t* cand_id, int cap) {
   if (M <= 0 || N <= 0) return SEGVLAD_OK;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "gemm: too many tiles");
+#define SV_GEMM_ARGS                                                                                               \
+  dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A, Bm, C, M, N, Kd, ldc, a_sub, col_scale, row_add, col_add, \
+      tiles_m, b_stride, thr, thr_ld, cand_cnt, cand_d2, cand_id, cap
   if (mode == 0)
-    hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A, Bm, C, M, N, Kd, ldc, a_sub,
-                       col_scale, row_add, col_add, tiles_m);
+    hipLaunchKernelGGL(gemm_nt_kernel<0>, SV_GEMM_ARGS);
+  else if (mode == 1)
+    hipLaunchKernelGGL(gemm_nt_kernel<1>, SV_GEMM_ARGS);
   else
-    hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A, Bm, C, M, N, Kd, ldc, a_sub,
-                       col_scale, row_add, col_add, tiles_m);
+    hipLaunchKernelGGL(gemm_nt_kernel<2>, SV_GEMM_ARGS);
+#undef SV_GEMM_ARGS
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
+}
+
+int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
+                      int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
+                      const float* col_add) {
+  return gemm_launch(ctx, mode, A, Bm, C, M, N, Kd, ldc, a_sub, col_scale, row_add, col_add, 1, nullptr, 0, nullptr, nullptr,
+                     nullptr, 0);
+}
+
+int sv_launch_l2_strided(segvlad_ctx* ctx, const float* Q, const float* R, float* dist, int M, int n_sample, int Kd,
+                         int64_t ldc, const float* qn, const float* rn, int b_stride) {
+  return gemm_launch(ctx, 1, Q, R, dist, M, n_sample, Kd, ldc, nullptr, nullptr, qn, rn, b_stride, nullptr, 0, nullptr, nullptr,
+                     nullptr, 0);
+}
+
+int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M, int n_sample, int Kd, const float* qn,
+                        const float* rn, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
+                        float* cand_d2, uint32_t* cand_id, int cap) {
+  return gemm_launch(ctx, 2, Q, R, nullptr, M, n_sample, Kd, 0, nullptr, nullptr, qn, rn, b_stride, thr, thr_ld, cand_cnt,
+                     cand_d2, cand_id, cap);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -179,6 +179,57 @@ int sv_launch_select_topk(segvlad_ctx* ctx, const float* dist, int64_t ld, int n
 }
 
 // ------------------------------------------------------------------------------------------------
+// top-k of a per-query candidate list produced by the filtered GEMM epilogue (unordered, <= cap
+// entries).  (key, id) pairs are sorted in LDS, so the result does not depend on the order in which
+// the atomics handed out the slots.  A list that overflowed its capacity raises *overflow and the
+// caller falls back to the matrix path.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_cand_kernel(const uint32_t* __restrict__ cnt,
+                                                          const float* __restrict__ cd2,
+                                                          const uint32_t* __restrict__ cid, int cap, int k,
+                                                          float* __restrict__ d2_out, int64_t* __restrict__ idx_out,
+                                                          uint32_t* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const uint32_t c = cnt[row];
+  if (c > (uint32_t)cap) {
+    if (tid == 0) atomicOr(overflow, 1u);
+    return;
+  }
+  int npad = 2;
+  while (npad < (int)c) npad <<= 1;
+  for (int j = tid; j < npad; j += 256)
+    a[j] = (j < (int)c) ? (((uint64_t)f2key(cd2[row * cap + j]) << 32) | cid[row * cap + j]) : ~0ull;
+  bitonic_sort_lds(a, npad, tid, 256);
+  for (int j = tid; j < k; j += 256) {
+    float d = INFINITY;
+    int64_t id = -1;
+    if (j < (int)c) {
+      d = key2f((uint32_t)(a[j] >> 32));
+      id = (int64_t)(uint32_t)a[j];
+    }
+    d2_out[row * k + j] = d;
+    if (idx_out) idx_out[row * k + j] = id;
+  }
+}
+
+int sv_launch_select_cand(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id,
+                          int nq, int cap, int k, float* d2_out, int64_t* idx_out, uint32_t* overflow) {
+  if (nq <= 0) return SEGVLAD_OK;
+  const size_t lds = (size_t)cap * 8;
+  if (lds > 128 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "select_cand: cap=%d exceeds the LDS sort", cap);
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_cand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(select_cand_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, k, d2_out,
+                     idx_out, overflow);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // merge of per-shard lists: sort (key, id) pairs; id -1 (empty slot) sorts last
 // ------------------------------------------------------------------------------------------------
 struct KeyId {

@@ -86,7 +86,11 @@ class SegVLADEngine:
     def set_profiling(self, on: bool):
         self.lib.segvlad_set_profiling(self._h, int(on))
 
+    def profile_reset(self):
+        self.lib.segvlad_profile_reset(self._h)
+
     def stage_ms(self, stage: str):
+        """(total ms, kernel launches) of the stage since the last profile_reset()."""
         ms, n = C.c_float(), C.c_int()
         self._stream()
         self._check(self.lib.segvlad_stage_ms(self._h, stage.encode(), C.byref(ms), C.byref(n)), f"stage_ms({stage})")

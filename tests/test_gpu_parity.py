@@ -351,3 +351,53 @@ def test_e2e_small_golden(eng):
     gt[5] = []
     rec = O().calc_recall([list(p[p >= 0]) for p in pred], gt, 5)
     assert np.allclose(rec, z["recalls"])
+
+
+# ------------------------------------------------------------------------------------------------
+# large-database search path: sampled thresholds + filtered GEMM epilogue (exactness must not depend on it)
+# ------------------------------------------------------------------------------------------------
+def test_knn_leveled_filter_path_is_exact(eng):
+    rng = np.random.Generator(np.random.PCG64(200))
+    n, d, nq, k = 70001, 48, 300, 50          # > 32768 rows: one filter level (stride 16)
+    R = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    R[5000] = R[123]                            # exact duplicates: ties must resolve to the lower id
+    R[60000] = R[123]
+    Q[0] = R[123] + 1e-3
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = (t.cpu().numpy() for t in eng.search(Q, k))
+    rd2, ridx = O().knn_l2(R, Q, k)
+    assert np.all(np.diff(d2, axis=1) >= 0)
+    assert np.abs(d2 - rd2).max() < 2e-4 * rd2.max()
+    assert idx[0][:3].tolist() == [123, 5000, 60000]
+    sep = np.minimum(np.diff(rd2, axis=1, prepend=-1), np.diff(rd2, axis=1, append=1e9)) > 1e-3
+    assert np.array_equal(idx[sep], ridx[sep])
+    assert (idx == ridx).mean() > 0.99
+    # the same rows through the plain matrix path (database split below the level threshold) give identical bits
+    parts = [(0, 30000), (30000, 60000), (60000, n)]
+    dp, ip = [], []
+    for a, b in parts:
+        eng.db_reset()
+        eng.db_add(R[a:b])
+        dd, ii = eng.search(Q, k)
+        dp.append(dd.cpu().numpy())
+        ip.append(np.where(ii.cpu().numpy() >= 0, ii.cpu().numpy() + a, -1))
+    dm, im = O().merge_topk(dp, ip, k)
+    assert np.array_equal(im, idx) and np.array_equal(dm, d2)
+
+
+def test_knn_filter_overflow_falls_back_to_exact(eng):
+    """Adversarial layout: every sampled row (id % 16 == 0) is far away, all other rows are near -> the sampled
+    threshold admits everything, the candidate lists overflow, and the search must still be exact."""
+    rng = np.random.Generator(np.random.PCG64(201))
+    n, d, nq, k = 40000, 16, 20, 10
+    R = (rng.standard_normal((n, d)) * 0.01).astype(np.float32)
+    R[::16] += 100.0
+    Q = (rng.standard_normal((nq, d)) * 0.01).astype(np.float32)
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = (t.cpu().numpy() for t in eng.search(Q, k))
+    rd2, ridx = O().knn_l2(R, Q, k)
+    assert np.abs(d2 - rd2).max() < 1e-6
+    assert (idx == ridx).mean() > 0.9 and np.all(idx % 16 != 0)
