@@ -60,6 +60,7 @@ def parse():
     p.add_argument("--no-pca", action="store_true", help="raw K*D descriptors (only with a small --db-images)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--build-batch", type=int, default=100)
+    p.add_argument("--debug-timing", action="store_true", help="after the timed region, print a synchronised per-phase wall-clock breakdown of one step to stderr")
     return p.parse_args()
 
 
@@ -217,6 +218,23 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if a.debug_timing and rank == 0:
+        def tick(label, t_prev):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            print(f"[debug-timing] {label}: {(t - t_prev) * 1e3:.2f} ms", file=sys.stderr)
+            return t
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        bits = eng.incidence(q_msk, H, W, 14); t = tick("incidence", t)
+        cent = eng.mask_centroids(q_msk).cpu().numpy(); t = tick("centroids + D2H", t)
+        from revisit_anything_amd.pipeline import adjacency_batch
+        adj = adjacency_batch(cent, q_off_local, a.order, pipe.adj_workers); t = tick("host adjacency (Qhull)", t)
+        desc = eng.seg_vlad(q_tok, bits, q_off_local, adj)["out"]; t = tick("seg_vlad (incl. adj H2D)", t)
+        qd = eng.pca_apply(desc, l2norm=True) if use_pca else desc; t = tick("pca", t)
+        d2, idx = eng.search(qd, 200); t = tick("search", t)
+        sims, m = eng.sims_from_d2(d2, idx, 50); t = tick("sims", t)
+        eng.vote(m, sims, q_off_all, n_top=5, img_of_seg=index.img_of_seg_global); t = tick("vote", t)
     pred = out[0].cpu().numpy()
     gt = [[int(t)] for t in tau]
     recalls = recall_at(pred, gt, 5)

@@ -67,6 +67,16 @@ int segvlad_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int
  *      centroids [S][2] fp64 (x, y); an empty mask yields NaN (the reference raises ValueError).  */
 int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* centroids);
 
+/* ---- neighbourhood adjacency for a batch: getNbrsDelaunay + nbrMasksAGGFastSingle
+ *      func_vpr.py:1241-1245, 1315-1345.  centroids [S_tot][2] fp64 (x, y) from segvlad_mask_centroids,
+ *      seg_offsets [B+1] int32 HOST, order >= 1.  adj_out: concatenated per-image [S_b][S_b] byte
+ *      matrices = (A1^order > 0), A1 = Delaunay neighbours + self loop; images with S_b <= 3 get the
+ *      reference's special rows e0(+e1).  Computed on the device (empty-circle test per point pair;
+ *      identical to Qhull for points in general position).  n_empty_out (HOST, may be NULL): number of
+ *      NaN centroids (= empty masks, for which the reference raises ValueError); passing it synchronises. */
+int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
+                      uint8_t* adj_out, uint32_t* n_empty_out);
+
 /* ---- segment VLAD for a batch of B images of identical token geometry
  *      seg_vlad_gpu_single(_img) -> vlad_single -> vlad_matmuls_per_cluster   func_vpr.py:1065-1210
  *      tokens      [B][D][N] fp32, as stored by the reference (D-major, N contiguous)
@@ -136,8 +146,8 @@ int segvlad_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const 
                  int64_t n_ref_seg, const int32_t* qseg_offsets, int n_img, int k, float smin, float smax, int n_top, int mode,
                  int32_t* pred_out, double* score_out);
 
-/* ---- instrumentation: with profiling on, every kernel group of a stage ("incidence", "assign",
- *      "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote") is bracketed by a HIP event pair
+/* ---- instrumentation: with profiling on, every kernel group of a stage ("incidence", "adjacency",
+ *      "assign", "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote") is bracketed by a HIP event pair
  *      on the context stream.  segvlad_stage_ms returns the SUM of the elapsed times (ms) and the number
  *      of kernel launches recorded for the stage since the last segvlad_profile_reset; it returns
  *      SEGVLAD_ERR_STATE if the stage has not run.  Replaces the (discarded) time.time() pair of

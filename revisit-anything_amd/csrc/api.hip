@@ -232,6 +232,47 @@ int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm
   return sv_finish(ctx);
 }
 
+int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
+                      uint8_t* adj_out, uint32_t* n_empty_out) {
+  CHECK_CTX();
+  if (B < 0 || order < 1) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency: need B>=0 and order>=1 (order 0 = pass adj=NULL)");
+  if (B == 0) return SEGVLAD_OK;
+  if (!centroids || !seg_offsets || !adj_out) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency: null pointer");
+  if (sv_is_device_ptr(seg_offsets)) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency: seg_offsets must be host memory");
+  int S_max = 0;
+  std::vector<int64_t> adj_off(B + 1, 0);
+  for (int b = 0; b < B; ++b) {
+    const int s = seg_offsets[b + 1] - seg_offsets[b];
+    if (s < 0) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency: seg_offsets must be non-decreasing");
+    if (s > S_max) S_max = s;
+    adj_off[b + 1] = adj_off[b] + (int64_t)s * s;
+  }
+  const int S_tot = seg_offsets[B];
+  if (S_tot == 0) return SEGVLAD_OK;
+  const void* dc;
+  void* dout;
+  SV_TRY(sv_in(ctx, centroids, (size_t)S_tot * 2 * sizeof(double), &dc));
+  SV_TRY(sv_out(ctx, adj_out, (size_t)adj_off[B], &dout));
+  SV_HIP(ctx->s_segoff.reserve((size_t)(B + 1) * sizeof(int32_t)));
+  SV_HIP(ctx->s_adjoff.reserve((size_t)(B + 1) * sizeof(int64_t)));
+  SV_HIP(ctx->s_flag.reserve(64));
+  SV_HIP(hipMemcpyAsync(ctx->s_segoff.p, seg_offsets, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  SV_HIP(hipMemcpyAsync(ctx->s_adjoff.p, adj_off.data(), (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  uint32_t* bad = ctx->s_flag.as<uint32_t>() + 4;
+  SV_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
+  {
+    StageScope sc(ctx, "adjacency");
+    SV_TRY(sv_launch_adjacency(ctx, (const double*)dc, ctx->s_segoff.as<int32_t>(), ctx->s_adjoff.as<int64_t>(), B, S_max, order,
+                               (uint8_t*)dout, bad));
+    sc.count();
+  }
+  if (n_empty_out) {
+    SV_HIP(hipMemcpyAsync(n_empty_out, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SV_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return sv_finish(ctx);
+}
+
 // ---- segment VLAD -----------------------------------------------------------------------------------
 int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
                    const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out, float* gap_out,

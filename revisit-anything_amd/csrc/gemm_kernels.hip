@@ -8,15 +8,15 @@
 //           B rows may be a strided sample (row j of the operand = database row j * b_stride).
 //
 // Tile 128x128x32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles.  Operands are staged k-major in
-// LDS ([k][row], +4 pad) so that an MFMA operand read is 32 consecutive dwords per half-wave
-// (conflict-free ds_read_b32); the next k-tile is prefetched into registers while the current one
-// is multiplied.
+// LDS ([k][row], row stride 129) so that an MFMA operand read is 32 consecutive dwords per half-wave
+// (conflict-free ds_read_b32) and the transposing stores are conflict-free too; LDS is double
+// buffered (one barrier per k-tile), global loads run two k-tiles ahead in registers.
 #include "ctx.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = 132;
+constexpr int BM = 128, BN = 128, BK = 32, LDT = 129;  // LDT = 1 (mod 32): conflict-free k-major stores
 
 __device__ __forceinline__ float4 ld4_guard(const float* base, int64_t row, int64_t nrows, int k, int Kd, int64_t ld,
                                             bool vec) {
@@ -35,6 +35,124 @@ __device__ __forceinline__ float4 ld4_guard(const float* base, int64_t row, int6
   return v;
 }
 
+// One k-tile of global data per thread: 4 x float4 of A and of B (rows lrow + 32 j, k quad lk).
+struct Stage {
+  float4 a[4], b[4];
+};
+
+template <int MODE, bool FAST>
+__device__ __forceinline__ void gload_tile(Stage& st, const float* __restrict__ A, const float* __restrict__ Bm,
+                                           const float* __restrict__ a_sub, int64_t m0, int64_t n0, int M, int N, int Kd,
+                                           int64_t ldb, int lrow, int lk, int k0, bool vec) {
+  if (FAST) {  // interior tile: no guards, 16-B loads only
+    const float* pa = A + (m0 + lrow) * (int64_t)Kd + k0 + lk;
+    const float* pb = Bm + (n0 + lrow) * ldb + k0 + lk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st.a[j] = *reinterpret_cast<const float4*>(pa + (int64_t)32 * j * Kd);
+      st.b[j] = *reinterpret_cast<const float4*>(pb + (int64_t)32 * j * ldb);
+    }
+    if (MODE == 0 && a_sub != nullptr) {
+      const float4 s = *reinterpret_cast<const float4*>(a_sub + k0 + lk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st.a[j].x -= s.x;
+        st.a[j].y -= s.y;
+        st.a[j].z -= s.z;
+        st.a[j].w -= s.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st.a[j] = ld4_guard(A, m0 + lrow + 32 * j, M, k0 + lk, Kd, Kd, vec);
+      st.b[j] = ld4_guard(Bm, n0 + lrow + 32 * j, N, k0 + lk, Kd, ldb, vec);
+    }
+    if (MODE == 0 && a_sub != nullptr) {
+      const float4 s = ld4_guard(a_sub, 0, 1, k0 + lk, Kd, 0, vec && ((reinterpret_cast<uintptr_t>(a_sub) & 15) == 0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // rows beyond M are never stored
+        st.a[j].x -= s.x;
+        st.a[j].y -= s.y;
+        st.a[j].z -= s.z;
+        st.a[j].w -= s.w;
+      }
+    }
+  }
+}
+
+// write quarter q (= row group j) of the staged tile into the k-major LDS image
+__device__ __forceinline__ void sstore_part(const Stage& st, float* As, float* Bs, int lrow, int lk, int j) {
+  const int r = lrow + 32 * j;
+  As[(lk + 0) * LDT + r] = st.a[j].x;
+  As[(lk + 1) * LDT + r] = st.a[j].y;
+  As[(lk + 2) * LDT + r] = st.a[j].z;
+  As[(lk + 3) * LDT + r] = st.a[j].w;
+  Bs[(lk + 0) * LDT + r] = st.b[j].x;
+  Bs[(lk + 1) * LDT + r] = st.b[j].y;
+  Bs[(lk + 2) * LDT + r] = st.b[j].z;
+  Bs[(lk + 3) * LDT + r] = st.b[j].w;
+}
+
+// Main loop.  LDS is double buffered (one barrier per k-tile): while tile kt is multiplied out of
+// buffer `cur`, the registers holding tile kt+1 are written into the other buffer during the second
+// half of the MFMA sequence (their global loads were issued a full k-tile earlier), and the loads of
+// tile kt+2 are issued right after the barrier.  MFMA operands for step ks+1 are read from LDS before
+// the four MFMAs of step ks are issued.
+template <int MODE, bool FAST>
+__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], float* lds, const float* __restrict__ A,
+                                              const float* __restrict__ Bm, const float* __restrict__ a_sub, int64_t m0,
+                                              int64_t n0, int M, int N, int Kd, int64_t ldb, int tid, bool vec) {
+  const int w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int wm = w >> 1, wn = w & 1;
+  const int lrow = tid >> 3, lk = (tid & 7) << 2;
+  const int ntiles = (Kd + BK - 1) / BK;
+  Stage st;
+  gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, 0, vec);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sstore_part(st, lds, lds + BK * LDT, lrow, lk, j);
+  if (ntiles > 1) gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, BK, vec);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const float* As = lds + cur * (2 * BK * LDT);
+    const float* Bs = As + BK * LDT;
+    float* Asn = lds + (cur ^ 1) * (2 * BK * LDT);
+    float* Bsn = Asn + BK * LDT;
+    const bool have_next = kt + 1 < ntiles;
+    const float* ap = As + kk * LDT + wm * 64 + i;
+    const float* bp = Bs + kk * LDT + wn * 64 + i;
+    float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (ks + 1 < BK / 2) {
+        na0 = ap[(2 * ks + 2) * LDT];
+        na1 = ap[(2 * ks + 2) * LDT + 32];
+        nb0 = bp[(2 * ks + 2) * LDT];
+        nb1 = bp[(2 * ks + 2) * LDT + 32];
+      }
+      acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+      acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+      acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+      acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+      if (have_next && ks >= BK / 2 - 4) sstore_part(st, Asn, Bsn, lrow, lk, ks - (BK / 2 - 4));
+      // keep the operand reads of step ks+1 AHEAD of the MFMAs of step ks (the scheduler otherwise sinks
+      // them behind the MFMAs to reuse the operand registers, exposing the LDS latency every step)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);  // DS write (second half of the tile only)
+      a0 = na0;
+      a1 = na1;
+      b0 = nb0;
+      b1 = nb1;
+    }
+    __syncthreads();
+    if (kt + 2 < ntiles) gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, (kt + 2) * BK, vec);
+    cur ^= 1;
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                       float* __restrict__ C, int M, int N, int Kd, int64_t ldc,
@@ -45,8 +163,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                                                       int b_stride, const float* __restrict__ thr, int64_t thr_ld,
                                                       uint32_t* __restrict__ cand_cnt, float* __restrict__ cand_d2,
                                                       uint32_t* __restrict__ cand_id, int cap) {
-  __shared__ float As[BK * LDT];
-  __shared__ float Bs[BK * LDT];
+  __shared__ float lds[2 * 2 * BK * LDT];  // [buffer][A|B][k][row]
   // tile order: m fastest so that the workgroups sharing a B panel (the big operand: database /
   // PCA components) are adjacent in dispatch order
   const int tile = blockIdx.x;
@@ -56,8 +173,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   const int wm = w >> 1, wn = w & 1;
   const bool vec = ((Kd & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
-  // loader mapping: thread -> (row = tid/8 + 32 j, k quad = (tid & 7) * 4), j = 0..3
-  const int lrow = tid >> 3, lk = (tid & 7) << 2;
+  const int64_t ldb = (int64_t)Kd * b_stride;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -67,58 +183,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 ra[4], rb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = ld4_guard(A, m0 + lrow + 32 * j, M, k0 + lk, Kd, Kd, vec);
-      rb[j] = ld4_guard(Bm, n0 + lrow + 32 * j, N, k0 + lk, Kd, (int64_t)Kd * b_stride, vec);
-    }
-    if (MODE == 0 && a_sub != nullptr) {
-      float4 s = ld4_guard(a_sub, 0, 1, k0 + lk, Kd, 0, vec && ((reinterpret_cast<uintptr_t>(a_sub) & 15) == 0));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // rows beyond M stay zero-filled; they are never stored
-        ra[j].x -= s.x;
-        ra[j].y -= s.y;
-        ra[j].z -= s.z;
-        ra[j].w -= s.w;
-      }
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = lrow + 32 * j;
-      As[(lk + 0) * LDT + r] = ra[j].x;
-      As[(lk + 1) * LDT + r] = ra[j].y;
-      As[(lk + 2) * LDT + r] = ra[j].z;
-      As[(lk + 3) * LDT + r] = ra[j].w;
-      Bs[(lk + 0) * LDT + r] = rb[j].x;
-      Bs[(lk + 1) * LDT + r] = rb[j].y;
-      Bs[(lk + 2) * LDT + r] = rb[j].z;
-      Bs[(lk + 3) * LDT + r] = rb[j].w;
-    }
-  };
-
-  const int ntiles = (Kd + BK - 1) / BK;
-  gload(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();  // previous tile's LDS reads are done
-    sstore();
-    __syncthreads();
-    if (kt + 1 < ntiles) gload((kt + 1) * BK);
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const float* ap = As + (2 * ks + kk) * LDT + wm * 64 + i;
-      const float* bp = Bs + (2 * ks + kk) * LDT + wn * 64 + i;
-      const float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
-      acc[0][0] = MFMA32(a0, b0, acc[0][0]);
-      acc[0][1] = MFMA32(a0, b1, acc[0][1]);
-      acc[1][0] = MFMA32(a1, b0, acc[1][0]);
-      acc[1][1] = MFMA32(a1, b1, acc[1][1]);
-    }
-  }
+  const bool fast = vec && (Kd % BK == 0) && (m0 + BM <= M) && (n0 + BN <= N) &&
+                    (MODE != 0 || a_sub == nullptr || (reinterpret_cast<uintptr_t>(a_sub) & 15) == 0);
+  if (fast)
+    gemm_mainloop<MODE, true>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec);
+  else
+    gemm_mainloop<MODE, false>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec);
 
   // ---- epilogue ---------------------------------------------------------------------------------
 #pragma unroll

@@ -162,6 +162,122 @@ int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// adjacency: Delaunay neighbours of the mask centroids + self loop, raised to `order`
+// (nbrMasksAGGFastSingle, func_vpr.py:1315-1345), one workgroup per image, no host round trip.
+//
+// Edge (u,v) belongs to the Delaunay triangulation iff some circle through u and v is empty.  The
+// circles through u,v are a one-parameter family (centre on the bisector, parameter t); a point p
+// on the left of u->v excludes t > tau_p, a point on the right excludes t < tau_p, with
+//     tau_p = ((p-u).(p-v)) / cross(v-u, p-u)            (a cotangent of the angle u-p-v).
+// So the edge exists iff max_{right} tau <= min_{left} tau, and a point strictly inside the segment
+// blocks it.  O(S) per pair, fp64.  Generic inputs give exactly Qhull's triangulation; exactly
+// co-circular quadruples (where the triangulation is not unique) keep both diagonals.
+// S <= 3 reproduces the reference's special case: every row = e0 (+ e1).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict__ cent,
+                                                        const int32_t* __restrict__ seg_off,
+                                                        const int64_t* __restrict__ adj_off, int order, int S_max,
+                                                        uint8_t* __restrict__ adj, uint32_t* __restrict__ n_bad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
+  const int SW = (S_max + 63) >> 6;
+  double* px = reinterpret_cast<double*>(smem);                  // [S_max]
+  double* py = px + S_max;                                       // [S_max]
+  uint64_t* A1 = reinterpret_cast<uint64_t*>(py + S_max);        // [S_max][SW]
+  uint64_t* P = A1 + (size_t)S_max * SW;                         // [S_max][SW]
+  uint64_t* Q = P + (size_t)S_max * SW;                          // [S_max][SW]
+  const int tid = threadIdx.x;
+  if (S == 0) return;
+  uint8_t* out = adj + adj_off[b];
+  for (int s = tid; s < S; s += 256) {
+    px[s] = cent[2 * (size_t)(s0 + s)];
+    py[s] = cent[2 * (size_t)(s0 + s) + 1];
+    if (px[s] != px[s] && n_bad) atomicAdd(n_bad, 1u);  // NaN centroid = empty mask (reference: ValueError)
+  }
+  for (int j = tid; j < S * SW; j += 256) A1[j] = 0;
+  __syncthreads();
+  if (S <= 3) {
+    for (int j = tid; j < S * S; j += 256) {
+      const int w = j % S;
+      out[j] = (w == 0 || (w == 1 && S > 1)) ? 1 : 0;
+    }
+    return;
+  }
+  for (int e = tid; e < S * S; e += 256) {
+    const int u = e / S, v = e - u * S;
+    if (u == v) {
+      atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (u >> 6)]), 1ull << (u & 63));
+      continue;
+    }
+    if (u > v) continue;
+    const double ux = px[u], uy = py[u], vx = px[v], vy = py[v];
+    const double ex = vx - ux, ey = vy - uy;
+    double tmin = INFINITY, tmax = -INFINITY;
+    bool blocked = false;
+    for (int p = 0; p < S; ++p) {
+      if (p == u || p == v) continue;
+      const double ax = px[p] - ux, ay = py[p] - uy;
+      const double bx = px[p] - vx, by = py[p] - vy;
+      const double num = fma(ax, bx, ay * by);
+      const double den = fma(ex, ay, -(ey * ax));
+      if (den > 0.0) {
+        tmin = fmin(tmin, num / den);
+      } else if (den < 0.0) {
+        tmax = fmax(tmax, num / den);
+      } else if (num < 0.0) {
+        blocked = true;
+      }
+    }
+    if (!blocked && tmax <= tmin) {
+      atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (v >> 6)]), 1ull << (v & 63));
+      atomicOr(reinterpret_cast<unsigned long long*>(&A1[v * SW + (u >> 6)]), 1ull << (u & 63));
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < S * SW; j += 256) P[j] = A1[j];
+  __syncthreads();
+  for (int it = 1; it < order; ++it) {  // P <- (P . A1) > 0
+    for (int j = tid; j < S * SW; j += 256) {
+      const int v = j / SW, w = j - v * SW;
+      uint64_t acc = 0;
+      for (int uw = 0; uw < SW; ++uw) {
+        uint64_t m = P[v * SW + uw];
+        while (m) {
+          const int u = (uw << 6) + __ffsll((unsigned long long)m) - 1;
+          m &= m - 1;
+          acc |= A1[u * SW + w];
+        }
+      }
+      Q[j] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < S * SW; j += 256) P[j] = Q[j];
+    __syncthreads();
+  }
+  for (int j = tid; j < S * S; j += 256) {
+    const int v = j / S, w = j - v * S;
+    out[j] = (uint8_t)((P[v * SW + (w >> 6)] >> (w & 63)) & 1ull);
+  }
+}
+
+int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg_off_dev, const int64_t* adj_off_dev,
+                        int B, int S_max, int order, uint8_t* adj, uint32_t* n_bad) {
+  if (B <= 0 || S_max <= 0) return SEGVLAD_OK;
+  const int SW = (S_max + 63) / 64;
+  const size_t lds = (size_t)S_max * 16 + (size_t)3 * S_max * SW * 8;
+  if (lds > 160 * 1024)
+    return ctx->fail(SEGVLAD_ERR_LIMIT, "adjacency: %d segments in one image exceed the LDS budget (%zu B)", S_max, lds);
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adjacency_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(adjacency_kernel, dim3(B), dim3(256), lds, ctx->stream, cent, seg_off_dev, adj_off_dev, order, S_max,
+                     adj, n_bad);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // assign: workgroup = (image, 64-token tile), 4 waves split D in 64-wide chunks.
 //   A operand  (32 tokens x 2 d):  lane (i = l&31, kk = l>>5) loads T[d0+kk][t0+2i .. 2i+1]  (8 B/lane,
 //              256 B contiguous per half-wave) -> M-tile 0 = even tokens, M-tile 1 = odd tokens

@@ -127,6 +127,24 @@ class SegVLADEngine:
         self._keep = [m]
         return out
 
+    def adjacency(self, centroids, seg_offsets, order: int, check_empty: bool = False) -> torch.Tensor:
+        """centroids [S_tot,2] fp64 -> uint8 buffer with the concatenated per-image [S_b,S_b] (A1^order > 0)
+        blocks, computed on the device.  check_empty=True synchronises and raises ValueError on an empty mask
+        (the reference's behaviour)."""
+        c = _as(centroids, np.float64, torch.float64)
+        so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+        B = len(so) - 1
+        total = int(((so[1:] - so[:-1]).astype(np.int64) ** 2).sum())
+        out = self._empty((total,), torch.uint8)
+        n_bad = (C.c_uint32 * 1)(0)
+        self._stream()
+        self._check(self.lib.segvlad_adjacency(self._h, _ptr(c), _ptr(so), B, int(order), _ptr(out),
+                                               C.cast(n_bad, C.c_void_p) if check_empty else None), "adjacency")
+        self._keep = [c]
+        if check_empty and n_bad[0]:
+            raise ValueError(f"{n_bad[0]} empty mask(s): centroid undefined")
+        return out
+
     # ---- segment VLAD -----------------------------------------------------------------------------
     def seg_vlad(self, tokens, inc_bits, seg_offsets: Sequence[int], adj=None, want_labels=False, want_gap=False,
                  want_block_norms=False, out: Optional[torch.Tensor] = None):

@@ -42,12 +42,13 @@ def adjacency_batch(centroids: np.ndarray, seg_offsets: Sequence[int], order: in
 
 class SegVLADPipeline:
     def __init__(self, engine: SegVLADEngine, H: int, W: int, patch: int = 14, order: int = 3, use_pca: bool = True,
-                 adj_workers: int = 8):
+                 adj_workers: int = 8, host_adjacency: bool = False):
         self.eng = engine
         self.H, self.W, self.patch = H, W, patch
         self.order = order
         self.use_pca = use_pca
         self.adj_workers = adj_workers
+        self.host_adjacency = host_adjacency
         self.N = (H // patch) * (W // patch)
 
     # ---- a2..a9: images -> (normalised) segment descriptors ------------------------------------------
@@ -59,8 +60,11 @@ class SegVLADPipeline:
         eng = self.eng
         bits = eng.incidence(masks, self.H, self.W, self.patch)
         if self.order and adj is None:
-            cent = eng.mask_centroids(masks).cpu().numpy()  # D2H of S_tot x 2 doubles (synchronises)
-            adj = adjacency_batch(cent, seg_offsets, self.order, self.adj_workers)
+            cent = eng.mask_centroids(masks)
+            if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)
+                adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
+            else:                     # device kernel: no host round trip
+                adj = eng.adjacency(cent, seg_offsets, self.order)
         elif not self.order:
             adj = None
         desc = eng.seg_vlad(tokens, bits, seg_offsets, adj)["out"]

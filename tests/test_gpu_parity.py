@@ -401,3 +401,57 @@ def test_knn_filter_overflow_falls_back_to_exact(eng):
     rd2, ridx = O().knn_l2(R, Q, k)
     assert np.abs(d2 - rd2).max() < 1e-6
     assert (idx == ridx).mean() > 0.9 and np.all(idx % 16 != 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# device adjacency (empty-circle test) against Qhull (the reference's library) and the golden cases
+# ------------------------------------------------------------------------------------------------
+def test_adjacency_device_matches_golden_masks(eng):
+    z = np.load(os.path.join(G, "adjacency_cases.npz"))
+    for S in (1, 2, 3, 4, 6, 12, 50):
+        m = np.unpackbits(z[f"S{S}_masks"], axis=1)[:, :60 * 80].reshape(S, 60, 80).astype(np.uint8)
+        cent = eng.mask_centroids(m)
+        for order in (1, 2, 3):
+            a = eng.adjacency(cent, np.array([0, S], np.int32), order).cpu().numpy().reshape(S, S)
+            assert np.array_equal(a.astype(bool), z[f"S{S}_o{order}"]), (S, order)
+
+
+def test_adjacency_device_matches_qhull_on_random_centroids(eng):
+    rng = np.random.Generator(np.random.PCG64(300))
+    sizes = [0, 1, 2, 3, 4, 5, 7, 20, 50, 64, 65, 150]
+    cents = [rng.uniform(0, 320, size=(S, 2)) * [1.0, 0.75] for S in sizes]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    cat = np.concatenate(cents)
+    for order in (1, 2, 3):
+        a = eng.adjacency(cat, offs, order).cpu().numpy()
+        pos = 0
+        for S, c in zip(sizes, cents):
+            want = O().adjacency_from_centroids(c, order)
+            got = a[pos:pos + S * S].reshape(S, S).astype(bool)
+            assert np.array_equal(got, want), (S, order)
+            pos += S * S
+        assert pos == len(a)
+
+
+def test_adjacency_empty_mask_raises(eng):
+    m = np.zeros((5, 20, 20), np.uint8)
+    m[:4, 3:6, 3:9] = 1
+    m[1, 10:12, 1:3] = 1
+    cent = eng.mask_centroids(m)
+    with pytest.raises(ValueError):
+        eng.adjacency(cent, np.array([0, 5], np.int32), 2, check_empty=True)
+
+
+def test_pipeline_device_adjacency_equals_host_qhull(eng):
+    import torch
+    from revisit_anything_amd.pipeline import SegVLADPipeline
+
+    K, D, H, W, S, B = 32, 64, 112, 140, 12, 3
+    C = synth().make_vocab(K, D, seed=1)
+    eng.set_vocab(C)
+    toks = torch.from_numpy(np.stack([synth().make_tokens(C, 80, seed=10 + b, noise=0.2) for b in range(B)])).to(eng.device)
+    masks = torch.from_numpy(np.concatenate([synth().make_blob_masks(S, 56, 70, seed=20 + b) for b in range(B)]).astype(np.uint8)).to(eng.device)
+    offs = (np.arange(B + 1) * S).astype(np.int32)
+    d_dev = SegVLADPipeline(eng, H, W, order=3, use_pca=False, host_adjacency=False).describe(toks, masks, offs).cpu().numpy()
+    d_host = SegVLADPipeline(eng, H, W, order=3, use_pca=False, host_adjacency=True).describe(toks, masks, offs).cpu().numpy()
+    assert np.array_equal(d_dev, d_host)
