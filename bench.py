@@ -40,7 +40,13 @@ from revisit_anything_amd.pipeline import SegVLADPipeline, recall_at  # noqa: E4
 from revisit_anything_amd.sharded import ShardedSegmentIndex, shard_images  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
+
+
+def eng_filter_products() -> int:
+    """MFMA products the kNN filter spends per algorithmic fp32 multiply-add (bf16x3 split = 3, fp16 = 1)."""
+    return 1 if os.environ.get("SEGVLAD_KNN_FILTER", "f16") == "f16" else 3
 
 
 def parse():
@@ -241,7 +247,7 @@ def main():
 
     # ---- per-stage device time (HIP events on the engine stream, summed over the timed steps) ----------------
     stages = {}
-    for s in ("incidence", "assign", "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote"):
+    for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote"):
         try:
             ms, n = eng.stage_ms(s)
             stages[s] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps}
@@ -264,16 +270,24 @@ def main():
         key = "pca" if dom == "pca" else "knn_gemm"
         if key == "knn_gemm":
             flops_step = 2.0 * nQ * S * n_local_rows * d_knn          # 2 * B_q * N_r * d (algorithmic)
-            kern = "gemm_nt_kernel<2> (Q.R^T, fused ||q||^2+||r||^2-2qr + threshold-filter epilogue)"
+            kern = ("knn_bf16_filter_kernel (Q.R^T as 3 bf16 MFMA products hi.hi+hi.lo+lo.hi, fused d2 + threshold-filter epilogue; "
+                    "exact fp32 refinement of the survivors)")
         else:
             flops_step = 2.0 * nq_local * S * (K * D) * P              # 2 * S * K*D * P per image
             kern = "gemm_nt_kernel<0> (PCA projection, fused mean-subtract + whitening scale)"
         launches = stages[key]["launches_per_step"]
         avg_ms = stages[key]["ms_per_step"] / max(launches, 1)
-        ach = flops_step / (stages[key]["ms_per_step"] * 1e-3) / 1e12
-        roof = {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches,
-                "dominant_stage": dom}
+        f32_equiv = flops_step / (stages[key]["ms_per_step"] * 1e-3) / 1e12
+        if key == "knn_gemm":
+            # the filter GEMM runs on the 16-bit MFMA pipe: PRODUCTS_PER_FMA MFMA products per algorithmic fp32 fma
+            prods = eng_filter_products()
+            ach, peak, unit_note = f32_equiv * prods, PEAK_16BIT_MFMA_TFLOPS, f"{prods} x 16-bit MFMA product(s) per fp32 fma"
+        else:
+            ach, peak, unit_note = f32_equiv, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA"
+        roof = {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches, "dominant_stage": dom,
+                "arithmetic": unit_note, "fp32_equivalent_tflops": f32_equiv,
+                "fp32_equivalent_vs_fp32_mfma_peak": f32_equiv / PEAK_F32_MFMA_TFLOPS}
     elif dom is not None:
         bytes_img = 4 * D * N + 4 * S * K * D + S * N / 8 + S * S + S * Hm * Wm
         ms = sum(stages[s]["ms_per_step"] for s in ("incidence", "assign", "prep", "aggregate") if s in stages)

@@ -1,6 +1,7 @@
 // C-ABI of libsegvlad_hip.so (see include/segvlad.h).  Host-side orchestration only: argument
 // checks, host/device pointer staging, scratch sizing and kernel sequencing on the context stream.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <cmath>
 
@@ -120,7 +121,9 @@ int segvlad_destroy(segvlad_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->vocab,    &ctx->vocab_bt, &ctx->pca_mean, &ctx->pca_comps, &ctx->pca_scale, &ctx->db_rows,
                     &ctx->db_norms, &ctx->db_img,   &ctx->s_xt,     &ctx->s_labels,  &ctx->s_rnorm,   &ctx->s_gap,
                     &ctx->s_colmask, &ctx->s_gscale, &ctx->s_segimg, &ctx->s_segoff, &ctx->s_adjoff,  &ctx->s_dist,
-                    &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff};
+                    &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff, &ctx->s_cand_cnt, &ctx->s_cand_d2,
+                    &ctx->s_cand_id, &ctx->s_thr_d2, &ctx->s_thr_idx, &ctx->s_flag,   &ctx->s_qh,     &ctx->s_ql,
+                    &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -462,6 +465,9 @@ int segvlad_db_reset(segvlad_ctx* ctx) {
   ctx->db_n = 0;
   ctx->db_d = 0;
   ctx->db_has_img = false;
+  ctx->db_split_rows = 0;
+  ctx->db_rn_max = 0.f;
+  ctx->db_rn_max_rows = 0;
   return SEGVLAD_OK;
 }
 
@@ -571,7 +577,51 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_TRY(search_matrix(ctx, (const float*)dq, nq, n, d, k, qn, (float*)dd2, (int64_t*)didx));
     return sv_finish(ctx);
   }
+  const float* R = ctx->db_rows.as<float>();
+  const float* rn = ctx->db_norms.as<float>();
   const int chunk = 4096;
+  const bool bf16_path = (d % 32 == 0) && (getenv("SEGVLAD_KNN_FP32") == nullptr);
+  constexpr int RCAP = 512;
+  float rn_max = 0.f, c_eps = 0.f;
+  if (bf16_path) {
+    // lazily extend the bf16 planes and the max row norm to the rows added since the last search
+    if (ctx->db_split_rows < n) {
+      auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
+        if (new_bytes <= b.cap) return hipSuccess;
+        DevBuf nb;
+        hipError_t e = nb.reserve(new_bytes + new_bytes / 4);
+        if (e != hipSuccess) return e;
+        if (old_bytes) {
+          e = hipMemcpyAsync(nb.p, b.p, old_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+          if (e != hipSuccess) return e;
+        }
+        b.release();
+        b = nb;
+        return hipSuccess;
+      };
+      SV_HIP(grow(ctx->db_hi, (size_t)ctx->db_split_rows * d * 2, (size_t)n * d * 2));
+      SV_HIP(grow(ctx->db_lo, (size_t)ctx->db_split_rows * d * 2, (size_t)n * d * 2));
+      const int64_t r0 = ctx->db_split_rows;
+      SV_TRY(sv_launch_split_bf16(ctx, R + (size_t)r0 * d, (n - r0) * d, ctx->db_hi.as<uint16_t>() + (size_t)r0 * d,
+                                  ctx->db_lo.as<uint16_t>() + (size_t)r0 * d));
+      ctx->db_split_rows = n;
+    }
+    if (ctx->db_rn_max_rows < n) {
+      float m = 0.f;
+      SV_TRY(sv_row_norm_max(ctx, rn + ctx->db_rn_max_rows, n - ctx->db_rn_max_rows, &m));
+      if (m > ctx->db_rn_max) ctx->db_rn_max = m;
+      ctx->db_rn_max_rows = n;
+    }
+    rn_max = ctx->db_rn_max;
+    // |d2~ - d2| <= 2 * (3*2^-16 + 4*d*2^-24) * ||q|| * ||r||   (+25 % slack)
+    c_eps = 2.5f * (3.f / 65536.f + 4.f * (float)d / 16777216.f);
+    SV_HIP(ctx->s_qh.reserve((size_t)nq * d * 2));
+    SV_HIP(ctx->s_ql.reserve((size_t)nq * d * 2));
+    SV_TRY(sv_launch_split_bf16(ctx, (const float*)dq, (int64_t)nq * d, ctx->s_qh.as<uint16_t>(), ctx->s_ql.as<uint16_t>()));
+    SV_HIP(ctx->s_ref_cnt.reserve((size_t)chunk * 4));
+    SV_HIP(ctx->s_ref_id.reserve((size_t)chunk * RCAP * 4));
+  }
   SV_HIP(ctx->s_cand_cnt.reserve((size_t)chunk * 4));
   SV_HIP(ctx->s_cand_d2.reserve((size_t)chunk * CAP * 4));
   SV_HIP(ctx->s_cand_id.reserve((size_t)chunk * CAP * 4));
@@ -579,8 +629,6 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_HIP(ctx->s_thr_idx.reserve((size_t)chunk * k * 8));
   SV_HIP(ctx->s_flag.reserve(64));
   SV_HIP(hipMemsetAsync(ctx->s_flag.p, 0, 4, ctx->stream));
-  const float* R = ctx->db_rows.as<float>();
-  const float* rn = ctx->db_norms.as<float>();
   const int64_t n0 = (n + stride0 - 1) / stride0;
   const int64_t ld0 = (n0 + 3) & ~3ll;
   SV_HIP(ctx->s_dist.reserve((size_t)chunk * ld0 * 4));
@@ -588,7 +636,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     const int m = (nq - q0 < chunk) ? (nq - q0) : chunk;
     const float* qp = (const float*)dq + (size_t)q0 * d;
     float* thr = ctx->s_thr_d2.as<float>();
-    {  // level 0: exact top-k of the coarsest sample -> thr[q][k-1]
+    {  // level 0: exact (fp32) top-k of the coarsest sample -> thr[q][k-1]
       {
         StageScope sc(ctx, "knn_gemm");
         SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn + q0, rn, (int)stride0));
@@ -598,24 +646,56 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, k, thr, ctx->s_thr_idx.as<int64_t>(), k, 0));
       sc.count();
     }
+    const float* thr_ptr = thr + (k - 1);
+    int64_t thr_ld = k;
+    float eps_mult = 1.f;  // level-0 thresholds are exact distances: one margin covers the filter's error
     int64_t stride = stride0;
     for (int lv = 1; lv <= levels; ++lv) {
       stride /= RATIO;
       const int64_t ns = (n + stride - 1) / stride;
       const bool last = (lv == levels);
       SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
-      {
-        StageScope sc(ctx, "knn_gemm");
-        SV_TRY(sv_launch_l2_filter(ctx, qp, R, m, (int)ns, d, qn + q0, rn, (int)stride, thr + (k - 1), k,
-                                   ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
+      if (bf16_path) {
+        {
+          StageScope sc(ctx, "knn_gemm");
+          SV_TRY(sv_launch_bf16_filter(ctx, ctx->s_qh.as<uint16_t>() + (size_t)q0 * d, ctx->s_ql.as<uint16_t>() + (size_t)q0 * d,
+                                       ctx->db_hi.as<uint16_t>(), ctx->db_lo.as<uint16_t>(), m, (int)ns, d, (int)stride, qn + q0, rn,
+                                       thr_ptr, thr_ld, eps_mult, c_eps, rn_max, ctx->s_cand_cnt.as<uint32_t>(),
+                                       ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
+          sc.count();
+        }
+        StageScope sc(ctx, "knn_select");
+        SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
+                                       ctx->s_cand_id.as<uint32_t>(), m, CAP, k, last ? 1 : 0, qn + q0, c_eps, rn_max, thr,
+                                       ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), RCAP,
+                                       ctx->s_flag.as<uint32_t>()));
         sc.count();
+        if (last) {
+          SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn + q0, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(),
+                                        RCAP, k, (float*)dd2 + (size_t)q0 * k, (int64_t*)didx + (size_t)q0 * k));
+          sc.count();
+        }
+        // thresholds now hold approximate k-th distances A_k: the exact k-th is <= A_k + eps, and any true
+        // neighbour has d2~ <= A_k + 2 eps
+        thr_ptr = thr;
+        thr_ld = 1;
+        eps_mult = 2.f;
+      } else {
+        {
+          StageScope sc(ctx, "knn_gemm");
+          SV_TRY(sv_launch_l2_filter(ctx, qp, R, m, (int)ns, d, qn + q0, rn, (int)stride, thr_ptr, thr_ld,
+                                     ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
+          sc.count();
+        }
+        StageScope sc(ctx, "knn_select");
+        // the filter pass has consumed thr; the select may overwrite it with the tighter thresholds
+        SV_TRY(sv_launch_select_cand(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(),
+                                     m, CAP, k, last ? (float*)dd2 + (size_t)q0 * k : thr,
+                                     last ? (int64_t*)didx + (size_t)q0 * k : nullptr, ctx->s_flag.as<uint32_t>()));
+        sc.count();
+        thr_ptr = thr + (k - 1);
+        thr_ld = k;
       }
-      StageScope sc(ctx, "knn_select");
-      // the filter pass has consumed thr; the select may overwrite it with the tighter thresholds
-      SV_TRY(sv_launch_select_cand(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(),
-                                   m, CAP, k, last ? (float*)dd2 + (size_t)q0 * k : thr, last ? (int64_t*)didx + (size_t)q0 * k : nullptr,
-                                   ctx->s_flag.as<uint32_t>()));
-      sc.count();
     }
   }
   uint32_t flag = 0;

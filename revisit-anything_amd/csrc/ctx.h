@@ -26,6 +26,12 @@
     if (_r != SEGVLAD_OK) return _r; \
   } while (0)
 
+// squared L2 distance from the norms and the dot product; ONE definition so that every path (matrix GEMM,
+// filtered GEMM, exact refinement) rounds identically: fma(-2, dot, ||q||^2 + ||r||^2)
+#if defined(__HIPCC__)
+__device__ __forceinline__ float sv_d2(float q2, float r2, float dot) { return __fmaf_rn(-2.f, dot, q2 + r2); }
+#endif
+
 // grow-only device buffer
 struct DevBuf {
   void* p = nullptr;
@@ -83,10 +89,16 @@ struct segvlad_ctx {
   int64_t db_n = 0;
   DevBuf db_rows, db_norms, db_img;
   bool db_has_img = false;
+  // bf16 hi/lo planes of the rows (built lazily for the large-database search path) + max row norm^2
+  DevBuf db_hi, db_lo;
+  int64_t db_split_rows = 0;
+  float db_rn_max = 0.f;
+  int64_t db_rn_max_rows = 0;
 
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
-  DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag;
+  DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
+      s_qh, s_ql, s_ref_cnt, s_ref_id;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -151,6 +163,19 @@ int sv_launch_l2_strided(segvlad_ctx* ctx, const float* Q, const float* R, float
 int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M, int n_sample, int Kd, const float* qn,
                         const float* rn, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
                         float* cand_d2, uint32_t* cand_id, int cap);
+
+// knn_bf16_kernels.hip
+int sv_launch_split_bf16(segvlad_ctx* ctx, const float* X, int64_t n_elems, uint16_t* hi, uint16_t* lo);
+int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Ql, const uint16_t* Rh, const uint16_t* Rl,
+                          int M, int n_sample, int d, int b_stride, const float* qn, const float* rn, const float* thr,
+                          int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2,
+                          uint32_t* cand_id, int cap);
+int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
+                            int cap, int k, int mode, const float* qn, float c_eps, float rn_max, float* thr_out,
+                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* overflow);
+int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
+                           const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out);
+int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 
 // select_kernels.hip
 // top-k of per-query candidate lists (LDS sort on (distance, id)); lists longer than cap set *overflow

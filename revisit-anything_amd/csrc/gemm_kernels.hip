@@ -107,14 +107,18 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], float* lds, c
   const int wm = w >> 1, wn = w & 1;
   const int lrow = tid >> 3, lk = (tid & 7) << 2;
   const int ntiles = (Kd + BK - 1) / BK;
-  Stage st;
-  gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, 0, vec);
+  // two register stages (ping-pong): tile kt+1 is being written to LDS while tile kt+2 is still in flight
+  Stage s0, s1;
+  gload_tile<MODE, FAST>(s0, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, 0, vec);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) sstore_part(st, lds, lds + BK * LDT, lrow, lk, j);
-  if (ntiles > 1) gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, BK, vec);
+  for (int j = 0; j < 4; ++j) sstore_part(s0, lds, lds + BK * LDT, lrow, lk, j);
+  if (ntiles > 1) gload_tile<MODE, FAST>(s0, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, BK, vec);
+  if (ntiles > 2) gload_tile<MODE, FAST>(s1, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, 2 * BK, vec);
   __syncthreads();
   int cur = 0;
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // one k-tile: multiply out of buffer `cur`, spill `st` (tile kt+1) into the other buffer during the last
+  // four MFMA steps, barrier, then refill `st` with tile kt+3
+  auto ktile = [&](Stage& st, int kt) {
     const float* As = lds + cur * (2 * BK * LDT);
     const float* Bs = As + BK * LDT;
     float* Asn = lds + (cur ^ 1) * (2 * BK * LDT);
@@ -141,16 +145,22 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], float* lds, c
       // them behind the MFMAs to reuse the operand registers, exposing the LDS latency every step)
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);  // DS write (second half of the tile only)
+      __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);  // DS write (last four steps only)
       a0 = na0;
       a1 = na1;
       b0 = nb0;
       b1 = nb1;
     }
     __syncthreads();
-    if (kt + 2 < ntiles) gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, (kt + 2) * BK, vec);
+    if (kt + 3 < ntiles) gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, (kt + 3) * BK, vec);
     cur ^= 1;
+  };
+  int kt = 0;
+  for (; kt + 1 < ntiles; kt += 2) {
+    ktile(s0, kt);      // s0 holds tile kt+1
+    ktile(s1, kt + 1);  // s1 holds tile kt+2
   }
+  if (kt < ntiles) ktile(s0, kt);
 }
 
 template <int MODE>
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
           if (MODE == 0) {
             C[row * ldc + col] = acc[mt][nt][r] * cs;
           } else {
-            const float v = (row_add[row] + cs) - 2.f * acc[mt][nt][r];
+            const float v = sv_d2(row_add[row], cs, acc[mt][nt][r]);
             if (MODE == 1) {
               C[row * ldc + col] = v;
             } else if (v <= thr[row * thr_ld]) {

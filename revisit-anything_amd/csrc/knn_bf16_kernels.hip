@@ -1,0 +1,456 @@
+// Exact kNN, large-database path: bf16x3 MFMA filter + exact fp32 refinement (gfx950).
+//
+// fp32 MFMA runs at 1/16 of the bf16 rate on CDNA4.  Every fp32 value is split into two bf16 pieces
+// x = hi + lo + e, |e| <= 2^-16 |x|, and the filter GEMM accumulates hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_32x32x16_bf16 (products of two bf16 are exact in fp32).  The result differs from the fp32
+// fma-chain value of the exact path by at most
+//        |dot~ - dot| <= (3*2^-16 + 4*d*2^-24) * ||q|| * ||r||         (dropped terms + accumulation)
+// so a candidate filter with that margin can never drop a true neighbour.  The filter's survivors
+// (about k per query after the threshold levels) are then re-evaluated with the SAME sequential fp32
+// fma chain as the matrix path (gemm_nt_kernel<1>), sorted by (distance, id) and emitted: the final
+// distances and ids are bit-identical to the all-fp32 path.
+//
+//   split_bf16_kernel        fp32 [n][d] -> hi, lo bf16 planes
+//   knn_bf16_filter_kernel   128x128x32 tiles, 4 waves x (2x2) 32x32x16 MFMA tiles x 3 products;
+//                            16-B coalesced global loads -> registers -> XOR-swizzled LDS (conflict-free
+//                            ds_read_b128 fragments), double-buffered LDS, two register stages in flight;
+//                            epilogue appends (d2~, id) with d2~ <= thr + margin to the candidate lists
+//   select_approx_kernel     per query: sort candidates by d2~; intermediate level: A_k (k-th smallest);
+//                            last level: the refine list {d2~ <= A_k + 2 eps}
+//   refine_exact_kernel      per query: exact fp32 distances of the refine list, sort, top-k
+#include <stdlib.h>
+
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t f2key_(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f_(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// ---- fp32 -> (hi, lo) bf16, round-to-nearest-even ---------------------------------------------------
+__device__ __forceinline__ uint16_t bf16_rne(float x) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ X, int64_t n4, uint16_t* __restrict__ hi,
+                                                         uint16_t* __restrict__ lo) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(X)[j];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = bf16_rne(f[e]);
+      l[e] = bf16_rne(f[e] - bf16_to_f32(h[e]));
+    }
+    reinterpret_cast<uint2*>(hi)[j] = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    reinterpret_cast<uint2*>(lo)[j] = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  }
+}
+
+int sv_launch_split_bf16(segvlad_ctx* ctx, const float* X, int64_t n_elems, uint16_t* hi, uint16_t* lo) {
+  if (n_elems <= 0) return SEGVLAD_OK;
+  const int64_t n4 = n_elems / 4;  // callers guarantee d % 8 == 0
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n4, hi, lo);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ---- filter GEMM ---------------------------------------------------------------------------------------
+// Tile BM x BN x 32 (32 bf16 = 64 B = 4 chunks of 16 B per row and plane); WM x WN waves, each wave TM x TN
+// MFMA tiles of 32x32.  Instantiated as 128x128 with 2x2 waves (2 workgroups per CU); a 256x256 variant
+// measured the same time (the kernel is bound by HBM latency of the streamed DB operand, not by L2->LDS
+// bandwidth), so the prefetch depth, not the tile, is the lever.
+constexpr int FBK = 32;
+
+// physical chunk of logical chunk c in row r: spreads a 16-lane ds_read_b128 group over all 16 slots
+__device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// Register stages: two 16-B loads per thread and plane in both tile configurations; THREE named stage sets
+// rotate so that every k-tile's global loads are issued three k-tiles before they are written to LDS (the DB
+// operand streams from HBM with ~2 us latency while a k-tile of bf16 MFMAs lasts only ~0.4-0.7 us).
+// Named locals + macros: a struct or indexed array here is not promoted to registers by hipcc 7.2.
+#define F_DECL(X) uint4 gah0##X, gah1##X, gal0##X, gal1##X, gbh0##X, gbh1##X, gbl0##X, gbl1##X
+#define F_GLOAD(X, k0_)                                                          \
+  do {                                                                           \
+    const int64_t ko_ = (int64_t)(k0_) + 8 * (tid & 3);                          \
+    gah0##X = *reinterpret_cast<const uint4*>(Qh + qa0 * d + ko_);               \
+    gah1##X = *reinterpret_cast<const uint4*>(Qh + qa1 * d + ko_);               \
+    gal0##X = *reinterpret_cast<const uint4*>(Ql + qa0 * d + ko_);               \
+    gal1##X = *reinterpret_cast<const uint4*>(Ql + qa1 * d + ko_);               \
+    gbh0##X = *reinterpret_cast<const uint4*>(Rh + rb0 * ldb + ko_);             \
+    gbh1##X = *reinterpret_cast<const uint4*>(Rh + rb1 * ldb + ko_);             \
+    gbl0##X = *reinterpret_cast<const uint4*>(Rl + rb0 * ldb + ko_);             \
+    gbl1##X = *reinterpret_cast<const uint4*>(Rl + rb1 * ldb + ko_);             \
+  } while (0)
+
+#define F_SSTORE(X, S_)                                                          \
+  do {                                                                           \
+    unsigned char* s_ = (S_);                                                    \
+    *reinterpret_cast<uint4*>(s_ + so0) = gah0##X;                               \
+    *reinterpret_cast<uint4*>(s_ + so1) = gah1##X;                               \
+    *reinterpret_cast<uint4*>(s_ + PA + so0) = gal0##X;                          \
+    *reinterpret_cast<uint4*>(s_ + PA + so1) = gal1##X;                          \
+    *reinterpret_cast<uint4*>(s_ + 2 * PA + so0) = gbh0##X;                      \
+    *reinterpret_cast<uint4*>(s_ + 2 * PA + so1) = gbh1##X;                      \
+    *reinterpret_cast<uint4*>(s_ + 2 * PA + PB + so0) = gbl0##X;                 \
+    *reinterpret_cast<uint4*>(s_ + 2 * PA + PB + so1) = gbl1##X;                 \
+  } while (0)
+
+template <int BM, int BN, int WM, int WN, int DEPTH>
+__global__ __launch_bounds__(64 * WM * WN, 2) void knn_bf16_filter_kernel(
+    const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Ql, const uint16_t* __restrict__ Rh,
+    const uint16_t* __restrict__ Rl, int M, int N, int d, int b_stride, int tiles_m, const float* __restrict__ qn,
+    const float* __restrict__ rn, const float* __restrict__ thr, int64_t thr_ld, float eps_mult, float c_eps, float rn_max,
+    uint32_t* __restrict__ cand_cnt, float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap) {
+  constexpr int T = 64 * WM * WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);  // MFMA tiles per wave
+  constexpr int LA = BM * 4 / T, LB = BN * 4 / T;          // 16-B loads per thread, plane and k-tile
+  constexpr int PA = BM * 64, PB = BN * 64;                // plane bytes
+  constexpr int STAGE = 2 * PA + 2 * PB;                   // Ah, Al, Bh, Bl
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tile = blockIdx.x;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int wm = w / WN, wn = w % WN;
+  const int64_t ldb = (int64_t)d * b_stride;
+  const int ntiles = d / FBK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  static_assert(LA == 2 && LB == 2, "two 16-B loads per thread and plane");
+  F_DECL(A);
+  F_DECL(B);
+  F_DECL(C);
+  const int lr0 = tid >> 2, lr1 = lr0 + T / 4;
+  // clamp: rows beyond the edge are loaded from the last valid row and never emitted
+  const int64_t qa0 = (m0 + lr0 < M) ? (m0 + lr0) : (M - 1), qa1 = (m0 + lr1 < M) ? (m0 + lr1) : (M - 1);
+  const int64_t rb0 = (n0 + lr0 < N) ? (n0 + lr0) : (N - 1), rb1 = (n0 + lr1 < N) ? (n0 + lr1) : (N - 1);
+  const int so0 = lr0 * 64 + swz(lr0, tid & 3) * 16, so1 = lr1 * 64 + swz(lr1, tid & 3) * 16;
+  F_GLOAD(A, 0);
+  F_SSTORE(A, lds);
+  if (ntiles > 1) F_GLOAD(A, FBK);
+  if (DEPTH == 3) {
+    if (ntiles > 2) F_GLOAD(B, 2 * FBK);
+    if (ntiles > 3) F_GLOAD(C, 3 * FBK);
+  }
+  __syncthreads();
+  int cur = 0;
+  const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
+  // multiply k-tile `kt` out of LDS buffer `cur`
+  auto compute = [&]() {
+    const unsigned char* S = lds + cur * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cl = 2 * ks + kk;  // logical 16-B chunk (8 consecutive k) of this lane
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int ra = fa0 + 32 * t;
+        ah[t] = *reinterpret_cast<const bf16x8*>(S + ra * 64 + swz(ra, cl) * 16);
+        al[t] = *reinterpret_cast<const bf16x8*>(S + PA + ra * 64 + swz(ra, cl) * 16);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int rb = fb0 + 32 * t;
+        bh[t] = *reinterpret_cast<const bf16x8*>(S + 2 * PA + rb * 64 + swz(rb, cl) * 16);
+        bl[t] = *reinterpret_cast<const bf16x8*>(S + 2 * PA + PB + rb * 64 + swz(rb, cl) * 16);
+      }
+      // three products per accumulator, small terms first; the TM*TN accumulators are independent, so
+      // consecutive MFMAs never wait on each other
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_BF16(al[mt], bh[nt], acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bl[nt], acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bh[nt], acc[mt][nt]);
+    }
+  };
+  // iteration kt: compute tile kt; write stage X (tile kt+1, loaded three k-tiles ago) to the other buffer;
+  // barrier; refill X with tile kt+4
+#define F_STEP(X)                                                     \
+  do {                                                                \
+    compute();                                                        \
+    if (kt + 1 < ntiles) F_SSTORE(X, lds + (cur ^ 1) * STAGE);        \
+    __syncthreads();                                                  \
+    if (kt + 4 < ntiles) F_GLOAD(X, (kt + 4) * FBK);                  \
+    cur ^= 1;                                                         \
+    ++kt;                                                             \
+  } while (0)
+  int kt = 0;
+  if (DEPTH == 3) {
+    while (kt < ntiles) {
+      F_STEP(A);
+      if (kt >= ntiles) break;
+      F_STEP(B);
+      if (kt >= ntiles) break;
+      F_STEP(C);
+    }
+  } else {
+    for (; kt < ntiles; ++kt) {
+      compute();
+      if (kt + 1 < ntiles) F_SSTORE(A, lds + (cur ^ 1) * STAGE);
+      __syncthreads();
+      if (kt + 2 < ntiles) F_GLOAD(A, (kt + 2) * FBK);
+      cur ^= 1;
+    }
+  }
+#undef F_STEP
+
+  // ---- epilogue: d2~ = (||q||^2 + ||r||^2) - 2 dot~ ; keep d2~ <= thr + eps_mult * eps(q) -----------------
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    const int64_t col = n0 + wn * (32 * TN) + nt * 32 + i;
+    if (col >= N) continue;
+    const float cn = rn[col * b_stride];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row < M) {
+          const float q2 = qn[row];
+          const float v = sv_d2(q2, cn, acc[mt][nt][r]);
+          const float lim = thr[row * thr_ld] + eps_mult * c_eps * sqrtf(q2 * rn_max);
+          if (v <= lim) {
+            const uint32_t slot = atomicAdd(&cand_cnt[row], 1u);
+            if (slot < (uint32_t)cap) {
+              cand_d2[row * cap + slot] = v;
+              cand_id[row * cap + slot] = (uint32_t)(col * b_stride);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int DEPTH>
+static int launch_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Ql, const uint16_t* Rh, const uint16_t* Rl,
+                         int M, int n_sample, int d, int b_stride, const float* qn, const float* rn, const float* thr,
+                         int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2,
+                         uint32_t* cand_id, int cap) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (n_sample + BN - 1) / BN;
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "bf16 filter: too many tiles");
+  const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
+  auto kern = knn_bf16_filter_kernel<BM, BN, WM, WN, DEPTH>;
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Ql, Rh, Rl, M, n_sample, d, b_stride,
+                     tiles_m, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Ql, const uint16_t* Rh, const uint16_t* Rl,
+                          int M, int n_sample, int d, int b_stride, const float* qn, const float* rn, const float* thr,
+                          int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2,
+                          uint32_t* cand_id, int cap) {
+  if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
+  const char* dep = getenv("SEGVLAD_FILTER_DEPTH");
+  if (dep && atoi(dep) == 3)
+    return launch_filter<128, 128, 2, 2, 3>(ctx, Qh, Ql, Rh, Rl, M, n_sample, d, b_stride, qn, rn, thr, thr_ld, eps_mult, c_eps,
+                                            rn_max, cand_cnt, cand_d2, cand_id, cap);
+  return launch_filter<128, 128, 2, 2, 1>(ctx, Qh, Ql, Rh, Rl, M, n_sample, d, b_stride, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max,
+                                          cand_cnt, cand_d2, cand_id, cap);
+}
+
+// ---- candidate handling ----------------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic64(uint64_t* a, int n, int tid) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (n >> 1); t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const uint64_t x = a[lo], y = a[hi];
+        if ((y < x) == up) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// mode 0: thr_out[q] = A_k (k-th smallest approximate distance; +inf if fewer than k candidates)
+// mode 1: refine list = ids with d2~ <= A_k + 2 eps(q), at most rcap (more -> *overflow)
+__global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+                                                            const uint32_t* __restrict__ cid, int cap, int k, int mode,
+                                                            const float* __restrict__ qn, float c_eps, float rn_max,
+                                                            float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
+                                                            uint32_t* __restrict__ ref_id, int rcap,
+                                                            uint32_t* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const uint32_t c = cnt[row];
+  if (c > (uint32_t)cap) {
+    if (tid == 0) {
+      atomicOr(overflow, 1u);
+      if (mode == 1) ref_cnt[row] = 0;
+    }
+    return;
+  }
+  int npad = 2;
+  while (npad < (int)c) npad <<= 1;
+  for (int j = tid; j < npad; j += 256)
+    a[j] = (j < (int)c) ? (((uint64_t)f2key_(cd2[row * cap + j]) << 32) | cid[row * cap + j]) : ~0ull;
+  bitonic64(a, npad, tid);
+  const float ak = ((int)c >= k) ? key2f_((uint32_t)(a[k - 1] >> 32)) : INFINITY;
+  if (mode == 0) {
+    if (tid == 0) thr_out[row] = ak;
+    return;
+  }
+  const float lim = ak + 2.f * c_eps * sqrtf(qn[row] * rn_max);
+  const uint32_t klim = f2key_(lim);
+  // sorted ascending: count entries with key <= klim (parallel count; entries are contiguous from 0)
+  __shared__ uint32_t s_n;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  uint32_t local = 0;
+  for (int j = tid; j < (int)c; j += 256) local += ((uint32_t)(a[j] >> 32) <= klim) ? 1u : 0u;
+  atomicAdd(&s_n, local);
+  __syncthreads();
+  const uint32_t n = s_n;
+  if (n > (uint32_t)rcap) {
+    if (tid == 0) {
+      atomicOr(overflow, 1u);
+      ref_cnt[row] = 0;
+    }
+    return;
+  }
+  for (int j = tid; j < (int)n; j += 256) ref_id[row * rcap + j] = (uint32_t)a[j];
+  if (tid == 0) ref_cnt[row] = n;
+}
+
+int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
+                            int cap, int k, int mode, const float* qn, float c_eps, float rn_max, float* thr_out,
+                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* overflow) {
+  if (nq <= 0) return SEGVLAD_OK;
+  const size_t lds = (size_t)cap * 8;
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_approx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, k, mode, qn,
+                     c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, overflow);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// exact distances of the refine list: the sequential fp32 fma chain over k = 0..d-1 (bit-identical to the
+// v_mfma_f32_32x32x2_f32 chain of the matrix path), then (distance, id) sort and top-k
+__global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
+                                                           const float* __restrict__ qn, const float* __restrict__ rn,
+                                                           const uint32_t* __restrict__ ref_cnt,
+                                                           const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
+                                                           float* __restrict__ d2_out, int64_t* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);                          // [d]
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem + (size_t)d * 4);     // [rpad]
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const int n = (int)ref_cnt[row];
+  for (int j = tid; j < d; j += 256) qs[j] = Q[row * d + j];
+  for (int j = tid; j < rpad; j += 256) a[j] = ~0ull;
+  __syncthreads();
+  const float q2 = qn[row];
+  for (int j = tid; j < n; j += 256) {
+    const uint32_t id = ref_id[row * rcap + j];
+    const float4* rp = reinterpret_cast<const float4*>(R + (size_t)id * d);
+    float acc = 0.f;
+    for (int t = 0; t < (d >> 2); ++t) {
+      const float4 rv = rp[t];
+      const float4 qv = reinterpret_cast<const float4*>(qs)[t];
+      acc = fmaf(qv.x, rv.x, acc);
+      acc = fmaf(qv.y, rv.y, acc);
+      acc = fmaf(qv.z, rv.z, acc);
+      acc = fmaf(qv.w, rv.w, acc);
+    }
+    const float v = sv_d2(q2, rn[id], acc);
+    a[j] = ((uint64_t)f2key_(v) << 32) | id;
+  }
+  bitonic64(a, rpad, tid);
+  for (int j = tid; j < k; j += 256) {
+    float dd = INFINITY;
+    int64_t id = -1;
+    if (j < n) {
+      dd = key2f_((uint32_t)(a[j] >> 32));
+      id = (int64_t)(uint32_t)a[j];
+    }
+    d2_out[row * k + j] = dd;
+    idx_out[row * k + j] = id;
+  }
+}
+
+int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
+                           const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out) {
+  if (nq <= 0) return SEGVLAD_OK;
+  int rpad = 2;
+  while (rpad < rcap) rpad <<= 1;
+  const size_t lds = (size_t)d * 4 + (size_t)rpad * 8;
+  if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "refine: d=%d too large for the LDS query cache", d);
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(refine_exact_kernel, dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap, rpad, k,
+                     d2_out, idx_out);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// ---- max of the database row norms (margin scale) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) m = max(m, f2key_(x[j]));
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host) {
+  SV_HIP(ctx->s_minmax.reserve(16));
+  uint32_t* mm = ctx->s_minmax.as<uint32_t>() + 2;
+  SV_HIP(hipMemsetAsync(mm, 0, 4, ctx->stream));
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (n > 0) hipLaunchKernelGGL(max_kernel, dim3(blocks), dim3(256), 0, ctx->stream, norms, n, mm);
+  uint32_t key = 0;
+  SV_HIP(hipMemcpyAsync(&key, mm, 4, hipMemcpyDeviceToHost, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  const uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+  float f;
+  memcpy(&f, &u, 4);
+  *out_host = (n > 0 && key != 0) ? f : 0.f;
+  return SEGVLAD_OK;
+}

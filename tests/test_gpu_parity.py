@@ -356,9 +356,10 @@ def test_e2e_small_golden(eng):
 # ------------------------------------------------------------------------------------------------
 # large-database search path: sampled thresholds + filtered GEMM epilogue (exactness must not depend on it)
 # ------------------------------------------------------------------------------------------------
-def test_knn_leveled_filter_path_is_exact(eng):
+@pytest.mark.parametrize("d", [48, 64])   # 48: fp32 filter levels; 64 (d % 32 == 0): bf16x3 filter + exact refinement
+def test_knn_leveled_filter_path_is_exact(eng, d):
     rng = np.random.Generator(np.random.PCG64(200))
-    n, d, nq, k = 70001, 48, 300, 50          # > 32768 rows: one filter level (stride 16)
+    n, nq, k = 70001, 300, 50                 # > 32768 rows: one filter level (stride 16)
     R = rng.standard_normal((n, d)).astype(np.float32)
     Q = rng.standard_normal((nq, d)).astype(np.float32)
     R[5000] = R[123]                            # exact duplicates: ties must resolve to the lower id
@@ -387,11 +388,12 @@ def test_knn_leveled_filter_path_is_exact(eng):
     assert np.array_equal(im, idx) and np.array_equal(dm, d2)
 
 
-def test_knn_filter_overflow_falls_back_to_exact(eng):
+@pytest.mark.parametrize("d", [16, 32])
+def test_knn_filter_overflow_falls_back_to_exact(eng, d):
     """Adversarial layout: every sampled row (id % 16 == 0) is far away, all other rows are near -> the sampled
     threshold admits everything, the candidate lists overflow, and the search must still be exact."""
     rng = np.random.Generator(np.random.PCG64(201))
-    n, d, nq, k = 40000, 16, 20, 10
+    n, nq, k = 40000, 20, 10
     R = (rng.standard_normal((n, d)) * 0.01).astype(np.float32)
     R[::16] += 100.0
     Q = (rng.standard_normal((nq, d)) * 0.01).astype(np.float32)
@@ -455,3 +457,30 @@ def test_pipeline_device_adjacency_equals_host_qhull(eng):
     d_dev = SegVLADPipeline(eng, H, W, order=3, use_pca=False, host_adjacency=False).describe(toks, masks, offs).cpu().numpy()
     d_host = SegVLADPipeline(eng, H, W, order=3, use_pca=False, host_adjacency=True).describe(toks, masks, offs).cpu().numpy()
     assert np.array_equal(d_dev, d_host)
+
+
+def test_knn_bf16_path_two_levels_unit_vectors(eng):
+    """> 524288 rows: two filter levels (strides 256, 16, 1); unit-norm 128-d rows like the PCA'd descriptors.
+    The bf16x3 filter + fp32 refinement must reproduce the plain fp32 matrix path bit for bit."""
+    import torch
+
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(7)
+    n, d, nq, k = 600000, 128, 64, 200
+    R = torch.nn.functional.normalize(torch.randn(n, d, device=eng.device, generator=g), dim=1)
+    Q = torch.nn.functional.normalize(R[torch.randint(0, n, (nq,), device=eng.device, generator=g)] +
+                                      0.3 * torch.randn(nq, d, device=eng.device, generator=g) / d ** 0.5, dim=1)
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = eng.search(Q, k)
+    os.environ["SEGVLAD_KNN_FP32"] = "1"       # same levels, fp32 filter GEMM instead of bf16x3
+    try:
+        d2f, idxf = eng.search(Q, k)
+    finally:
+        del os.environ["SEGVLAD_KNN_FP32"]
+    assert torch.equal(idx, idxf) and torch.equal(d2, d2f)
+    # and against the oracle on a slice of the queries
+    Rh = R.cpu().numpy()
+    rd2, ridx = O().knn_l2(Rh, Q[:8].cpu().numpy(), k)
+    assert np.abs(d2[:8].cpu().numpy() - rd2).max() < 1e-5
+    assert (idx[:8].cpu().numpy() == ridx).mean() > 0.98
