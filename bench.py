@@ -270,8 +270,10 @@ def main():
         key = "pca" if dom == "pca" else "knn_gemm"
         if key == "knn_gemm":
             flops_step = 2.0 * nQ * S * n_local_rows * d_knn          # 2 * B_q * N_r * d (algorithmic)
-            kern = ("knn_bf16_filter_kernel (Q.R^T as 3 bf16 MFMA products hi.hi+hi.lo+lo.hi, fused d2 + threshold-filter epilogue; "
-                    "exact fp32 refinement of the survivors)")
+            kern = ("knn_f16_filter_kernel (Q.R^T as one fp16 MFMA product per fp32 fma, global->LDS DMA, fused d2 + "
+                    "threshold-filter epilogue; exact fp32 refinement of the survivors)" if eng_filter_products() == 1 else
+                    "knn_bf16_filter_kernel (Q.R^T as 3 bf16 MFMA products hi.hi+hi.lo+lo.hi, fused d2 + threshold-filter "
+                    "epilogue; exact fp32 refinement of the survivors)")
         else:
             flops_step = 2.0 * nq_local * S * (K * D) * P              # 2 * S * K*D * P per image
             kern = "gemm_nt_kernel<0> (PCA projection, fused mean-subtract + whitening scale)"

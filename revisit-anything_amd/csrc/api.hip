@@ -2,6 +2,7 @@
 // checks, host/device pointer staging, scratch sizing and kernel sequencing on the context stream.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <cmath>
 
@@ -123,7 +124,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_colmask, &ctx->s_gscale, &ctx->s_segimg, &ctx->s_segoff, &ctx->s_adjoff,  &ctx->s_dist,
                     &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff, &ctx->s_cand_cnt, &ctx->s_cand_d2,
                     &ctx->s_cand_id, &ctx->s_thr_d2, &ctx->s_thr_idx, &ctx->s_flag,   &ctx->s_qh,     &ctx->s_ql,
-                    &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo};
+                    &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo,    &ctx->db_f16,   &ctx->s_qf16};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -466,6 +467,9 @@ int segvlad_db_reset(segvlad_ctx* ctx) {
   ctx->db_d = 0;
   ctx->db_has_img = false;
   ctx->db_split_rows = 0;
+  ctx->db_f16_rows = 0;
+  ctx->db_f16_scale = 0.f;
+  ctx->db_maxabs = 0.f;
   ctx->db_rn_max = 0.f;
   ctx->db_rn_max_rows = 0;
   return SEGVLAD_OK;
@@ -580,33 +584,29 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   const float* R = ctx->db_rows.as<float>();
   const float* rn = ctx->db_norms.as<float>();
   const int chunk = 4096;
-  const bool bf16_path = (d % 32 == 0) && (getenv("SEGVLAD_KNN_FP32") == nullptr);
+  // filter arithmetic: "f16" (one fp16 product, d % 64 == 0), "bf16x3" (three bf16 products, d % 32 == 0), or
+  // plain fp32 (SEGVLAD_KNN_FP32=1 or unsupported d)
+  const char* fsel = getenv("SEGVLAD_KNN_FILTER");
+  const bool no16 = getenv("SEGVLAD_KNN_FP32") != nullptr;
+  const bool f16_path = !no16 && (d % 64 == 0) && !(fsel && strcmp(fsel, "bf16x3") == 0);
+  const bool bf16_path = !no16 && !f16_path && (d % 32 == 0);
   constexpr int RCAP = 512;
-  float rn_max = 0.f, c_eps = 0.f;
-  if (bf16_path) {
-    // lazily extend the bf16 planes and the max row norm to the rows added since the last search
-    if (ctx->db_split_rows < n) {
-      auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
-        if (new_bytes <= b.cap) return hipSuccess;
-        DevBuf nb;
-        hipError_t e = nb.reserve(new_bytes + new_bytes / 4);
-        if (e != hipSuccess) return e;
-        if (old_bytes) {
-          e = hipMemcpyAsync(nb.p, b.p, old_bytes, hipMemcpyDeviceToDevice, ctx->stream);
-          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-          if (e != hipSuccess) return e;
-        }
-        b.release();
-        b = nb;
-        return hipSuccess;
-      };
-      SV_HIP(grow(ctx->db_hi, (size_t)ctx->db_split_rows * d * 2, (size_t)n * d * 2));
-      SV_HIP(grow(ctx->db_lo, (size_t)ctx->db_split_rows * d * 2, (size_t)n * d * 2));
-      const int64_t r0 = ctx->db_split_rows;
-      SV_TRY(sv_launch_split_bf16(ctx, R + (size_t)r0 * d, (n - r0) * d, ctx->db_hi.as<uint16_t>() + (size_t)r0 * d,
-                                  ctx->db_lo.as<uint16_t>() + (size_t)r0 * d));
-      ctx->db_split_rows = n;
+  float rn_max = 0.f, c_eps = 0.f, inv_scale = 1.f;
+  auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
+    if (new_bytes <= b.cap) return hipSuccess;
+    DevBuf nb;
+    hipError_t e = nb.reserve(new_bytes + new_bytes / 4);
+    if (e != hipSuccess) return e;
+    if (old_bytes) {
+      e = hipMemcpyAsync(nb.p, b.p, old_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) return e;
     }
+    b.release();
+    b = nb;
+    return hipSuccess;
+  };
+  if (f16_path || bf16_path) {
     if (ctx->db_rn_max_rows < n) {
       float m = 0.f;
       SV_TRY(sv_row_norm_max(ctx, rn + ctx->db_rn_max_rows, n - ctx->db_rn_max_rows, &m));
@@ -614,13 +614,54 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       ctx->db_rn_max_rows = n;
     }
     rn_max = ctx->db_rn_max;
+    SV_HIP(ctx->s_ref_cnt.reserve((size_t)chunk * 4));
+    SV_HIP(ctx->s_ref_id.reserve((size_t)chunk * RCAP * 4));
+  }
+  if (f16_path) {
+    // power-of-two scales that put the largest magnitude in [8192, 16384): no overflow, negligible underflow
+    auto pow2_scale = [](float maxabs) -> float {
+      if (!(maxabs > 0.f) || !std::isfinite(maxabs)) return 1.f;
+      int e;
+      frexpf(maxabs, &e);  // maxabs = m * 2^e, m in [0.5, 1)
+      return ldexpf(1.f, 14 - e);
+    };
+    if (ctx->db_f16_rows < n) {
+      float m_new = 0.f;
+      SV_TRY(sv_maxabs(ctx, R + (size_t)ctx->db_f16_rows * d, (n - ctx->db_f16_rows) * d, &m_new));
+      const bool rescale = ctx->db_f16_rows == 0 || m_new * ctx->db_f16_scale >= 32768.f;
+      if (m_new > ctx->db_maxabs) ctx->db_maxabs = m_new;
+      int64_t r0 = ctx->db_f16_rows;
+      if (rescale) {
+        ctx->db_f16_scale = pow2_scale(ctx->db_maxabs);
+        r0 = 0;
+      }
+      SV_HIP(grow(ctx->db_f16, (size_t)r0 * d * 2, (size_t)n * d * 2));
+      SV_TRY(sv_launch_to_f16(ctx, R + (size_t)r0 * d, (n - r0) * d, ctx->db_f16_scale, ctx->db_f16.as<uint16_t>() + (size_t)r0 * d));
+      ctx->db_f16_rows = n;
+    }
+    float qmax = 0.f;
+    SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
+    const float qscale = pow2_scale(qmax);
+    SV_HIP(ctx->s_qf16.reserve((size_t)nq * d * 2));
+    SV_TRY(sv_launch_to_f16(ctx, (const float*)dq, (int64_t)nq * d, qscale, ctx->s_qf16.as<uint16_t>()));
+    inv_scale = 1.f / (qscale * ctx->db_f16_scale);
+    // |d2~ - d2| <= 2 * (2^-10 + 2^-22 + 2*d*2^-24) * ||q|| * ||r||   (+25 % slack)
+    c_eps = 2.5f * (1.f / 1024.f + 1.f / 4194304.f + 2.f * (float)d / 16777216.f);
+  } else if (bf16_path) {
+    // lazily extend the bf16 planes to the rows added since the last search
+    if (ctx->db_split_rows < n) {
+      SV_HIP(grow(ctx->db_hi, (size_t)ctx->db_split_rows * d * 2, (size_t)n * d * 2));
+      SV_HIP(grow(ctx->db_lo, (size_t)ctx->db_split_rows * d * 2, (size_t)n * d * 2));
+      const int64_t r0 = ctx->db_split_rows;
+      SV_TRY(sv_launch_split_bf16(ctx, R + (size_t)r0 * d, (n - r0) * d, ctx->db_hi.as<uint16_t>() + (size_t)r0 * d,
+                                  ctx->db_lo.as<uint16_t>() + (size_t)r0 * d));
+      ctx->db_split_rows = n;
+    }
     // |d2~ - d2| <= 2 * (3*2^-16 + 4*d*2^-24) * ||q|| * ||r||   (+25 % slack)
     c_eps = 2.5f * (3.f / 65536.f + 4.f * (float)d / 16777216.f);
     SV_HIP(ctx->s_qh.reserve((size_t)nq * d * 2));
     SV_HIP(ctx->s_ql.reserve((size_t)nq * d * 2));
     SV_TRY(sv_launch_split_bf16(ctx, (const float*)dq, (int64_t)nq * d, ctx->s_qh.as<uint16_t>(), ctx->s_ql.as<uint16_t>()));
-    SV_HIP(ctx->s_ref_cnt.reserve((size_t)chunk * 4));
-    SV_HIP(ctx->s_ref_id.reserve((size_t)chunk * RCAP * 4));
   }
   SV_HIP(ctx->s_cand_cnt.reserve((size_t)chunk * 4));
   SV_HIP(ctx->s_cand_d2.reserve((size_t)chunk * CAP * 4));
@@ -655,9 +696,14 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       const int64_t ns = (n + stride - 1) / stride;
       const bool last = (lv == levels);
       SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
-      if (bf16_path) {
+      if (f16_path || bf16_path) {
         {
           StageScope sc(ctx, "knn_gemm");
+          if (f16_path)
+            SV_TRY(sv_launch_f16_filter(ctx, ctx->s_qf16.as<uint16_t>() + (size_t)q0 * d, ctx->db_f16.as<uint16_t>(), m, (int)ns, d,
+                                        (int)stride, inv_scale, qn + q0, rn, thr_ptr, thr_ld, eps_mult, c_eps, rn_max,
+                                        ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
+          else
           SV_TRY(sv_launch_bf16_filter(ctx, ctx->s_qh.as<uint16_t>() + (size_t)q0 * d, ctx->s_ql.as<uint16_t>() + (size_t)q0 * d,
                                        ctx->db_hi.as<uint16_t>(), ctx->db_lo.as<uint16_t>(), m, (int)ns, d, (int)stride, qn + q0, rn,
                                        thr_ptr, thr_ld, eps_mult, c_eps, rn_max, ctx->s_cand_cnt.as<uint32_t>(),

@@ -92,13 +92,17 @@ struct segvlad_ctx {
   // bf16 hi/lo planes of the rows (built lazily for the large-database search path) + max row norm^2
   DevBuf db_hi, db_lo;
   int64_t db_split_rows = 0;
+  // fp16 image of the rows, scaled by a power of two (single-product filter)
+  DevBuf db_f16;
+  int64_t db_f16_rows = 0;
+  float db_f16_scale = 0.f, db_maxabs = 0.f;
   float db_rn_max = 0.f;
   int64_t db_rn_max_rows = 0;
 
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id;
+      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -176,6 +180,11 @@ int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const fl
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
+int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);
+int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out);
+int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
+                         float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,
+                         float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap);
 
 // select_kernels.hip
 // top-k of per-query candidate lists (LDS sort on (distance, id)); lists longer than cap set *overflow

@@ -283,6 +283,258 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
                                           cand_cnt, cand_d2, cand_id, cap);
 }
 
+// ---- fp16 single-product filter ----------------------------------------------------------------------------
+// One fp16 MFMA product per fp32 fma: x~ = fl16(s * x) with a power-of-two scale s (exact), products of two
+// fp16 are exact in fp32, so   |dot~ - dot| <= (2^-10 + 2^-22 + 2 d 2^-24) ||q|| ||r||   against the fp32 chain.
+// The margin is ~24x wider than bf16x3's, which lets ~1.3-1.4x more candidates through (they are cheap: the
+// exact refinement only sees the ~k survivors) for one third of the MFMA work.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256)
+    m = max(m, __float_as_uint(x[j]) & 0x7fffffffu);  // |x| bit pattern orders like the value
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host) {
+  SV_HIP(ctx->s_minmax.reserve(32));
+  uint32_t* mm = ctx->s_minmax.as<uint32_t>() + 4;
+  SV_HIP(hipMemsetAsync(mm, 0, 4, ctx->stream));
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (n > 0) hipLaunchKernelGGL(maxabs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, n, mm);
+  uint32_t u = 0;
+  SV_HIP(hipMemcpyAsync(&u, mm, 4, hipMemcpyDeviceToHost, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  float f;
+  memcpy(&f, &u, 4);
+  *out_host = f;
+  return SEGVLAD_OK;
+}
+
+__global__ __launch_bounds__(256) void to_f16_kernel(const float* __restrict__ X, int64_t n4, float scale,
+                                                     _Float16* __restrict__ out) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(X)[j];
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h;
+    h[0] = (_Float16)(v.x * scale);  // round-to-nearest-even conversion
+    h[1] = (_Float16)(v.y * scale);
+    h[2] = (_Float16)(v.z * scale);
+    h[3] = (_Float16)(v.w * scale);
+    reinterpret_cast<h4*>(out)[j] = h;
+  }
+}
+
+int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out) {
+  if (n_elems <= 0) return SEGVLAD_OK;
+  const int64_t n4 = n_elems / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n4, scale,
+                     reinterpret_cast<_Float16*>(out));
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// 128-B rows (64 fp16 = 8 chunks of 16 B): physical chunk of logical chunk c in row r
+__device__ __forceinline__ int swz8(int r, int c) { return c ^ ((r >> 1) & 7); }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Operand tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write): one
+// wave-instruction fills 1 KiB = 8 rows x 128 B of the LDS image, lane l landing at base + 16 l.  The LDS
+// image must therefore be lane-linear, so the bank-conflict swizzle is applied on the SOURCE side: lane
+// (row_in_block = l >> 3, physical chunk = l & 7) fetches logical chunk (l & 7) ^ ((row >> 1) & 7) of its row,
+// and the MFMA fragment reads apply the same involution.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
+    const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m,
+    float inv_scale, const float* __restrict__ qn, const float* __restrict__ rn, const float* __restrict__ thr,
+    int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* __restrict__ cand_cnt,
+    float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int HBK = 64;
+  constexpr int PA = BM * 128, PB = BN * 128;
+  constexpr int JA = BM / 8 / NW, JB = BN / 8 / NW;  // 1-KiB DMA blocks per wave and operand
+  static_assert(JA * 8 * NW == BM && JB * 8 * NW == BN, "tile rows must split into 8-row blocks per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tile = blockIdx.x;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS DMA bases live in M0
+  const int wm = w / WN, wn = w % WN;
+  const int64_t ldb = (int64_t)d * b_stride;
+  const int ntiles = d / HBK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // per-lane source rows of this wave's DMA blocks (clamped: edge rows are never emitted)
+  const int lrow = l >> 3, lch = l & 7;
+  const uint16_t* srcA[JA];
+  const uint16_t* srcB[JB];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int row = (w * JA + j) * 8 + lrow;
+    const int64_t qa = (m0 + row < M) ? (m0 + row) : (int64_t)(M - 1);
+    srcA[j] = Qh + qa * d + 8 * (lch ^ ((row >> 1) & 7));
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int row = (w * JB + j) * 8 + lrow;
+    const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
+    srcB[j] = Rh + rb * ldb + 8 * (lch ^ ((row >> 1) & 7));
+  }
+  // LDS: two A stages (queries: L2-resident, one k-tile of prefetch suffices) and THREE B stages: the database
+  // rows stream from HBM with ~2.5 us latency, so their DMA runs two k-tiles ahead.  Because vmcnt retires in
+  // order, "everything but the youngest JB DMA instructions has landed" is exactly "A(kt+1) and B(kt+1) are in".
+  unsigned char* const Abase = lds;
+  unsigned char* const Bbase = lds + 2 * PA;
+  auto dmaA = [&](int kt, int ia) {
+    unsigned char* S = Abase + ia * PA;
+    const int k0 = kt * HBK;
+#pragma unroll
+    for (int j = 0; j < JA; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0), (lptr_t)(S + (w * JA + j) * 1024), 16, 0, 0);
+  };
+  auto dmaB = [&](int kt, int ib) {
+    unsigned char* S = Bbase + ib * PB;
+    const int k0 = kt * HBK;
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + k0), (lptr_t)(S + (w * JB + j) * 1024), 16, 0, 0);
+  };
+  static_assert(JB == 4, "the counted wait below leaves exactly JB = 4 DMA instructions in flight");
+
+  dmaA(0, 0);
+  dmaB(0, 0);
+  if (ntiles > 1) {
+    dmaB(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  int ia = 0, ib = 0;
+  const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (kt + 1 < ntiles) dmaA(kt + 1, ia ^ 1);
+    const int ib2 = (ib + 2 >= 3) ? ib - 1 : ib + 2;
+    if (kt + 2 < ntiles) dmaB(kt + 2, ib2);
+    const unsigned char* SA = Abase + ia * PA;
+    const unsigned char* SB = Bbase + ib * PB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cl = 2 * ks + kk;  // logical 16-B chunk (8 consecutive k) of this lane
+      f16x8 a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int ra = fa0 + 32 * t;
+        a[t] = *reinterpret_cast<const f16x8*>(SA + ra * 128 + swz8(ra, cl) * 16);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int rb = fb0 + 32 * t;
+        b[t] = *reinterpret_cast<const f16x8*>(SB + rb * 128 + swz8(rb, cl) * 16);
+      }
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a[mt], b[nt], acc[mt][nt]);
+    }
+    // this wave's pieces of A(kt+1) and B(kt+1) have landed (B(kt+2) may still fly) and its LDS reads are done;
+    // after the barrier that holds for every wave, so the stages of tile kt may be overwritten
+    if (kt + 2 < ntiles)
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ia ^= 1;
+    ib = (ib + 1 >= 3) ? 0 : ib + 1;
+  }
+
+  // ---- epilogue: keep d2~ <= thr + eps_mult * eps(q).  The test runs on the raw accumulator against a per-row
+  // bound (one fma + compare per element); survivors are re-tested with the exact expression. -----------------
+  float cn[TN];
+  int64_t col[TN];
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    col[nt] = n0 + wn * (32 * TN) + nt * 32 + i;
+    cn[nt] = (col[nt] < N) ? rn[col[nt] * b_stride] : 0.f;
+  }
+  const float half_scale = 0.5f / inv_scale;
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = m0 + wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (row >= M) continue;
+      const float q2 = qn[row];
+      const float lim = thr[row * thr_ld] + eps_mult * c_eps * sqrtf(q2 * rn_max);
+      // v <= lim  <=>  acc >= (q2 + cn - lim) / 2 / inv_scale; widened by a relative 2^-18 so that rounding
+      // of this shortcut can only ADD candidates
+      const float base = (q2 - lim) * half_scale;
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const float tau = fmaf(cn[nt], half_scale, base);
+        if (acc[mt][nt][r] >= tau - fabsf(tau) * 3.8e-6f && col[nt] < N) {
+          const float v = sv_d2(q2, cn[nt], acc[mt][nt][r] * inv_scale);
+          if (v <= lim) {
+            const uint32_t slot = atomicAdd(&cand_cnt[row], 1u);
+            if (slot < (uint32_t)cap) {
+              cand_d2[row * cap + slot] = v;
+              cand_id[row * cap + slot] = (uint32_t)(col[nt] * b_stride);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
+                             float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
+                             float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
+                             int cap) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (n_sample + BN - 1) / BN;
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
+  const size_t lds = 2 * (size_t)BM * 128 + 3 * (size_t)BN * 128;  // two A stages + three B stages
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN>;
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
+                     inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
+                         float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,
+                         float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap) {
+  if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
+  const char* force = getenv("SEGVLAD_FILTER_TILE");
+  const bool big = force ? (atoi(force) == 256) : (M > 128);
+  if (big)
+    return launch_f16_filter<256, 256, 4, 2>(ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps,
+                                             rn_max, cand_cnt, cand_d2, cand_id, cap);
+  return launch_f16_filter<128, 128, 2, 2>(ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps,
+                                           rn_max, cand_cnt, cand_d2, cand_id, cap);
+}
+
 // ---- candidate handling ----------------------------------------------------------------------------------
 __device__ __forceinline__ void bitonic64(uint64_t* a, int n, int tid) {
   for (int size = 2; size <= n; size <<= 1) {

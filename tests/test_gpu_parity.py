@@ -356,7 +356,7 @@ def test_e2e_small_golden(eng):
 # ------------------------------------------------------------------------------------------------
 # large-database search path: sampled thresholds + filtered GEMM epilogue (exactness must not depend on it)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d", [48, 64])   # 48: fp32 filter levels; 64 (d % 32 == 0): bf16x3 filter + exact refinement
+@pytest.mark.parametrize("d", [48, 96, 64])   # 48: fp32 filter levels; 96: bf16x3 filter; 64: fp16 filter (+ exact refinement)
 def test_knn_leveled_filter_path_is_exact(eng, d):
     rng = np.random.Generator(np.random.PCG64(200))
     n, nq, k = 70001, 300, 50                 # > 32768 rows: one filter level (stride 16)
@@ -461,7 +461,7 @@ def test_pipeline_device_adjacency_equals_host_qhull(eng):
 
 def test_knn_bf16_path_two_levels_unit_vectors(eng):
     """> 524288 rows: two filter levels (strides 256, 16, 1); unit-norm 128-d rows like the PCA'd descriptors.
-    The bf16x3 filter + fp32 refinement must reproduce the plain fp32 matrix path bit for bit."""
+    The fp16 and the bf16x3 filters (+ fp32 refinement) must reproduce the all-fp32 path bit for bit."""
     import torch
 
     g = torch.Generator(device=eng.device)
@@ -472,15 +472,42 @@ def test_knn_bf16_path_two_levels_unit_vectors(eng):
                                       0.3 * torch.randn(nq, d, device=eng.device, generator=g) / d ** 0.5, dim=1)
     eng.db_reset()
     eng.db_add(R)
-    d2, idx = eng.search(Q, k)
-    os.environ["SEGVLAD_KNN_FP32"] = "1"       # same levels, fp32 filter GEMM instead of bf16x3
+    d2, idx = eng.search(Q, k)                 # default: fp16 single-product filter
+    os.environ["SEGVLAD_KNN_FP32"] = "1"       # same levels, fp32 filter GEMM
     try:
         d2f, idxf = eng.search(Q, k)
     finally:
         del os.environ["SEGVLAD_KNN_FP32"]
+    os.environ["SEGVLAD_KNN_FILTER"] = "bf16x3"
+    try:
+        d2b, idxb = eng.search(Q, k)
+    finally:
+        del os.environ["SEGVLAD_KNN_FILTER"]
     assert torch.equal(idx, idxf) and torch.equal(d2, d2f)
+    assert torch.equal(idxb, idxf) and torch.equal(d2b, d2f)
     # and against the oracle on a slice of the queries
     Rh = R.cpu().numpy()
     rd2, ridx = O().knn_l2(Rh, Q[:8].cpu().numpy(), k)
     assert np.abs(d2[:8].cpu().numpy() - rd2).max() < 1e-5
     assert (idx[:8].cpu().numpy() == ridx).mean() > 0.98
+
+
+def test_knn_f16_filter_unnormalised_scales(eng):
+    """The fp16 filter rescales queries and rows by powers of two: rows of very different magnitude (1e-3 .. 1e3),
+    incremental adds that force a rescale, and zero rows must not change the exact result."""
+    rng = np.random.Generator(np.random.PCG64(202))
+    n, d, nq, k = 50000, 64, 40, 20
+    R = rng.standard_normal((n, d)).astype(np.float32) * 1e-3
+    R[n // 2:] *= 1e3
+    R[7] = 0
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q[:10] *= 1e-3
+    eng.db_reset()
+    eng.db_add(R[:40000] * np.float32(1.0))
+    d2a, _ = eng.search(Q[:10], k)              # builds the fp16 image with the small scale
+    eng.db_add(R[40000:])                        # larger magnitudes arrive: the image must be rebuilt
+    d2, idx = (t.cpu().numpy() for t in eng.search(Q, k))
+    rd2, ridx = O().knn_l2(R, Q, k)
+    assert np.allclose(d2, rd2, rtol=2e-5, atol=1e-9)
+    sep = np.minimum(np.diff(rd2, axis=1, prepend=-1), np.diff(rd2, axis=1, append=1e30)) > 1e-4 * rd2
+    assert np.array_equal(idx[sep], ridx[sep])
