@@ -102,18 +102,19 @@ __device__ __forceinline__ void sstore_part(const Stage& st, float* As, float* B
 template <int MODE, bool FAST>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], float* lds, const float* __restrict__ A,
                                               const float* __restrict__ Bm, const float* __restrict__ a_sub, int64_t m0,
-                                              int64_t n0, int M, int N, int Kd, int64_t ldb, int tid, bool vec) {
+                                              int64_t n0, int M, int N, int Kd, int64_t ldb, int tid, bool vec,
+                                              int kbeg, int kend) {
   const int w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
   const int wm = w >> 1, wn = w & 1;
   const int lrow = tid >> 3, lk = (tid & 7) << 2;
-  const int ntiles = (Kd + BK - 1) / BK;
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
   // two register stages (ping-pong): tile kt+1 is being written to LDS while tile kt+2 is still in flight
   Stage s0, s1;
-  gload_tile<MODE, FAST>(s0, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, 0, vec);
+  gload_tile<MODE, FAST>(s0, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, kbeg, vec);
 #pragma unroll
   for (int j = 0; j < 4; ++j) sstore_part(s0, lds, lds + BK * LDT, lrow, lk, j);
-  if (ntiles > 1) gload_tile<MODE, FAST>(s0, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, BK, vec);
-  if (ntiles > 2) gload_tile<MODE, FAST>(s1, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, 2 * BK, vec);
+  if (ntiles > 1) gload_tile<MODE, FAST>(s0, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, kbeg + BK, vec);
+  if (ntiles > 2) gload_tile<MODE, FAST>(s1, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, kbeg + 2 * BK, vec);
   __syncthreads();
   int cur = 0;
   // one k-tile: multiply out of buffer `cur`, spill `st` (tile kt+1) into the other buffer during the last
@@ -152,7 +153,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], float* lds, c
       b1 = nb1;
     }
     __syncthreads();
-    if (kt + 3 < ntiles) gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, (kt + 3) * BK, vec);
+    if (kt + 3 < ntiles) gload_tile<MODE, FAST>(st, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, lrow, lk, kbeg + (kt + 3) * BK, vec);
     cur ^= 1;
   };
   int kt = 0;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                                                       const float* __restrict__ col_add, int tiles_m,
                                                       int b_stride, const float* __restrict__ thr, int64_t thr_ld,
                                                       uint32_t* __restrict__ cand_cnt, float* __restrict__ cand_d2,
-                                                      uint32_t* __restrict__ cand_id, int cap) {
+                                                      uint32_t* __restrict__ cand_id, int cap, int k_per_split) {
   __shared__ float lds[2 * 2 * BK * LDT];  // [buffer][A|B][k][row]
   // tile order: m fastest so that the workgroups sharing a B panel (the big operand: database /
   // PCA components) are adjacent in dispatch order
@@ -193,12 +194,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const bool fast = vec && (Kd % BK == 0) && (m0 + BM <= M) && (n0 + BN <= N) &&
+  // split-K (PCA projection only): blockIdx.y owns k in [kbeg, kend) and writes an un-scaled partial tile
+  const int kbeg = (int)blockIdx.y * k_per_split;
+  const int kend = (k_per_split > 0 && kbeg + k_per_split < Kd) ? kbeg + k_per_split : Kd;
+  const bool fast = vec && (Kd % BK == 0) && (kbeg % BK == 0) && (m0 + BM <= M) && (n0 + BN <= N) &&
                     (MODE != 0 || a_sub == nullptr || (reinterpret_cast<uintptr_t>(a_sub) & 15) == 0);
   if (fast)
-    gemm_mainloop<MODE, true>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec);
+    gemm_mainloop<MODE, true>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec, kbeg, kend);
   else
-    gemm_mainloop<MODE, false>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec);
+    gemm_mainloop<MODE, false>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec, kbeg, kend);
+  if (MODE == 0 && gridDim.y > 1) C += (int64_t)blockIdx.y * M * ldc;
 
   // ---- epilogue ---------------------------------------------------------------------------------
 #pragma unroll
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         const int64_t row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (row < M) {
           if (MODE == 0) {
-            C[row * ldc + col] = acc[mt][nt][r] * cs;
+            C[row * ldc + col] = (gridDim.y > 1) ? acc[mt][nt][r] : acc[mt][nt][r] * cs;
           } else {
             const float v = sv_d2(row_add[row], cs, acc[mt][nt][r]);
             if (MODE == 1) {
@@ -232,6 +237,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   }
 }
 
+// deterministic split-K reduction: out = (sum_s part[s]) * col_scale, slices added in index order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn, int N,
+                                                            int64_t ldc, const float* __restrict__ col_scale,
+                                                            float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= mn) return;
+  float s = part[j];
+  for (int t = 1; t < splits; ++t) s += part[(int64_t)t * mn + j];
+  const int col = (int)(j % ldc);
+  out[j] = (col < N && col_scale) ? s * col_scale[col] : s;
+}
+
 static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
                        int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
                        const float* col_add, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
@@ -240,9 +257,24 @@ static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* 
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "gemm: too many tiles");
-#define SV_GEMM_ARGS                                                                                               \
-  dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A, Bm, C, M, N, Kd, ldc, a_sub, col_scale, row_add, col_add, \
-      tiles_m, b_stride, thr, thr_ld, cand_cnt, cand_d2, cand_id, cap
+  // split-K for the projection when the tile count cannot fill / balance the 512 resident workgroup slots
+  int splits = 1, k_per_split = 0;
+  if (mode == 0 && ldc == N && tiles < 4096 && Kd >= 8 * BK) {
+    splits = (int)((2048 + tiles - 1) / tiles);
+    if (splits > 16) splits = 16;
+    k_per_split = (((Kd + splits - 1) / splits) + BK - 1) / BK * BK;
+    splits = (Kd + k_per_split - 1) / k_per_split;
+  }
+  float* Cout = C;
+  if (splits > 1) {
+    SV_HIP(ctx->s_dist.reserve((size_t)splits * M * ldc * sizeof(float)));
+    C = ctx->s_dist.as<float>();
+  } else {
+    k_per_split = 0;
+  }
+#define SV_GEMM_ARGS                                                                                                    \
+  dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, ctx->stream, A, Bm, C, M, N, Kd, ldc, a_sub, col_scale, row_add, \
+      col_add, tiles_m, b_stride, thr, thr_ld, cand_cnt, cand_d2, cand_id, cap, k_per_split
   if (mode == 0)
     hipLaunchKernelGGL(gemm_nt_kernel<0>, SV_GEMM_ARGS);
   else if (mode == 1)
@@ -251,6 +283,12 @@ static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* 
     hipLaunchKernelGGL(gemm_nt_kernel<2>, SV_GEMM_ARGS);
 #undef SV_GEMM_ARGS
   SV_HIP(hipGetLastError());
+  if (splits > 1) {
+    const int64_t mn = (int64_t)M * ldc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, ctx->stream, C, splits, mn, N, ldc,
+                       col_scale, Cout);
+    SV_HIP(hipGetLastError());
+  }
   return SEGVLAD_OK;
 }
 
