@@ -66,6 +66,10 @@ def parse():
     p.add_argument("--no-pca", action="store_true", help="raw K*D descriptors (only with a small --db-images)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--build-batch", type=int, default=100)
+    p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI); 'gloo' + "
+                   "--same-device lets several ranks share ONE GPU to exercise the N>1 code path on a 1-GPU box")
+    p.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
+    p.add_argument("--dump-preds", default=None, help="debug: rank 0 writes the last step's predictions to this .npy")
     p.add_argument("--debug-timing", action="store_true", help="after the timed region, print a synchronised per-phase wall-clock breakdown of one step to stderr")
     return p.parse_args()
 
@@ -125,11 +129,16 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if a.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
 
     S, K, D = a.segments, a.clusters, a.dim
     H, W = a.height, a.width
@@ -199,9 +208,13 @@ def main():
     def step():
         qd = pipe.describe(q_tok, q_msk, q_off_local)
         if world > 1:
-            parts = [torch.empty((int(qb[r + 1] - qb[r]) * S, P), device=dev) for r in range(world)]
+            rows = [int(qb[r + 1] - qb[r]) * S for r in range(world)]
+            mx = max(rows)
+            if qd.shape[0] < mx:   # all_gather needs equal shapes: pad the short slices
+                qd = torch.cat([qd, qd.new_zeros((mx - qd.shape[0], P))])
+            parts = [torch.empty((mx, P), device=dev) for _ in range(world)]
             dist.all_gather(parts, qd.contiguous())
-            qd = torch.cat(parts)
+            qd = torch.cat([p_[:n_] for p_, n_ in zip(parts, rows)])
         return index.retrieve(qd, q_off_all, 200, 50, 5)
 
     def fence():
@@ -242,6 +255,8 @@ def main():
         sims, m = eng.sims_from_d2(d2, idx, 50); t = tick("sims", t)
         eng.vote(m, sims, q_off_all, n_top=5, img_of_seg=index.img_of_seg_global); t = tick("vote", t)
     pred = out[0].cpu().numpy()
+    if a.dump_preds and rank == 0:
+        np.save(a.dump_preds, pred)
     gt = [[int(t)] for t in tau]
     recalls = recall_at(pred, gt, 5)
 

@@ -1,0 +1,73 @@
+"""N>1 path on the GPU box: two ranks share the one GPU (gloo for the collectives, each rank with its own
+SegVLADEngine context), the DB is row-sharded, per-shard top-k lists are all-gathered, merged and voted on the
+device.  Invariant: ids, distances and predictions equal the single-index result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem():
+    from revisit_anything_amd import synth
+
+    n_img, S, d, n_q = 900, 40, 64, 12          # 36000 rows: the sharded halves use the matrix path, the single index the filter path
+    R, img = synth.make_planted_db(n_img, S, d, seed=3000)
+    Q, tau, off = synth.make_planted_queries(R, n_img, S, n_q, seed=4000, sigma_q=2.0)
+    return R, img, Q, tau, off, n_img, S
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from revisit_anything_amd.engine import SegVLADEngine
+    from revisit_anything_amd.sharded import ShardedSegmentIndex, shard_images
+
+    R, img, Q, tau, off, n_img, S = _problem()
+    eng = SegVLADEngine(0)
+    ib = shard_images(n_img, world)
+    rows = slice(int(ib[rank]) * S, int(ib[rank + 1]) * S)
+    idx = ShardedSegmentIndex(eng, device=eng.device)
+    idx.build(torch.from_numpy(R[rows]).to(eng.device), img[rows])
+    d2, ids = idx.search(torch.from_numpy(Q).to(eng.device), 60)
+    pred, sc, m, sims = idx.retrieve(torch.from_numpy(Q).to(eng.device), off, k_search=60, k_vote=50, n_top=5, want_scores=True)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d2=d2.cpu().numpy(), ids=ids.cpu().numpy(), pred=pred.cpu().numpy(),
+             sc=sc.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_single_index(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+
+    assert torch.cuda.is_available()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    R, img, Q, tau, off, n_img, S = _problem()
+    eng = SegVLADEngine(0)
+    eng.db_add(R, img)
+    d2, ids = eng.search(Q, 60)
+    sims, m = eng.sims_from_d2(d2, ids, 50)
+    pred, sc = eng.vote(m, sims, off, n_top=5)
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["ids"], ids.cpu().numpy())
+        assert np.array_equal(z["d2"], d2.cpu().numpy())
+        assert np.array_equal(z["pred"], pred.cpu().numpy())
+        assert np.array_equal(z["sc"], sc.cpu().numpy())
+    assert (pred.cpu().numpy()[:, 0] // 4 == tau // 4).mean() >= 0.9   # right sibling group (4 near-duplicate places)
