@@ -63,6 +63,11 @@ int segvlad_set_vocab(segvlad_ctx* ctx, const float* C, int K, int D);
 int segvlad_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
                       uint64_t* inc_bits);
 
+/*      Fused variant: one pass over the mask bytes yields the incidence rows AND the centroids of
+ *      func_vpr.py:1314 (see segvlad_mask_centroids) -- what the batched pipeline calls.            */
+int segvlad_incidence_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                                uint64_t* inc_bits, double* centroids);
+
 /* ---- mask centroids: np.nonzero(mask).mean(1)[::-1]                  func_vpr.py:1314
  *      centroids [S][2] fp64 (x, y); an empty mask yields NaN (the reference raises ValueError).  */
 int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* centroids);

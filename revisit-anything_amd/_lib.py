@@ -24,6 +24,8 @@ SIGNATURES = {
     "segvlad_synchronize": (C.c_int, [c_ctx_p]),
     "segvlad_set_vocab": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int]),
     "segvlad_incidence": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "segvlad_incidence_centroids": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
     "segvlad_mask_centroids": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "segvlad_adjacency": (C.c_int, [c_ctx_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "segvlad_images": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_void_p,

@@ -203,24 +203,36 @@ int segvlad_set_vocab(segvlad_ctx* ctx, const float* C, int K, int D) {
 }
 
 // ---- incidence / centroids -------------------------------------------------------------------------
-int segvlad_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
-                      uint64_t* inc_bits) {
-  CHECK_CTX();
+static int incidence_impl(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                          uint64_t* inc_bits, double* centroids, bool want_centroids) {
   if (S < 0 || Hm <= 0 || Wm <= 0 || H <= 0 || W <= 0 || patch <= 0 || H / patch <= 0 || W / patch <= 0)
     return ctx->fail(SEGVLAD_ERR_ARG, "incidence: bad geometry S=%d masks %dx%d image %dx%d patch %d", S, Hm, Wm, H, W, patch);
   if (S == 0) return SEGVLAD_OK;
-  if (!masks || !inc_bits) return ctx->fail(SEGVLAD_ERR_ARG, "incidence: null pointer");
+  if (!masks || !inc_bits || (want_centroids && !centroids)) return ctx->fail(SEGVLAD_ERR_ARG, "incidence: null pointer");
   const int N = (H / patch) * (W / patch), nw = (N + 63) / 64;
   const void* dm;
-  void* dout;
+  void *dout, *dcent = nullptr;
   SV_TRY(sv_in(ctx, masks, (size_t)S * Hm * Wm, &dm));
   SV_TRY(sv_out(ctx, inc_bits, (size_t)S * nw * 8, &dout));
+  if (want_centroids) SV_TRY(sv_out(ctx, centroids, (size_t)S * 2 * sizeof(double), &dcent));
   {
     StageScope sc(ctx, "incidence");
-    SV_TRY(sv_launch_incidence(ctx, (const uint8_t*)dm, S, Hm, Wm, H, W, patch, (uint64_t*)dout));
+    SV_TRY(sv_launch_incidence(ctx, (const uint8_t*)dm, S, Hm, Wm, H, W, patch, (uint64_t*)dout, (double*)dcent));
     sc.count();
   }
   return sv_finish(ctx);
+}
+
+int segvlad_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                      uint64_t* inc_bits) {
+  CHECK_CTX();
+  return incidence_impl(ctx, masks, S, Hm, Wm, H, W, patch, inc_bits, nullptr, false);
+}
+
+int segvlad_incidence_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
+                                uint64_t* inc_bits, double* centroids) {
+  CHECK_CTX();
+  return incidence_impl(ctx, masks, S, Hm, Wm, H, W, patch, inc_bits, centroids, true);
 }
 
 int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* centroids) {

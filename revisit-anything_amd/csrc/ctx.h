@@ -135,7 +135,7 @@ struct StageScope {
 // vlad_kernels.hip
 int sv_launch_vocab_prepare(segvlad_ctx* ctx);
 int sv_launch_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
-                        uint64_t* inc_bits);
+                        uint64_t* inc_bits, double* centroids /* may be null */);
 int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* out);
 int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg_off_dev, const int64_t* adj_off_dev,
                         int B, int S_max, int order, uint8_t* adj, uint32_t* n_bad);

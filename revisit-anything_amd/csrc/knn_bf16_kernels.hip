@@ -555,8 +555,22 @@ __device__ __forceinline__ void bitonic64(uint64_t* a, int n, int tid) {
   __syncthreads();
 }
 
-// mode 0: thr_out[q] = A_k (k-th smallest approximate distance; +inf if fewer than k candidates)
-// mode 1: refine list = ids with d2~ <= A_k + 2 eps(q), at most rcap (more -> *overflow)
+// wave-aggregated LDS histogram increment (keys cluster on few digits: a plain atomicAdd would serialise)
+__device__ __forceinline__ void hist_add_(uint32_t* hist, bool active, uint32_t bin) {
+  uint64_t todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t lb = __shfl(bin, leader);
+    const uint64_t same = __ballot(active && bin == lb) & todo;
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+// Candidate lists are only RANKED here, never sorted: an MSB-first radix select over the keys held in LDS
+// yields A_k, the k-th smallest approximate distance (+inf if fewer than k candidates).
+//   mode 0: thr_out[q] = A_k
+//   mode 1: refine list = ids with d2~ <= A_k + 2 eps(q) (unordered; at most rcap, more -> *overflow)
 __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
                                                             const uint32_t* __restrict__ cid, int cap, int k, int mode,
                                                             const float* __restrict__ qn, float c_eps, float rn_max,
@@ -564,7 +578,9 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ ref_id, int rcap,
                                                             uint32_t* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);  // [cap]
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_digit, s_krem, s_n;
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   const uint32_t c = cnt[row];
@@ -575,46 +591,72 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
     }
     return;
   }
-  int npad = 2;
-  while (npad < (int)c) npad <<= 1;
-  for (int j = tid; j < npad; j += 256)
-    a[j] = (j < (int)c) ? (((uint64_t)f2key_(cd2[row * cap + j]) << 32) | cid[row * cap + j]) : ~0ull;
-  bitonic64(a, npad, tid);
-  const float ak = ((int)c >= k) ? key2f_((uint32_t)(a[k - 1] >> 32)) : INFINITY;
+  for (int j = tid; j < (int)c; j += 256) keys[j] = f2key_(cd2[row * cap + j]);
+  float ak = INFINITY;
+  if ((int)c >= k) {
+    uint32_t prefix = 0, mask = 0, krem = (uint32_t)k;
+    for (int pass = 3; pass >= 0; --pass) {
+      hist[tid] = 0;
+      __syncthreads();
+      const int shift = 8 * pass;
+      for (int j0 = 0; j0 < (int)c; j0 += 256) {
+        const int j = j0 + tid;
+        const uint32_t key = (j < (int)c) ? keys[j] : 0u;
+        hist_add_(hist, (j < (int)c) && ((key & mask) == prefix), (key >> shift) & 255u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0, dsel = 255;
+        for (uint32_t b = 0; b < 256; ++b) {
+          const uint32_t h = hist[b];
+          if (cum + h >= krem) {
+            dsel = b;
+            break;
+          }
+          cum += h;
+        }
+        s_digit = dsel;
+        s_krem = krem - cum;
+      }
+      __syncthreads();
+      prefix |= s_digit << shift;
+      mask |= 255u << shift;
+      krem = s_krem;
+      __syncthreads();
+    }
+    ak = key2f_(prefix);
+  } else {
+    __syncthreads();
+  }
   if (mode == 0) {
     if (tid == 0) thr_out[row] = ak;
     return;
   }
-  const float lim = ak + 2.f * c_eps * sqrtf(qn[row] * rn_max);
-  const uint32_t klim = f2key_(lim);
-  // sorted ascending: count entries with key <= klim (parallel count; entries are contiguous from 0)
-  __shared__ uint32_t s_n;
+  const uint32_t klim = f2key_(ak + 2.f * c_eps * sqrtf(qn[row] * rn_max));
   if (tid == 0) s_n = 0;
   __syncthreads();
-  uint32_t local = 0;
-  for (int j = tid; j < (int)c; j += 256) local += ((uint32_t)(a[j] >> 32) <= klim) ? 1u : 0u;
-  atomicAdd(&s_n, local);
+  for (int j = tid; j < (int)c; j += 256) {
+    if (keys[j] <= klim) {
+      const uint32_t slot = atomicAdd(&s_n, 1u);
+      if (slot < (uint32_t)rcap) ref_id[row * rcap + slot] = cid[row * cap + j];
+    }
+  }
   __syncthreads();
-  const uint32_t n = s_n;
-  if (n > (uint32_t)rcap) {
-    if (tid == 0) {
+  if (tid == 0) {
+    if (s_n > (uint32_t)rcap) {
       atomicOr(overflow, 1u);
       ref_cnt[row] = 0;
+    } else {
+      ref_cnt[row] = s_n;
     }
-    return;
   }
-  for (int j = tid; j < (int)n; j += 256) ref_id[row * rcap + j] = (uint32_t)a[j];
-  if (tid == 0) ref_cnt[row] = n;
 }
 
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int k, int mode, const float* qn, float c_eps, float rn_max, float* thr_out,
                             uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* overflow) {
   if (nq <= 0) return SEGVLAD_OK;
-  const size_t lds = (size_t)cap * 8;
-  if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_approx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  const size_t lds = (size_t)cap * 4;
   hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, k, mode, qn,
                      c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, overflow);
   SV_HIP(hipGetLastError());

@@ -104,12 +104,125 @@ __global__ __launch_bounds__(256) void incidence_kernel(const uint8_t* __restric
   if (lane == 0) inc[(size_t)s * nw + word] = b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused incidence + centroid: one workgroup per mask, ONE coalesced 16-B/lane pass over the mask bytes.
+//   phase 1: every 16-pixel chunk is reduced to a 16-bit "non-zero" word; non-empty chunks are OR-ed into an
+//            LDS bitmap of the mask (Hm x Wm bits) and feed the exact integer centroid sums;
+//   phase 2: lane = token: OR of the bitmap bits its up-sampled 14x14 cell samples (range test per source
+//            row when the mask is not larger than the image, per-pixel walk otherwise); ballot -> u64 words.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t nz_nibble(uint32_t w) {  // bit j = (byte j of w != 0)
+  uint32_t t = w | (w >> 4);
+  t |= t >> 2;
+  t |= t >> 1;
+  t &= 0x01010101u;
+  return ((t * 0x01020408u) >> 24) & 0xfu;
+}
+
+__global__ __launch_bounds__(256) void incidence_fused_kernel(const uint8_t* __restrict__ masks, int Hm, int Wm, int H, int W,
+                                                              int patch, int dh, int dw, float sh, float sw,
+                                                              uint64_t* __restrict__ inc, int nw,
+                                                              double* __restrict__ cent) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* bits = reinterpret_cast<uint32_t*>(smem);  // [Hm][wpr]
+  __shared__ unsigned long long red[3][4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int wpr = (Wm + 31) >> 5;  // u32 words per bitmap row
+  const int cpr = Wm >> 4;         // 16-pixel chunks per row (Wm % 16 == 0)
+  for (int j = tid; j < Hm * wpr; j += 256) bits[j] = 0;
+  __syncthreads();
+  const uint4* m16 = reinterpret_cast<const uint4*>(masks + (size_t)s * Hm * Wm);
+  const int total = Hm * cpr;
+  unsigned long long sr = 0, sc = 0, cnt = 0;
+  for (int q = tid; q < total; q += 256) {
+    const uint4 v = m16[q];
+    if ((v.x | v.y | v.z | v.w) == 0) continue;
+    const uint32_t nz = nz_nibble(v.x) | (nz_nibble(v.y) << 4) | (nz_nibble(v.z) << 8) | (nz_nibble(v.w) << 12);
+    const int r = q / cpr, cc = q - r * cpr;
+    atomicOr(&bits[r * wpr + (cc >> 1)], nz << (16 * (cc & 1)));
+    const uint32_t pc = __popc(nz);
+    const uint32_t pos = __popc(nz & 0xAAAAu) + 2 * __popc(nz & 0xCCCCu) + 4 * __popc(nz & 0xF0F0u) + 8 * __popc(nz & 0xFF00u);
+    cnt += pc;
+    sr += (unsigned long long)r * pc;
+    sc += (unsigned long long)(16 * cc) * pc + pos;
+  }
+  if (cent) {  // exact integer sums -> bit-identical to np.nonzero(mask).mean(1)[::-1]
+    for (int o = 32; o > 0; o >>= 1) {
+      sr += __shfl_xor(sr, o);
+      sc += __shfl_xor(sc, o);
+      cnt += __shfl_xor(cnt, o);
+    }
+    if ((tid & 63) == 0) {
+      red[0][tid >> 6] = sr;
+      red[1][tid >> 6] = sc;
+      red[2][tid >> 6] = cnt;
+    }
+  }
+  __syncthreads();
+  if (cent && tid == 0) {
+    const double c = (double)(red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    cent[2 * (size_t)s + 0] = (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]) / c;
+    cent[2 * (size_t)s + 1] = (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]) / c;
+  }
+  const int N = dh * dw;
+  const bool ranges = (sh <= 1.0f) && (sw <= 1.0f);  // up-sampling: a cell samples contiguous source rows/cols
+  for (int t0 = 0; t0 < nw * 64; t0 += 256) {
+    const int t = t0 + tid;
+    bool any = false;
+    if (t < N) {
+      const int ty = t / dw, tx = t - ty * dw;
+      const int i0 = ty * patch, i1 = (ty == dh - 1) ? H - 1 : i0 + patch - 1;
+      const int j0 = tx * patch, j1 = (tx == dw - 1) ? W - 1 : j0 + patch - 1;
+      if (ranges) {
+        const int rlo = min((int)floorf((float)i0 * sh), Hm - 1), rhi = min((int)floorf((float)i1 * sh), Hm - 1);
+        const int clo = min((int)floorf((float)j0 * sw), Wm - 1), chi = min((int)floorf((float)j1 * sw), Wm - 1);
+        const int w0 = clo >> 5, w1 = chi >> 5;
+        for (int r = rlo; r <= rhi && !any; ++r) {
+          for (int wv = w0; wv <= w1; ++wv) {
+            const int lo = (wv == w0) ? (clo & 31) : 0, hi = (wv == w1) ? (chi & 31) : 31;
+            const uint32_t msk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            if (bits[r * wpr + wv] & msk) { any = true; break; }
+          }
+        }
+      } else {
+        int pr = -1;
+        for (int i = i0; i <= i1 && !any; ++i) {
+          const int r = min((int)floorf((float)i * sh), Hm - 1);
+          if (r == pr) continue;
+          pr = r;
+          int pc = -1;
+          for (int j = j0; j <= j1; ++j) {
+            const int c = min((int)floorf((float)j * sw), Wm - 1);
+            if (c == pc) continue;
+            pc = c;
+            if ((bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u) { any = true; break; }
+          }
+        }
+      }
+    }
+    const uint64_t b = __ballot(any);
+    const int word = t >> 6;
+    if ((tid & 63) == 0 && word < nw) inc[(size_t)s * nw + word] = b;
+  }
+}
+
 int sv_launch_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
-                        uint64_t* inc_bits) {
+                        uint64_t* inc_bits, double* centroids) {
   const int dh = H / patch, dw = W / patch;
   const int N = dh * dw, nw = (N + 63) / 64;
   const float sh = (float)Hm / (float)H, sw = (float)Wm / (float)W;
   if (S == 0) return SEGVLAD_OK;
+  const size_t lds = (size_t)Hm * ((Wm + 31) / 32) * 4;
+  if ((Wm % 16) == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0 && lds <= 150 * 1024) {
+    if (lds > 64 * 1024)
+      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(incidence_fused_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(incidence_fused_kernel, dim3(S), dim3(256), lds, ctx->stream, masks, Hm, Wm, H, W, patch, dh, dw, sh, sw,
+                       inc_bits, nw, centroids);
+    SV_HIP(hipGetLastError());
+    return SEGVLAD_OK;
+  }
+  if (centroids) SV_TRY(sv_launch_centroids(ctx, masks, S, Hm, Wm, centroids));
   hipLaunchKernelGGL(incidence_kernel, dim3(S, (nw + 3) / 4), dim3(256), 0, ctx->stream, masks, Hm, Wm, H, W, patch, dh,
                      dw, sh, sw, inc_bits, nw);
   SV_HIP(hipGetLastError());

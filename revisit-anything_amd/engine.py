@@ -118,6 +118,19 @@ class SegVLADEngine:
         self._keep = [m]
         return out
 
+    def incidence_centroids(self, masks, H: int, W: int, patch: int = 14):
+        """One pass over the masks: (incidence bit rows [S, ceil(N/64)] as int64, centroids [S,2] fp64 (x, y))."""
+        m = masks.to(torch.uint8).contiguous() if isinstance(masks, torch.Tensor) else np.ascontiguousarray(masks).astype(np.uint8)
+        S, Hm, Wm = m.shape
+        N = (H // patch) * (W // patch)
+        out = self._empty((S, (N + 63) // 64), torch.int64)
+        cent = self._empty((S, 2), torch.float64)
+        self._stream()
+        self._check(self.lib.segvlad_incidence_centroids(self._h, _ptr(m), S, Hm, Wm, H, W, patch, _ptr(out), _ptr(cent)),
+                    "incidence_centroids")
+        self._keep = [m]
+        return out, cent
+
     def mask_centroids(self, masks) -> torch.Tensor:
         m = masks.to(torch.uint8).contiguous() if isinstance(masks, torch.Tensor) else np.ascontiguousarray(masks).astype(np.uint8)
         S, Hm, Wm = m.shape

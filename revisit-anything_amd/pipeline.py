@@ -58,15 +58,16 @@ class SegVLADPipeline:
         adj: precomputed concatenated adjacency (uint8) or None to derive it (order>0) from the masks.
         Returns [S_tot, P] (PCA'd, row-normalised when l2norm) or [S_tot, K*D]."""
         eng = self.eng
-        bits = eng.incidence(masks, self.H, self.W, self.patch)
         if self.order and adj is None:
-            cent = eng.mask_centroids(masks)
+            bits, cent = eng.incidence_centroids(masks, self.H, self.W, self.patch)   # one pass over the mask bytes
             if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)
                 adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
             else:                     # device kernel: no host round trip
                 adj = eng.adjacency(cent, seg_offsets, self.order)
-        elif not self.order:
-            adj = None
+        else:
+            bits = eng.incidence(masks, self.H, self.W, self.patch)
+            if not self.order:
+                adj = None
         desc = eng.seg_vlad(tokens, bits, seg_offsets, adj)["out"]
         if self.use_pca:
             desc = eng.pca_apply(desc, l2norm=l2norm)

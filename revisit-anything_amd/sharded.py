@@ -78,13 +78,15 @@ class ShardedSegmentIndex:
         return int(self.row_start[-1])
 
     # ---- query --------------------------------------------------------------------------------------
-    def search(self, Q, k: int):
-        """Global top-k over all shards: (d2 [nq,k] ascending, idx [nq,k] GLOBAL ids), identical on every rank."""
+    def search(self, Q, k: int, k_local: Optional[int] = None):
+        """Global top-k over all shards: (d2 [nq,k] ascending, idx [nq,k] GLOBAL ids), identical on every rank.
+        k_local >= k: search depth used on each shard before the exchange (only the first k columns travel:
+        the global top-k is contained in the union of the per-shard top-k lists)."""
         nq = int(Q.shape[0])
         if self.n_local:
-            d2, idx = self.be.search(Q, k)
-            d2 = torch.as_tensor(d2).to(self.device)
-            idx = torch.as_tensor(idx).to(self.device)
+            d2, idx = self.be.search(Q, max(k, k_local or k))
+            d2 = torch.as_tensor(d2).to(self.device)[:, :k].contiguous()
+            idx = torch.as_tensor(idx).to(self.device)[:, :k].contiguous()
             idx = torch.where(idx >= 0, idx + int(self.row_start[self.rank]), idx)
         else:
             d2 = torch.full((nq, k), float("inf"), dtype=torch.float32, device=self.device)
@@ -104,7 +106,11 @@ class ShardedSegmentIndex:
                  want_scores: bool = False):
         """search -> keep k_vote, 2-d^2 -> vote with the global segment->image map.  The global min/max of the
         vote (func_vpr.py:212-213) is taken over the merged (global) similarities, so it needs no extra collective."""
-        d2, idx = self.search(Q, k_search)
+        if self.world > 1:
+            # the reference searches 200 and keeps 50 (place_rec_main.py:56,78): only the kept columns are exchanged
+            d2, idx = self.search(Q, k_vote, k_local=k_search)
+        else:
+            d2, idx = self.search(Q, k_search)
         sims, m = self.be.sims_from_d2(d2, idx, k_vote)
         pred, sc = self.be.vote(m, sims, np.asarray(qseg_offsets, dtype=np.int32), n_top=n_top, mode=mode,
                                 img_of_seg=self.img_of_seg_global, want_scores=want_scores)

@@ -511,3 +511,17 @@ def test_knn_f16_filter_unnormalised_scales(eng):
     assert np.allclose(d2, rd2, rtol=2e-5, atol=1e-9)
     sep = np.minimum(np.diff(rd2, axis=1, prepend=-1), np.diff(rd2, axis=1, append=1e30)) > 1e-4 * rd2
     assert np.array_equal(idx[sep], ridx[sep])
+
+
+def test_incidence_centroids_fused_equals_separate(eng):
+    for (S, Hm, Wm, H, W, seed) in [(50, 240, 320, 480, 640, 1), (9, 64, 96, 126, 150, 2), (5, 208, 272, 100, 130, 3)]:
+        masks = synth().make_blob_masks(S, Hm, Wm, seed=seed).astype(np.uint8) * np.uint8(255)   # any non-zero byte counts
+        bits, cent = eng.incidence_centroids(masks, H, W)
+        N = (H // 14) * (W // 14)
+        assert np.array_equal(O().unpack_bits_u64(bits.cpu().numpy().view(np.uint64), N), O().incidence(masks != 0, H, W))
+        assert np.array_equal(cent.cpu().numpy(), O().mask_centroids([m for m in masks]))
+    # width not a multiple of 16 -> the per-token fallback kernel, same results
+    masks = synth().make_blob_masks(6, 50, 70, seed=4).astype(np.uint8)
+    bits, cent = eng.incidence_centroids(masks, 126, 150)
+    assert np.array_equal(O().unpack_bits_u64(bits.cpu().numpy().view(np.uint64), 90), O().incidence(masks != 0, 126, 150))
+    assert np.array_equal(cent.cpu().numpy(), O().mask_centroids([m for m in masks]))
