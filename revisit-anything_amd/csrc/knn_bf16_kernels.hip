@@ -340,18 +340,27 @@ int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float sc
   return SEGVLAD_OK;
 }
 
-// 128-B rows (64 fp16 = 8 chunks of 16 B): physical chunk of logical chunk c in row r
-__device__ __forceinline__ int swz8(int r, int c) { return c ^ ((r >> 1) & 7); }
-
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+template <int N_>
+__device__ __forceinline__ void wait_vm_lgkm0() {  // s_waitcnt needs a literal count
+  if (N_ == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if (N_ == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+  else if (N_ == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+  else if (N_ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+}
+
 // Operand tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write): one
-// wave-instruction fills 1 KiB = 8 rows x 128 B of the LDS image, lane l landing at base + 16 l.  The LDS
-// image must therefore be lane-linear, so the bank-conflict swizzle is applied on the SOURCE side: lane
-// (row_in_block = l >> 3, physical chunk = l & 7) fetches logical chunk (l & 7) ^ ((row >> 1) & 7) of its row,
-// and the MFMA fragment reads apply the same involution.
-template <int BM, int BN, int WM, int WN>
+// wave-instruction fills 1 KiB of the LDS image, lane l landing at base + 16 l, i.e. RP = 1024 / row_bytes rows
+// of HBK fp16.  The LDS image must be lane-linear, so the bank-conflict swizzle is applied on the SOURCE side:
+// the lane that owns physical chunk p of row r fetches logical chunk p ^ f(r), and the MFMA fragment reads apply
+// the same involution (f(r) = (r >> 1) & 7 for 128-B rows, (r >> 2) & 3 for 64-B rows: a 16-lane ds_read_b128
+// group then covers all 16 bank slots).
+//   BM x BN tile, WM x WN waves, HBK k per tile, two A stages (queries: L2 resident) and NB B stages (database
+//   rows stream from HBM/MALL; NB = 3 keeps their DMA two k-tiles ahead via a counted vmcnt).
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m,
     float inv_scale, const float* __restrict__ qn, const float* __restrict__ rn, const float* __restrict__ thr,
@@ -359,10 +368,14 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-  constexpr int HBK = 64;
-  constexpr int PA = BM * 128, PB = BN * 128;
-  constexpr int JA = BM / 8 / NW, JB = BN / 8 / NW;  // 1-KiB DMA blocks per wave and operand
-  static_assert(JA * 8 * NW == BM && JB * 8 * NW == BN, "tile rows must split into 8-row blocks per wave");
+  constexpr int RB = HBK * 2;            // row bytes per k-tile
+  constexpr int CH = RB / 16;            // 16-B chunks per row (4 or 8)
+  constexpr int RP = 1024 / RB;          // rows per 1-KiB DMA piece
+  constexpr int KS = HBK / 16;           // MFMA k-steps per tile
+  constexpr int PA = BM * RB, PB = BN * RB;
+  constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and operand
+  static_assert(JA * RP * NW == BM && JB * RP * NW == BN && (JA + JB) % KS == 0, "tile/wave geometry");
+  static_assert(TM * TN * 16 <= 128, "survivor bitmap holds 128 accumulator elements per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tile = blockIdx.x;
   const int tm = tile % tiles_m, tn = tile / tiles_m;
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   const int wm = w / WN, wn = w % WN;
   const int64_t ldb = (int64_t)d * b_stride;
   const int ntiles = d / HBK;
+  auto swz = [](int r, int c) { return CH == 8 ? (c ^ ((r >> 1) & 7)) : (c ^ ((r >> 2) & 3)); };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -381,130 +395,197 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // per-lane source rows of this wave's DMA blocks (clamped: edge rows are never emitted)
-  const int lrow = l >> 3, lch = l & 7;
+  // per-lane source rows of this wave's DMA pieces (clamped: edge rows are never emitted)
+  const int lrow_p = l / CH, lch = l % CH;
   const uint16_t* srcA[JA];
   const uint16_t* srcB[JB];
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
-    const int row = (w * JA + j) * 8 + lrow;
+    const int row = (w * JA + j) * RP + lrow_p;
     const int64_t qa = (m0 + row < M) ? (m0 + row) : (int64_t)(M - 1);
-    srcA[j] = Qh + qa * d + 8 * (lch ^ ((row >> 1) & 7));
+    srcA[j] = Qh + qa * d + 8 * swz(row, lch);
   }
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
-    const int row = (w * JB + j) * 8 + lrow;
+    const int row = (w * JB + j) * RP + lrow_p;
     const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
-    srcB[j] = Rh + rb * ldb + 8 * (lch ^ ((row >> 1) & 7));
+    srcB[j] = Rh + rb * ldb + 8 * swz(row, lch);
   }
-  // LDS: two A stages (queries: L2-resident, one k-tile of prefetch suffices) and THREE B stages: the database
-  // rows stream from HBM with ~2.5 us latency, so their DMA runs two k-tiles ahead.  Because vmcnt retires in
-  // order, "everything but the youngest JB DMA instructions has landed" is exactly "A(kt+1) and B(kt+1) are in".
   unsigned char* const Abase = lds;
   unsigned char* const Bbase = lds + 2 * PA;
-  auto dmaA = [&](int kt, int ia) {
-    unsigned char* S = Abase + ia * PA;
-    const int k0 = kt * HBK;
-#pragma unroll
-    for (int j = 0; j < JA; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0), (lptr_t)(S + (w * JA + j) * 1024), 16, 0, 0);
+  constexpr int BAHEAD = NB - 1;  // how many k-tiles ahead the B DMA runs (A always runs one ahead)
+  // DMA piece p of iteration kt: pieces 0..JA-1 belong to A(kt+1), JA..JA+JB-1 to B(kt+BAHEAD)
+  auto dma_piece = [&](int piece, int kt, int ia_next, int ib_next) {
+    if (ABL == 3) return;  // ablation: no DMA in the loop
+    if (piece < JA) {
+      if (kt + 1 < ntiles)
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[piece] + (kt + 1) * HBK),
+                                         (lptr_t)(Abase + ia_next * PA + (w * JA + piece) * 1024), 16, 0, 0);
+    } else {
+      const int j = piece - JA;
+      if (kt + BAHEAD < ntiles)
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (kt + BAHEAD) * HBK),
+                                         (lptr_t)(Bbase + ib_next * PB + (w * JB + j) * 1024), 16, 0, 0);
+    }
   };
-  auto dmaB = [&](int kt, int ib) {
-    unsigned char* S = Bbase + ib * PB;
-    const int k0 = kt * HBK;
+  // prologue: A(0), B(0) [, B(1)]
+#pragma unroll
+  for (int j = 0; j < JA; ++j)
+    __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j]), (lptr_t)(Abase + (w * JA + j) * 1024), 16, 0, 0);
+#pragma unroll
+  for (int j = 0; j < JB; ++j)
+    __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j]), (lptr_t)(Bbase + (w * JB + j) * 1024), 16, 0, 0);
+  if (NB == 3 && ntiles > 1) {
 #pragma unroll
     for (int j = 0; j < JB; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + k0), (lptr_t)(S + (w * JB + j) * 1024), 16, 0, 0);
-  };
-  static_assert(JB == 4, "the counted wait below leaves exactly JB = 4 DMA instructions in flight");
-
-  dmaA(0, 0);
-  dmaB(0, 0);
-  if (ntiles > 1) {
-    dmaB(1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + HBK), (lptr_t)(Bbase + PB + (w * JB + j) * 1024), 16, 0, 0);
+    wait_vm_lgkm0<JB>();
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm_lgkm0<0>();
   }
   __builtin_amdgcn_s_barrier();
+
   int ia = 0, ib = 0;
   const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
   for (int kt = 0; kt < ntiles; ++kt) {
-    if (kt + 1 < ntiles) dmaA(kt + 1, ia ^ 1);
-    const int ib2 = (ib + 2 >= 3) ? ib - 1 : ib + 2;
-    if (kt + 2 < ntiles) dmaB(kt + 2, ib2);
+    const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
     const unsigned char* SA = Abase + ia * PA;
     const unsigned char* SB = Bbase + ib * PB;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int cl = 2 * ks + kk;  // logical 16-B chunk (8 consecutive k) of this lane
       f16x8 a[TM], b[TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         const int ra = fa0 + 32 * t;
-        a[t] = *reinterpret_cast<const f16x8*>(SA + ra * 128 + swz8(ra, cl) * 16);
+        a[t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
       }
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         const int rb = fb0 + 32 * t;
-        b[t] = *reinterpret_cast<const f16x8*>(SB + rb * 128 + swz8(rb, cl) * 16);
+        b[t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
       }
+#pragma unroll
+      for (int pz = 0; pz < (JA + JB) / KS; ++pz) dma_piece(ks * ((JA + JB) / KS) + pz, kt, ia ^ 1, ibn);
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a[mt], b[nt], acc[mt][nt]);
+        for (int nt = 0; nt < TN; ++nt) {
+          if (ABL == 2) {  // ablation: no MFMA (operands stay live)
+            acc[mt][nt][0] += (float)a[mt][0] + (float)b[nt][0];
+          } else {
+            acc[mt][nt] = MFMA_F16(a[mt], b[nt], acc[mt][nt]);
+          }
+        }
     }
-    // this wave's pieces of A(kt+1) and B(kt+1) have landed (B(kt+2) may still fly) and its LDS reads are done;
-    // after the barrier that holds for every wave, so the stages of tile kt may be overwritten
-    if (kt + 2 < ntiles)
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    // this wave's pieces of A(kt+1) and B(kt+1) have landed (with NB = 3, B(kt+2) -- the youngest JB DMA
+    // instructions -- may still fly: vmcnt retires in order) and its LDS reads are done; after the barrier that
+    // holds for every wave, so the stages of tile kt may be overwritten
+    if (NB == 3 && kt + 2 < ntiles)
+      wait_vm_lgkm0<JB>();
     else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      wait_vm_lgkm0<0>();
     __builtin_amdgcn_s_barrier();
     ia ^= 1;
-    ib = (ib + 1 >= 3) ? 0 : ib + 1;
+    ib = (ib + 1 >= NB) ? 0 : ib + 1;
   }
 
-  // ---- epilogue: keep d2~ <= thr + eps_mult * eps(q).  The test runs on the raw accumulator against a per-row
-  // bound (one fma + compare per element); survivors are re-tested with the exact expression. -----------------
-  float cn[TN];
+  if (ABL >= 1) {  // ablation: no epilogue (accumulators stay live)
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) t += acc[mt][nt][0] + acc[mt][nt][15];
+    if (t == 12345.678f) cand_cnt[0] = 1;
+    return;
+  }
+  // ---- epilogue: keep d2~ <= thr + eps_mult * eps(q) -----------------------------------------------------------
+  // Per-row quantities are staged ONCE per workgroup in LDS (free after the last barrier).  Pass 1 screens every
+  // accumulator element with one fma + compare against a conservative per-row bound, re-tests the (rare) hits
+  // exactly, records them in a per-lane bitmap and counts them per row in LDS (non-returning adds); ONE global
+  // atomic per row and workgroup then reserves a slot range; pass 2 walks the bitmap and writes the survivors at
+  // range + LDS ticket.  (One returning global atomic per survivor parked the wave for ~1.5 us each.)  The list
+  // order is arbitrary: every consumer ranks or sorts it.
+  float* rq2 = reinterpret_cast<float*>(lds);                // [BM] ||q||^2
+  float* rlim = rq2 + BM;                                     // [BM] exact limit
+  float* rtau = rlim + BM;                                    // [BM] screening bound on the raw accumulator (minus slack)
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(rtau + BM);    // [BM] survivors of this tile per query row
+  uint32_t* gbase = lcnt + BM;                                // [BM] first slot reserved in the global list
+  const float half_scale = 0.5f / inv_scale;
+  const float rmax_hs = rn_max * half_scale;
+  for (int j = tid; j < BM; j += 64 * NW) {
+    const int64_t row = m0 + j;
+    float q2 = 0.f, lim = -INFINITY, tau = INFINITY;
+    if (row < M) {
+      q2 = qn[row];
+      lim = thr[row * thr_ld] + eps_mult * c_eps * sqrtf(q2 * rn_max);
+      // v <= lim  <=>  acc >= ((q2 - lim) + cn) * half_scale; the slack (relative 2^-17 of the largest possible
+      // magnitude) makes rounding of this shortcut only ever ADD candidates
+      const float base = (q2 - lim) * half_scale;
+      tau = base - 7.7e-6f * (fabsf(base) + rmax_hs);
+    }
+    rq2[j] = q2;
+    rlim[j] = lim;
+    rtau[j] = tau;
+    lcnt[j] = 0;
+  }
+  float cnh[TN], cn[TN];
   int64_t col[TN];
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
     col[nt] = n0 + wn * (32 * TN) + nt * 32 + i;
-    cn[nt] = (col[nt] < N) ? rn[col[nt] * b_stride] : 0.f;
+    cn[nt] = (col[nt] < N) ? rn[col[nt] * b_stride] : INFINITY;  // +inf: columns beyond N never pass
+    cnh[nt] = cn[nt] * half_scale;
   }
-  const float half_scale = 0.5f / inv_scale;
+  __syncthreads();
+  uint32_t bm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int mt = 0; mt < TM; ++mt) {
+  for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t row = m0 + wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-      if (row >= M) continue;
-      const float q2 = qn[row];
-      const float lim = thr[row * thr_ld] + eps_mult * c_eps * sqrtf(q2 * rn_max);
-      // v <= lim  <=>  acc >= (q2 + cn - lim) / 2 / inv_scale; widened by a relative 2^-18 so that rounding
-      // of this shortcut can only ADD candidates
-      const float base = (q2 - lim) * half_scale;
+      const int lrow = wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      const float tau = rtau[lrow];
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
-        const float tau = fmaf(cn[nt], half_scale, base);
-        if (acc[mt][nt][r] >= tau - fabsf(tau) * 3.8e-6f && col[nt] < N) {
-          const float v = sv_d2(q2, cn[nt], acc[mt][nt][r] * inv_scale);
-          if (v <= lim) {
-            const uint32_t slot = atomicAdd(&cand_cnt[row], 1u);
+        if (acc[mt][nt][r] >= tau + cnh[nt]) {
+          if (sv_d2(rq2[lrow], cn[nt], acc[mt][nt][r] * inv_scale) <= rlim[lrow]) {
+            const int e = (mt * TN + nt) * 16 + r;
+            bm[e >> 5] |= 1u << (e & 31);
+            atomicAdd(&lcnt[lrow], 1u);
+          }
+        }
+      }
+    }
+  __syncthreads();
+  for (int j = tid; j < BM; j += 64 * NW) {
+    const uint32_t c = lcnt[j];
+    gbase[j] = (c > 0 && m0 + j < M) ? atomicAdd(&cand_cnt[m0 + j], c) : 0u;
+    lcnt[j] = 0;
+  }
+  __syncthreads();
+  if ((bm[0] | bm[1] | bm[2] | bm[3]) != 0u) {
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const int e = (mt * TN + nt) * 16 + r;
+          if ((bm[e >> 5] >> (e & 31)) & 1u) {
+            const uint32_t slot = gbase[lrow] + atomicAdd(&lcnt[lrow], 1u);
             if (slot < (uint32_t)cap) {
-              cand_d2[row * cap + slot] = v;
+              const int64_t row = m0 + lrow;
+              cand_d2[row * cap + slot] = sv_d2(rq2[lrow], cn[nt], acc[mt][nt][r] * inv_scale);
               cand_id[row * cap + slot] = (uint32_t)(col[nt] * b_stride);
             }
           }
         }
       }
-    }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -512,8 +593,9 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (n_sample + BN - 1) / BN;
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
-  const size_t lds = 2 * (size_t)BM * 128 + 3 * (size_t)BN * 128;  // two A stages + three B stages
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN>;
+  size_t lds = 2 * (size_t)BM * HBK * 2 + (size_t)NB * BN * HBK * 2;  // two A stages + NB B stages
+  if (lds < (size_t)BM * 20) lds = (size_t)BM * 20;                   // epilogue scratch
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL>;
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -526,13 +608,20 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,
                          float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap) {
   if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
-  const char* force = getenv("SEGVLAD_FILTER_TILE");
-  const bool big = force ? (atoi(force) == 256) : (M > 128);
-  if (big)
-    return launch_f16_filter<256, 256, 4, 2>(ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps,
-                                             rn_max, cand_cnt, cand_d2, cand_id, cap);
-  return launch_f16_filter<128, 128, 2, 2>(ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps,
-                                           rn_max, cand_cnt, cand_d2, cand_id, cap);
+#define SV_F16_ARGS ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap
+  const char* cfg = getenv("SEGVLAD_F16_CFG");  // tuning knob (default chosen from measurements)
+  const int c = cfg ? atoi(cfg) : (M > 128 ? 1 : 3);
+  switch (c) {
+    case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
+    case 10: return launch_f16_filter<256, 256, 4, 2, 64, 3, 1>(SV_F16_ARGS);  // ablations of config 0 (WRONG results)
+    case 20: return launch_f16_filter<256, 256, 4, 2, 64, 3, 2>(SV_F16_ARGS);
+    case 30: return launch_f16_filter<256, 256, 4, 2, 64, 3, 3>(SV_F16_ARGS);
+    case 1: return launch_f16_filter<256, 256, 4, 2, 32, 2>(SV_F16_ARGS);  //  64 KiB LDS, 2 workgroups / CU
+    case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
+    case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB
+    default: return launch_f16_filter<128, 128, 2, 2, 32, 2>(SV_F16_ARGS); //  32 KiB
+  }
+#undef SV_F16_ARGS
 }
 
 // ---- candidate handling ----------------------------------------------------------------------------------
