@@ -124,7 +124,8 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_colmask, &ctx->s_gscale, &ctx->s_segimg, &ctx->s_segoff, &ctx->s_adjoff,  &ctx->s_dist,
                     &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff, &ctx->s_cand_cnt, &ctx->s_cand_d2,
                     &ctx->s_cand_id, &ctx->s_thr_d2, &ctx->s_thr_idx, &ctx->s_flag,   &ctx->s_qh,     &ctx->s_ql,
-                    &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo,    &ctx->db_f16,   &ctx->s_qf16};
+                    &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo,    &ctx->db_f16,   &ctx->s_qf16,
+                    &ctx->pca_w1,    &ctx->pca_w2,   &ctx->s_xh1,     &ctx->s_xh2};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -432,6 +433,22 @@ int segvlad_pca_set(segvlad_ctx* ctx, const float* mean, const float* comps, con
   ctx->P = P;
   ctx->KD = KD;
   ctx->whiten = whiten;
+  ctx->pca_w_scale = 0.f;
+  if (KD % 32 == 0) {  // fp16 two-term split of the components for the 16-bit MFMA projection
+    float wmax = 0.f, mmax = 0.f;
+    SV_TRY(sv_maxabs(ctx, ctx->pca_comps.as<float>(), (int64_t)P * KD, &wmax));
+    SV_TRY(sv_maxabs(ctx, ctx->pca_mean.as<float>(), KD, &mmax));
+    if (wmax > 0.f && std::isfinite(wmax)) {
+      int e;
+      frexpf(wmax, &e);
+      ctx->pca_w_scale = ldexpf(1.f, 14 - e);
+      ctx->pca_mean_maxabs = mmax;
+      SV_HIP(ctx->pca_w1.reserve((size_t)P * KD * 2));
+      SV_HIP(ctx->pca_w2.reserve((size_t)P * KD * 2));
+      SV_TRY(sv_launch_split_f16x2(ctx, ctx->pca_comps.as<float>(), P, KD, nullptr, ctx->pca_w_scale, ctx->pca_w1.as<uint16_t>(),
+                                   ctx->pca_w2.as<uint16_t>()));
+    }
+  }
   SV_HIP(hipStreamSynchronize(ctx->stream));
   return sv_finish(ctx);
 }
@@ -446,11 +463,34 @@ int segvlad_pca_apply(segvlad_ctx* ctx, const float* X, int n, float* Y, int l2n
   void* dy;
   SV_TRY(sv_in(ctx, X, (size_t)n * ctx->KD * sizeof(float), &dx));
   SV_TRY(sv_out(ctx, Y, (size_t)n * ctx->P * sizeof(float), &dy));
+  const bool x3 = ctx->pca_w_scale > 0.f && getenv("SEGVLAD_PCA_FP32") == nullptr;
+  float xscale = 1.f;
+  if (x3) {  // scale so that |x - mean| * s < 2^15: no fp16 overflow, sub-normal losses far below fp32 epsilon
+    float xmax = 0.f;
+    SV_TRY(sv_maxabs(ctx, (const float*)dx, (int64_t)n * ctx->KD, &xmax));
+    const float bound = xmax + ctx->pca_mean_maxabs;
+    if (bound > 0.f && std::isfinite(bound)) {
+      int e;
+      frexpf(bound, &e);
+      xscale = ldexpf(1.f, 14 - e);
+    }
+    SV_HIP(ctx->s_xh1.reserve((size_t)n * ctx->KD * 2));
+    SV_HIP(ctx->s_xh2.reserve((size_t)n * ctx->KD * 2));
+  }
   {
     StageScope sc(ctx, "pca");
-    SV_TRY(sv_launch_gemm_nt(ctx, 0, (const float*)dx, ctx->pca_comps.as<float>(), (float*)dy, n, ctx->P, ctx->KD, ctx->P,
-                             ctx->pca_mean.as<float>(), ctx->pca_scale.as<float>(), nullptr, nullptr));
-    sc.count();
+    if (x3) {
+      SV_TRY(sv_launch_split_f16x2(ctx, (const float*)dx, n, ctx->KD, ctx->pca_mean.as<float>(), xscale, ctx->s_xh1.as<uint16_t>(),
+                                   ctx->s_xh2.as<uint16_t>()));
+      SV_TRY(sv_launch_gemm_f16x3(ctx, ctx->s_xh1.as<uint16_t>(), ctx->s_xh2.as<uint16_t>(), ctx->pca_w1.as<uint16_t>(),
+                                  ctx->pca_w2.as<uint16_t>(), n, ctx->P, ctx->KD, 1.f / (xscale * ctx->pca_w_scale),
+                                  ctx->pca_scale.as<float>(), (float*)dy));
+      sc.count(3);
+    } else {
+      SV_TRY(sv_launch_gemm_nt(ctx, 0, (const float*)dx, ctx->pca_comps.as<float>(), (float*)dy, n, ctx->P, ctx->KD, ctx->P,
+                               ctx->pca_mean.as<float>(), ctx->pca_scale.as<float>(), nullptr, nullptr));
+      sc.count();
+    }
     if (l2norm) {
       SV_TRY(sv_launch_normalize_rows(ctx, (const float*)dy, n, ctx->P, (float*)dy));
       sc.count();

@@ -83,6 +83,8 @@ struct segvlad_ctx {
   // PCA model
   int P = 0, KD = 0, whiten = 0;
   DevBuf pca_mean, pca_comps, pca_scale;  // scale = 1/sqrt(var) or 1
+  DevBuf pca_w1, pca_w2;                  // fp16 two-term split of comps * pca_w_scale (16-bit MFMA path)
+  float pca_w_scale = 0.f, pca_mean_maxabs = 0.f;
 
   // database (exact kNN)
   int db_d = 0;
@@ -102,7 +104,7 @@ struct segvlad_ctx {
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16;
+      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -181,6 +183,11 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);
+// gemm_f16x3_kernels.hip
+int sv_launch_split_f16x2(segvlad_ctx* ctx, const float* X, int64_t n_rows, int d, const float* sub, float scale, uint16_t* h1,
+                          uint16_t* h2);
+int sv_launch_gemm_f16x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, const uint16_t* B1, const uint16_t* B2, int M,
+                         int N, int Kd, float out_scale, const float* col_scale, float* C);
 int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out);
 int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,

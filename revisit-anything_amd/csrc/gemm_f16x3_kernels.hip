@@ -1,0 +1,248 @@
+// PCA projection on the 16-bit matrix pipe with fp32-class accuracy (gfx950).
+//
+// fp32 MFMA runs at 1/16 of the fp16 rate.  Each fp32 operand is scaled by a power of two and split into TWO
+// fp16 values, x*s = h1 + h2 + e with |e| <= 2^-22 |x*s| (two 11-bit significands), and the product is
+// accumulated as h2.g1 + h1.g2 + h1.g1 on v_mfma_f32_32x32x16_f16 (fp16 x fp16 products are exact in fp32, the
+// accumulator is fp32).  The dropped terms are <= 3*2^-22 ||a|| ||b||: BELOW the fp32 chain's own accumulation
+// error for K = 98304 (sqrt(K) 2^-24 typical), i.e. the result is at least as accurate as the fp32-MFMA GEMM it
+// replaces, at 3/16 of the matrix-pipe time.  (The kNN filter can afford a single product because it only needs
+// a rigorous bound; here the value itself is the output, hence the two-term split.)
+//
+//   split_f16x2_kernel   (X - sub) * scale -> h1, h2 planes (sub = PCA mean on the A side, none on the W side)
+//   gemm_f16x3_kernel    C = (A1+A2).(B1+B2)^T * col_scale: BM x BN x 32 tiles, global->LDS DMA with source-side
+//                        swizzle (see knn_bf16_kernels.hip), two stages per operand, optional split-K
+#include <stdlib.h>
+
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ X, int64_t n_rows, int d,
+                                                          const float* __restrict__ sub, float scale,
+                                                          _Float16* __restrict__ h1, _Float16* __restrict__ h2) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int64_t n4 = n_rows * (int64_t)(d >> 2);
+  const int d4 = d >> 2;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(X)[j];
+    if (sub) {
+      const float4 s = reinterpret_cast<const float4*>(sub)[j % d4];
+      v.x -= s.x;
+      v.y -= s.y;
+      v.z -= s.z;
+      v.w -= s.w;
+    }
+    const float f[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+    h4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = (_Float16)f[e];
+      b[e] = (_Float16)(f[e] - (float)a[e]);
+    }
+    reinterpret_cast<h4*>(h1)[j] = a;
+    reinterpret_cast<h4*>(h2)[j] = b;
+  }
+}
+
+int sv_launch_split_f16x2(segvlad_ctx* ctx, const float* X, int64_t n_rows, int d, const float* sub, float scale, uint16_t* h1,
+                          uint16_t* h2) {
+  if (n_rows <= 0) return SEGVLAD_OK;
+  int64_t blocks = (n_rows * (d / 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n_rows, d, sub, scale,
+                     reinterpret_cast<_Float16*>(h1), reinterpret_cast<_Float16*>(h2));
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+template <int N_>
+__device__ __forceinline__ void wait_vm_lgkm0_() {
+  if (N_ == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if (N_ == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+  else if (N_ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+}
+
+// C[M][N] (+ split-K partials) = sum_k (A1+A2)[m][k] (B1+B2)[n][k], k in this block's slice.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t* __restrict__ A1,
+                                                                  const uint16_t* __restrict__ A2,
+                                                                  const uint16_t* __restrict__ B1,
+                                                                  const uint16_t* __restrict__ B2, int M, int N, int Kd,
+                                                                  int tiles_m, int k_per_split, float out_scale,
+                                                                  const float* __restrict__ col_scale,
+                                                                  float* __restrict__ C, int64_t ldc) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int HBK = 32, RB = 64, RP = 16;           // 64-B rows per plane and k-tile, 16 rows per 1-KiB DMA piece
+  constexpr int PA = BM * RB, PB = BN * RB;            // one plane
+  constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and PLANE
+  static_assert(JA * RP * NW == BM && JB * RP * NW == BN, "tile/wave geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tile = blockIdx.x;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / WN, wn = w % WN;
+  const int kbeg = (int)blockIdx.y * k_per_split;
+  const int kend = (kbeg + k_per_split < Kd) ? kbeg + k_per_split : Kd;
+  const int ntiles = (kend - kbeg) / HBK;
+  auto swz = [](int r, int c) { return c ^ ((r >> 2) & 3); };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lrow_p = l >> 2, lch = l & 3;
+  int64_t offA[JA], offB[JB];  // element offsets of this lane's 16-B chunk inside a plane (without k)
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int row = (w * JA + j) * RP + lrow_p;
+    const int64_t ra = (m0 + row < M) ? (m0 + row) : (int64_t)(M - 1);
+    offA[j] = ra * Kd + kbeg + 8 * swz(row, lch);
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int row = (w * JB + j) * RP + lrow_p;
+    const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
+    offB[j] = rb * Kd + kbeg + 8 * swz(row, lch);
+  }
+  // LDS: stage s = [A1 | A2 | B1 | B2], two stages
+  constexpr int STAGE = 2 * PA + 2 * PB;
+  auto dma_tile = [&](int kt, int buf) {
+    unsigned char* S = lds + buf * STAGE;
+    const int k0 = kt * HBK;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(A1 + offA[j] + k0), (lptr_t)(S + (w * JA + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(A2 + offA[j] + k0), (lptr_t)(S + PA + (w * JA + j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(B1 + offB[j] + k0), (lptr_t)(S + 2 * PA + (w * JB + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(B2 + offB[j] + k0), (lptr_t)(S + 2 * PA + PB + (w * JB + j) * 1024), 16, 0, 0);
+    }
+  };
+  dma_tile(0, 0);
+  wait_vm_lgkm0_<0>();
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (kt + 1 < ntiles) dma_tile(kt + 1, cur ^ 1);  // lands while tile kt is multiplied
+    const unsigned char* S = lds + cur * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cl = 2 * ks + kk;
+      f16x8 a1[TM], a2[TM], b1[TN], b2[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int ra = fa0 + 32 * t;
+        a1[t] = *reinterpret_cast<const f16x8*>(S + ra * RB + swz(ra, cl) * 16);
+        a2[t] = *reinterpret_cast<const f16x8*>(S + PA + ra * RB + swz(ra, cl) * 16);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int rb = fb0 + 32 * t;
+        b1[t] = *reinterpret_cast<const f16x8*>(S + 2 * PA + rb * RB + swz(rb, cl) * 16);
+        b2[t] = *reinterpret_cast<const f16x8*>(S + 2 * PA + PB + rb * RB + swz(rb, cl) * 16);
+      }
+      // small terms first; the TM*TN accumulators are independent, so consecutive MFMAs never wait on each other
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a2[mt], b1[nt], acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a1[mt], b2[nt], acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a1[mt], b1[nt], acc[mt][nt]);
+    }
+    wait_vm_lgkm0_<0>();
+    __builtin_amdgcn_s_barrier();
+    cur ^= 1;
+  }
+
+  if (gridDim.y > 1) C += (int64_t)blockIdx.y * M * ldc;
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    const int64_t col = n0 + wn * (32 * TN) + nt * 32 + i;
+    if (col >= N) continue;
+    const float cs = (gridDim.y > 1) ? 1.f : out_scale * (col_scale ? col_scale[col] : 1.f);
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row < M) C[row * ldc + col] = acc[mt][nt][r] * cs;
+      }
+  }
+}
+
+// out = (sum_s part[s]) * out_scale * col_scale, slices added in index order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_scale_kernel(const float* __restrict__ part, int splits, int64_t mn,
+                                                                  int N, float out_scale,
+                                                                  const float* __restrict__ col_scale,
+                                                                  float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= mn) return;
+  float s = part[j];
+  for (int t = 1; t < splits; ++t) s += part[(int64_t)t * mn + j];
+  const int col = (int)(j % N);
+  out[j] = s * out_scale * (col_scale ? col_scale[col] : 1.f);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, const uint16_t* B1, const uint16_t* B2, int M,
+                     int N, int Kd, float out_scale, const float* col_scale, float* C) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  // split-K so that >= ~2 waves of workgroups fill the chip evenly
+  const int slots = 256 * ((BM == 256) ? 1 : 2);
+  int splits = (int)((4 * slots + tiles - 1) / tiles);
+  if (splits > 32) splits = 32;
+  if (splits < 1) splits = 1;
+  int k_per_split = (((Kd + splits - 1) / splits) + 31) / 32 * 32;
+  splits = (Kd + k_per_split - 1) / k_per_split;
+  float* dst = C;
+  if (splits > 1) {
+    SV_HIP(ctx->s_dist.reserve((size_t)splits * M * N * sizeof(float)));
+    dst = ctx->s_dist.as<float>();
+  }
+  const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
+  auto kern = gemm_f16x3_kernel<BM, BN, WM, WN>;
+  if (lds > 64 * 1024)
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(64 * WM * WN), lds, ctx->stream, A1, A2, B1, B2, M, N, Kd,
+                     tiles_m, k_per_split, out_scale, col_scale, dst, (int64_t)N);
+  SV_HIP(hipGetLastError());
+  if (splits > 1) {
+    const int64_t mn = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_scale_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, ctx->stream, dst, splits, mn,
+                       N, out_scale, col_scale, C);
+    SV_HIP(hipGetLastError());
+  }
+  return SEGVLAD_OK;
+}
+
+// C[M][N] = ((A1+A2) . (B1+B2)^T) * out_scale * col_scale[n]; Kd % 32 == 0
+int sv_launch_gemm_f16x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, const uint16_t* B1, const uint16_t* B2, int M,
+                         int N, int Kd, float out_scale, const float* col_scale, float* C) {
+  if (M <= 0 || N <= 0) return SEGVLAD_OK;
+  const char* cfg = getenv("SEGVLAD_X3_TILE");
+  const bool big = cfg ? (atoi(cfg) == 256) : (M >= 1024);  // 256x256 tiles: 8.1 vs 12.6 ms at 10000 x 98304 x 1024
+  if (big) return launch_x3<256, 256, 4, 2>(ctx, A1, A2, B1, B2, M, N, Kd, out_scale, col_scale, C);
+  return launch_x3<128, 128, 2, 2>(ctx, A1, A2, B1, B2, M, N, Kd, out_scale, col_scale, C);
+}

@@ -525,3 +525,27 @@ def test_incidence_centroids_fused_equals_separate(eng):
     bits, cent = eng.incidence_centroids(masks, 126, 150)
     assert np.array_equal(O().unpack_bits_u64(bits.cpu().numpy().view(np.uint64), 90), O().incidence(masks != 0, 126, 150))
     assert np.array_equal(cent.cpu().numpy(), O().mask_centroids([m for m in masks]))
+
+
+def test_pca_f16_split_path_is_fp32_class(eng):
+    """The projection runs as three fp16 MFMA products of a two-term split.  It must be at least as close to the
+    fp64 oracle as the all-fp32 MFMA GEMM (SEGVLAD_PCA_FP32=1) on descriptor-like data with a wide dynamic range."""
+    rng = np.random.Generator(np.random.PCG64(400))
+    KD, P, n = 64 * 256, 96, 300
+    mean, comps, var = synth().make_pca_model(KD, P, seed=6)
+    X = rng.standard_normal((n, KD)).astype(np.float32)
+    X[:, ::7] *= 1e-4                                   # tiny components next to large ones
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    eng.pca_set(mean, comps, var, whiten=True)
+    ref = O().pca_transform(X, mean, comps, var, True)
+    y16 = eng.pca_apply(X).cpu().numpy()
+    os.environ["SEGVLAD_PCA_FP32"] = "1"
+    try:
+        y32 = eng.pca_apply(X).cpu().numpy()
+    finally:
+        del os.environ["SEGVLAD_PCA_FP32"]
+    e16 = np.abs(y16 - ref).max() / np.abs(ref).max()
+    e32 = np.abs(y32 - ref).max() / np.abs(ref).max()
+    assert e16 < 2e-5 and e16 < 4 * e32 + 1e-6, (e16, e32)
+    cos = (y16 * ref).sum(1) / (np.linalg.norm(y16, axis=1) * np.linalg.norm(ref, axis=1))
+    assert (1 - cos).max() < 5e-7   # fp32 outputs: the cosine itself is only resolved to ~1e-7
