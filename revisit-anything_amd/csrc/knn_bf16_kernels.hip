@@ -610,7 +610,7 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
 #define SV_F16_ARGS ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap
   const char* cfg = getenv("SEGVLAD_F16_CFG");  // tuning knob (default chosen from measurements)
-  const int c = cfg ? atoi(cfg) : (M > 128 ? 1 : 3);
+  const int c = cfg ? atoi(cfg) : (M > 128 ? 0 : 3);
   switch (c) {
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
     case 10: return launch_f16_filter<256, 256, 4, 2, 64, 3, 1>(SV_F16_ARGS);  // ablations of config 0 (WRONG results)
