@@ -49,6 +49,30 @@ def eng_filter_products() -> int:
     return 1 if os.environ.get("SEGVLAD_KNN_FILTER", "f16") == "f16" else 3
 
 
+def eng_pca_products(kd: int, p_dim: int) -> int:
+    """MFMA products of the PCA projection per algorithmic fp32 multiply-add: the default is three fp16 products of a
+    two-term split (hi.hi + hi.lo + lo.hi); SEGVLAD_PCA_FP32=1 selects the single fp32 MFMA GEMM."""
+    return 1 if (os.environ.get("SEGVLAD_PCA_FP32") or kd % 64 or p_dim % 64) else 3
+
+
+def pmc_traffic(kernel_prefix: str, workload_key: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    produced by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this workload); None when no
+    summary for exactly this workload is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("workload_key") != workload_key:
+            continue
+        for k in j.get("kernels", []):
+            if k["name"].startswith(kernel_prefix):
+                return k["hbm_bytes_per_launch"]
+    return None
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -70,6 +94,8 @@ def parse():
                    "--same-device lets several ranks share ONE GPU to exercise the N>1 code path on a 1-GPU box")
     p.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
     p.add_argument("--dump-preds", default=None, help="debug: rank 0 writes the last step's predictions to this .npy")
+    p.add_argument("--pmc-calibrate", action="store_true", help="after the run, map a 1 GiB tensor through torch.sign once (a known 1 GiB read + "
+                   "1 GiB write) so that tools/pmc_summary.py can calibrate FETCH_SIZE / WRITE_SIZE from the same rocprofv3 pass")
     p.add_argument("--debug-timing", action="store_true", help="after the timed region, print a synchronised per-phase wall-clock breakdown of one step to stderr")
     return p.parse_args()
 
@@ -291,7 +317,9 @@ def main():
                     "epilogue; exact fp32 refinement of the survivors)")
         else:
             flops_step = 2.0 * nq_local * S * (K * D) * P              # 2 * S * K*D * P per image
-            kern = "gemm_nt_kernel<0> (PCA projection, fused mean-subtract + whitening scale)"
+            kern = ("gemm_f16x3_kernel (PCA projection as 3 fp16 MFMA products of a two-term split, fused mean-subtract + "
+                    "whitening scale)" if eng_pca_products(K * D, P) == 3 else
+                    "gemm_nt_kernel<0> (PCA projection, fp32 MFMA, fused mean-subtract + whitening scale)")
         launches = stages[key]["launches_per_step"]
         avg_ms = stages[key]["ms_per_step"] / max(launches, 1)
         f32_equiv = flops_step / (stages[key]["ms_per_step"] * 1e-3) / 1e12
@@ -299,10 +327,13 @@ def main():
             # the filter GEMM runs on the 16-bit MFMA pipe: PRODUCTS_PER_FMA MFMA products per algorithmic fp32 fma
             prods = eng_filter_products()
             ach, peak, unit_note = f32_equiv * prods, PEAK_16BIT_MFMA_TFLOPS, f"{prods} x 16-bit MFMA product(s) per fp32 fma"
+        elif eng_pca_products(K * D, P) == 3:
+            ach, peak, unit_note = f32_equiv * 3, PEAK_16BIT_MFMA_TFLOPS, "3 x fp16 MFMA products per fp32 fma"
         else:
             ach, peak, unit_note = f32_equiv, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA"
+        wl_key = f"q{nQ}x{S}_db{nR * S}_d{d_knn}_k{K}_w{world}"
         roof = {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches, "dominant_stage": dom,
+                "traffic": pmc_traffic(kern.split(" ")[0], wl_key), "avg_launch_ms": avg_ms, "launches_per_step": launches, "dominant_stage": dom,
                 "arithmetic": unit_note, "fp32_equivalent_tflops": f32_equiv,
                 "fp32_equivalent_vs_fp32_mfma_peak": f32_equiv / PEAK_F32_MFMA_TFLOPS}
     elif dom is not None:
@@ -319,6 +350,32 @@ def main():
     if vlad_roof["achieved"]:
         vlad_roof["frac"] = vlad_roof["achieved"] / PEAK_HBM_GBS
 
+    # secondary: the kNN stage in its HBM-bound regime (B_q <= 50, i.e. ONE query image per pass)
+    stream_roof = None
+    if use_pca and world == 1 and n_local_rows > 0:
+        qd1 = pipe.describe(q_tok[:1], q_msk[:S], np.array([0, S], dtype=np.int32))
+        for _ in range(3):
+            eng.search(qd1, 200)
+        torch.cuda.synchronize()
+        eng.set_profiling(True)
+        eng.profile_reset()
+        reps = 20
+        for _ in range(reps):
+            eng.search(qd1, 200)
+        torch.cuda.synchronize()
+        g_ms = eng.stage_ms("knn_gemm")[0] / reps
+        s_ms = eng.stage_ms("knn_select")[0] / reps
+        eng.set_profiling(False)
+        alg = 4.0 * n_local_rows * d_knn + 4.0 * S * d_knn + 8.0 * S * 200     # fp32 DB rows read once
+        moved = alg / 2 if eng_filter_products() == 1 else alg                  # the fp16 filter streams a 2-byte plane
+        stream_roof = {"bound": "hbm", "B_q": S, "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                       "achieved": alg / (g_ms * 1e-3) / 1e9, "frac": alg / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       "bytes_actually_streamed_gbs": moved / (g_ms * 1e-3) / 1e9,
+                       "frac_of_bytes_actually_streamed": moved / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       "filter_ms": g_ms, "select_refine_ms": s_ms,
+                       "note": "one 50-segment query image per pass over the whole shard; 'achieved' uses SURVEY 8d's fp32 "
+                               "algorithmic bytes, the fp16 filter moves half of them"}
+
     res = {
         "metric": "query_images_per_sec", "value": nQ * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -329,7 +386,7 @@ def main():
                    "tokens": N, "pca_dim": P if use_pca else None, "order": a.order, "parallelism": f"db-row-shard x{world}"},
         "recall_at_1": recalls[0], "recall_at_5": recalls[4], "db_build_s": t_build,
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in stages.items()},
-        "roofline": roof, "roofline_vlad": vlad_roof,
+        "roofline": roof, "roofline_vlad": vlad_roof, "roofline_knn_stream": stream_roof,
     }
 
     if world == 1 and not a.no_cpu_baseline:
@@ -337,6 +394,12 @@ def main():
     else:
         res["cpu_baseline"] = None
     print(json.dumps(res))
+    if a.pmc_calibrate:
+        cal = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        torch.cuda.synchronize()
+        cal2 = cal.sign()    # elementwise kernel ("sign_kernel"): 2^30 B read, 2^30 B written
+        torch.cuda.synchronize()
+        del cal, cal2
     if world > 1:
         dist.destroy_process_group()
 

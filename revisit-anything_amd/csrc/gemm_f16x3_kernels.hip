@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
                                                                   const uint16_t* __restrict__ A2,
                                                                   const uint16_t* __restrict__ B1,
                                                                   const uint16_t* __restrict__ B2, int M, int N, int Kd,
-                                                                  int tiles_m, int k_per_split, float out_scale,
+                                                                  int tiles_m, int gm, int n_splits, int k_per_split, float out_scale,
                                                                   const float* __restrict__ col_scale,
                                                                   float* __restrict__ C, int64_t ldc) {
   constexpr int NW = WM * WN;
@@ -83,13 +83,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
   constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and PLANE
   static_assert(JA * RP * NW == BM && JB * RP * NW == BN, "tile/wave geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tile = blockIdx.x;
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  // XCD-aware order (see knn_f16_filter_kernel): the 32 workgroups one XCD runs side by side are a gm x (32/gm) block
+  // of output tiles of ONE k-split, sharing their A and B slices in that XCD's L2
+  int tm, tn, split;
+  if (gm > 0) {
+    const int b = blockIdx.x, xcd = b & 7, s = b >> 3, within = s & 31, u = (s >> 5) * 8 + xcd;
+    const int gn = 32 / gm, sm_cnt = (tiles_m + gm - 1) / gm, tiles_n = (N + BN - 1) / BN;
+    split = u % n_splits;
+    const int r = u / n_splits;
+    tm = (r % sm_cnt) * gm + within % gm;
+    tn = (r / sm_cnt) * gn + within / gm;
+    if (tm >= tiles_m || tn >= tiles_n) return;
+  } else {
+    tm = blockIdx.x % tiles_m;
+    tn = blockIdx.x / tiles_m;
+    split = blockIdx.y;
+  }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / WN, wn = w % WN;
-  const int kbeg = (int)blockIdx.y * k_per_split;
+  const int kbeg = split * k_per_split;
   const int kend = (kbeg + k_per_split < Kd) ? kbeg + k_per_split : Kd;
   const int ntiles = (kend - kbeg) / HBK;
   auto swz = [](int r, int c) { return c ^ ((r >> 2) & 3); };
@@ -175,12 +189,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
     cur ^= 1;
   }
 
-  if (gridDim.y > 1) C += (int64_t)blockIdx.y * M * ldc;
+  if (n_splits > 1) C += (int64_t)split * M * ldc;
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
     const int64_t col = n0 + wn * (32 * TN) + nt * 32 + i;
     if (col >= N) continue;
-    const float cs = (gridDim.y > 1) ? 1.f : out_scale * (col_scale ? col_scale[col] : 1.f);
+    const float cs = (n_splits > 1) ? 1.f : out_scale * (col_scale ? col_scale[col] : 1.f);
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -225,8 +239,19 @@ static int launch_x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, c
   auto kern = gemm_f16x3_kernel<BM, BN, WM, WN>;
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(64 * WM * WN), lds, ctx->stream, A1, A2, B1, B2, M, N, Kd,
-                     tiles_m, k_per_split, out_scale, col_scale, dst, (int64_t)N);
+  const char* gme = getenv("SEGVLAD_X3_GM");  // tile-block height of the XCD-aware order (0 = plain order, k-split in grid.y)
+  int gm = gme ? atoi(gme) : 8;
+  dim3 grid((unsigned)tiles, (unsigned)splits);
+  if (gm > 0) {
+    gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
+    while (gm < 32 && 32 / gm > tiles_n) gm <<= 1;   // no wider than the output
+    while (gm > 1 && gm / 2 >= tiles_m) gm >>= 1;
+    const int gn = 32 / gm;
+    const int64_t units = (int64_t)((tiles_m + gm - 1) / gm) * ((tiles_n + gn - 1) / gn) * splits;
+    grid = dim3((unsigned)((units + 7) / 8 * 8 * 32), 1);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, ctx->stream, A1, A2, B1, B2, M, N, Kd, tiles_m, gm, splits, k_per_split,
+                     out_scale, col_scale, dst, (int64_t)N);
   SV_HIP(hipGetLastError());
   if (splits > 1) {
     const int64_t mn = (int64_t)M * N;

@@ -362,7 +362,7 @@ __device__ __forceinline__ void wait_vm_lgkm0() {  // s_waitcnt needs a literal 
 //   rows stream from HBM/MALL; NB = 3 keeps their DMA two k-tiles ahead via a counted vmcnt).
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
-    const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m,
+    const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     float inv_scale, const float* __restrict__ qn, const float* __restrict__ rn, const float* __restrict__ thr,
     int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* __restrict__ cand_cnt,
     float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap) {
@@ -375,10 +375,22 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   constexpr int PA = BM * RB, PB = BN * RB;
   constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and operand
   static_assert(JA * RP * NW == BM && JB * RP * NW == BN && (JA + JB) % KS == 0, "tile/wave geometry");
-  static_assert(TM * TN * 16 <= 128, "survivor bitmap holds 128 accumulator elements per lane");
+  constexpr int BMW = (TM * TN * 16 + 31) / 32;  // survivor bitmap words per lane
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tile = blockIdx.x;
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2); the 32
+  // workgroups an XCD runs side by side form one gm x (32/gm) block of tiles, so that they share their query and
+  // database rows in that L2 while they march over k (tm-fastest order made every XCD fetch every database row).
+  int tm, tn;
+  if (gm > 0) {
+    const int b = blockIdx.x, xcd = b & 7, s = b >> 3, within = s & 31, st = (s >> 5) * 8 + xcd;
+    const int gn = 32 / gm, sm_cnt = (tiles_m + gm - 1) / gm;
+    tm = (st % sm_cnt) * gm + within % gm;
+    tn = (st / sm_cnt) * gn + within / gm;
+    if (tm >= tiles_m || tn >= (N + BN - 1) / BN) return;
+  } else {
+    tm = blockIdx.x % tiles_m;
+    tn = blockIdx.x / tiles_m;
+  }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS DMA bases live in M0
@@ -538,7 +550,9 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     cnh[nt] = cn[nt] * half_scale;
   }
   __syncthreads();
-  uint32_t bm[4] = {0u, 0u, 0u, 0u};
+  uint32_t bm[BMW];
+#pragma unroll
+  for (int t = 0; t < BMW; ++t) bm[t] = 0u;
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -563,7 +577,10 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     lcnt[j] = 0;
   }
   __syncthreads();
-  if ((bm[0] | bm[1] | bm[2] | bm[3]) != 0u) {
+  uint32_t any = 0u;
+#pragma unroll
+  for (int t = 0; t < BMW; ++t) any |= bm[t];
+  if (any != 0u) {
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -591,7 +608,16 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
                              int cap) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (n_sample + BN - 1) / BN;
-  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  int64_t tiles = (int64_t)tiles_m * tiles_n;
+  const char* gme = getenv("SEGVLAD_F16_GM");  // tile-block height of the XCD-aware order (0 = plain tm-fastest order)
+  int gm = gme ? atoi(gme) : 4;
+  if (gm > 0) {
+    gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
+    while (gm > 1 && gm / 2 >= tiles_m) gm >>= 1;
+    const int gn = 32 / gm;
+    const int64_t st = (int64_t)((tiles_m + gm - 1) / gm) * ((tiles_n + gn - 1) / gn);
+    tiles = (st + 7) / 8 * 8 * 32;
+  }
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
   size_t lds = 2 * (size_t)BM * HBK * 2 + (size_t)NB * BN * HBK * 2;  // two A stages + NB B stages
   if (lds < (size_t)BM * 20) lds = (size_t)BM * 20;                   // epilogue scratch
@@ -599,7 +625,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
-                     inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
+                     gm, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -619,6 +645,13 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 1: return launch_f16_filter<256, 256, 4, 2, 32, 2>(SV_F16_ARGS);  //  64 KiB LDS, 2 workgroups / CU
     case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
     case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB
+    case 5: return launch_f16_filter<256, 256, 2, 2, 64, 3>(SV_F16_ARGS);  // 4 waves of 128 x 128: 0.5 LDS fragment / MFMA
+    case 15: return launch_f16_filter<256, 256, 2, 2, 64, 3, 1>(SV_F16_ARGS);
+    case 6: return launch_f16_filter<256, 256, 2, 2, 32, 3>(SV_F16_ARGS);
+    case 7: return launch_f16_filter<256, 128, 4, 1, 32, 3>(SV_F16_ARGS);  // 56 KiB, 4 waves: 2 independent workgroups / CU
+    case 17: return launch_f16_filter<256, 128, 4, 1, 32, 3, 1>(SV_F16_ARGS);
+    case 8: return launch_f16_filter<256, 128, 4, 1, 32, 2>(SV_F16_ARGS);
+    case 9: return launch_f16_filter<128, 256, 2, 2, 32, 3>(SV_F16_ARGS);
     default: return launch_f16_filter<128, 128, 2, 2, 32, 2>(SV_F16_ARGS); //  32 KiB
   }
 #undef SV_F16_ARGS
@@ -753,19 +786,22 @@ int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const fl
 }
 
 // exact distances of the refine list: the sequential fp32 fma chain over k = 0..d-1 (bit-identical to the
-// v_mfma_f32_32x32x2_f32 chain of the matrix path), then (distance, id) sort and top-k
+// v_mfma_f32_32x32x2_f32 chain of the matrix path), then (distance, id) sort and top-k.  QLDS: the query row is cached in
+// LDS (d up to ~38k); raw K*D descriptors (d = 98 304) read it through L1/L2 instead (all lanes read the same address).
+template <bool QLDS>
 __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
                                                            const float* __restrict__ qn, const float* __restrict__ rn,
                                                            const uint32_t* __restrict__ ref_cnt,
                                                            const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
                                                            float* __restrict__ d2_out, int64_t* __restrict__ idx_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* qs = reinterpret_cast<float*>(smem);                          // [d]
-  uint64_t* a = reinterpret_cast<uint64_t*>(smem + (size_t)d * 4);     // [rpad]
+  float* qs = reinterpret_cast<float*>(smem);                                     // [d] when QLDS
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem + (QLDS ? (size_t)d * 4 : 0));   // [rpad]
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   const int n = (int)ref_cnt[row];
-  for (int j = tid; j < d; j += 256) qs[j] = Q[row * d + j];
+  if (QLDS)
+    for (int j = tid; j < d; j += 256) qs[j] = Q[row * d + j];
   for (int j = tid; j < rpad; j += 256) a[j] = ~0ull;
   __syncthreads();
   const float q2 = qn[row];
@@ -775,7 +811,7 @@ __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restri
     float acc = 0.f;
     for (int t = 0; t < (d >> 2); ++t) {
       const float4 rv = rp[t];
-      const float4 qv = reinterpret_cast<const float4*>(qs)[t];
+      const float4 qv = QLDS ? reinterpret_cast<const float4*>(qs)[t] : reinterpret_cast<const float4*>(Q + row * d)[t];
       acc = fmaf(qv.x, rv.x, acc);
       acc = fmaf(qv.y, rv.y, acc);
       acc = fmaf(qv.z, rv.z, acc);
@@ -802,13 +838,18 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
   if (nq <= 0) return SEGVLAD_OK;
   int rpad = 2;
   while (rpad < rcap) rpad <<= 1;
-  const size_t lds = (size_t)d * 4 + (size_t)rpad * 8;
-  if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "refine: d=%d too large for the LDS query cache", d);
-  if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-  hipLaunchKernelGGL(refine_exact_kernel, dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap, rpad, k,
-                     d2_out, idx_out);
+  size_t lds = (size_t)d * 4 + (size_t)rpad * 8;
+  if (lds > 160 * 1024) {
+    lds = (size_t)rpad * 8;
+    hipLaunchKernelGGL(refine_exact_kernel<false>, dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
+                       rpad, k, d2_out, idx_out);
+  } else {
+    if (lds > 64 * 1024)
+      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine_exact_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(refine_exact_kernel<true>, dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
+                       rpad, k, d2_out, idx_out);
+  }
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

@@ -388,6 +388,38 @@ def test_knn_leveled_filter_path_is_exact(eng, d):
     assert np.array_equal(im, idx) and np.array_equal(dm, d2)
 
 
+def test_knn_raw_descriptor_width_refines_without_lds_query_cache(eng):
+    """Raw K*D-wide rows (BASELINE configs[1] searches 98 304-d descriptors without PCA): the query row no longer fits
+    the refinement kernel's LDS cache.  Filtered search over the whole database == matrix-path search over three
+    parts merged, bit for bit.  Rows live on a 32-d subspace so that the fp16 filter margin stays selective."""
+    import torch
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    n, nq, k, d, lat = 40000, 200, 50, 40960, 32
+    B = torch.linalg.qr(torch.randn(d, lat, device=dev, generator=g))[0].T.contiguous()      # [lat, d], orthonormal rows
+    R = torch.nn.functional.normalize(torch.randn(n, lat, device=dev, generator=g), dim=1) @ B
+    Q = torch.nn.functional.normalize(torch.randn(nq, lat, device=dev, generator=g), dim=1) @ B
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = (t.cpu().numpy() for t in eng.search(Q, k))
+    dp, ip = [], []
+    for a, b in [(0, 15000), (15000, 30000), (30000, n)]:
+        eng.db_reset()
+        eng.db_add(R[a:b].contiguous())
+        dd, ii = eng.search(Q, k)
+        dp.append(dd.cpu().numpy())
+        ip.append(ii.cpu().numpy() + a)
+    eng.db_reset()
+    dm, im = O().merge_topk(dp, ip, k)
+    assert np.array_equal(im, idx) and np.array_equal(dm, d2)
+    # and against float64 distances in the latent space (B has orthonormal rows)
+    Rl, Ql = (R @ B.T).double().cpu().numpy(), (Q @ B.T).double().cpu().numpy()
+    rd2, ridx = O().knn_l2(Rl, Ql, k)
+    assert np.abs(d2 - rd2).max() < 1e-4
+    assert (idx == ridx).mean() > 0.98
+
+
 @pytest.mark.parametrize("d", [16, 32])
 def test_knn_filter_overflow_falls_back_to_exact(eng, d):
     """Adversarial layout: every sampled row (id % 16 == 0) is far away, all other rows are near -> the sampled
