@@ -97,6 +97,16 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
                    const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out,
                    float* gap_out, float* block_norms_out);
 
+/* ---- fused segvlad_images + segvlad_pca_apply: the per-batch pair of place_rec_main.py:259-270
+ *      (seg_vlad_gpu_single per image, then apply_pca_transform_from_pkl on the batch) in one call.  The
+ *      aggregation kernel emits the projection GEMM's input planes directly, so the K*D-wide fp32 descriptor is
+ *      neither measured (max |x|), nor re-read, nor -- when desc_out is NULL -- written to HBM at all.
+ *      y [S_tot][P] fp32 (l2norm != 0: rows normalised as normalizeFeat); desc_out [S_tot][K*D] fp32 or NULL;
+ *      other arguments as segvlad_images.  Requires segvlad_set_vocab and segvlad_pca_set (KD == K*D).      */
+int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                       const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
+                       uint8_t* labels_out, float* gap_out);
+
 /* ---- the K-parametric entry: vlad_matmuls_per_cluster(num_c, masks, res, clus_labels, adjMat)
  *      func_vpr.py:1181-1210.  res [N][D] fp32 residuals (token-major, as the reference passes them),
  *      labels [N] u8 (< num_c <= 256), inc_bits [S][ceil(N/64)], adj [S][S] bytes or NULL,

@@ -291,10 +291,10 @@ int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* 
 }
 
 // ---- segment VLAD -----------------------------------------------------------------------------------
-int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
-                   const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out, float* gap_out,
-                   float* block_norms_out) {
-  CHECK_CTX();
+// pca_y != NULL: fused projection (segvlad_images_pca); out may then be NULL
+static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                       const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out, float* gap_out,
+                       float* block_norms_out, float* pca_y, int l2norm) {
   if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images: call segvlad_set_vocab first");
   if (B < 0 || N <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "images: B=%d N=%d", B, N);
   if (B == 0) return SEGVLAD_OK;
@@ -312,15 +312,28 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
     adj_off[b + 1] = adj_off[b] + (int64_t)s * s;
   }
   const int S_tot = seg_offsets[B];
-  if (S_tot > 0 && (!inc_bits || !out)) return ctx->fail(SEGVLAD_ERR_ARG, "images: null inc_bits/out");
+  if (S_tot > 0 && (!inc_bits || (!out && !pca_y))) return ctx->fail(SEGVLAD_ERR_ARG, "images: null inc_bits/out");
   const int SC = S_max > 0 ? (S_max + 63) / 64 : 1;
+  // fused projection: the descriptor entries are <= 1 in magnitude by construction, so the fp16 split scale is known
+  // before the data exists (pca_apply has to measure max|x| first)
+  const bool fused = pca_y != nullptr && S_tot > 0;
+  float xscale = 1.f;
+  void* d_y = nullptr;
+  if (fused) {
+    int e;
+    frexpf(1.f + ctx->pca_mean_maxabs, &e);
+    xscale = ldexpf(1.f, 14 - e);
+    SV_HIP(ctx->s_xh1.reserve((size_t)S_tot * ctx->KD * 2));
+    SV_HIP(ctx->s_xh2.reserve((size_t)S_tot * ctx->KD * 2));
+    SV_TRY(sv_out(ctx, pca_y, (size_t)S_tot * ctx->P * sizeof(float), &d_y));
+  }
 
   const void *d_tok, *d_inc = nullptr, *d_adj = nullptr;
   void *d_out = nullptr, *d_lab = nullptr, *d_gap = nullptr, *d_bn = nullptr;
   SV_TRY(sv_in(ctx, tokens, (size_t)B * D * N * sizeof(float), &d_tok));
   if (S_tot > 0) SV_TRY(sv_in(ctx, inc_bits, (size_t)S_tot * nw * 8, &d_inc));
   if (adj && S_tot > 0) SV_TRY(sv_in(ctx, adj, (size_t)adj_off[B], &d_adj));
-  if (S_tot > 0) SV_TRY(sv_out(ctx, out, (size_t)S_tot * K * D * sizeof(float), &d_out));
+  if (S_tot > 0 && out) SV_TRY(sv_out(ctx, out, (size_t)S_tot * K * D * sizeof(float), &d_out));
   if (labels_out) SV_TRY(sv_out(ctx, labels_out, (size_t)B * N, &d_lab));
   if (gap_out) SV_TRY(sv_out(ctx, gap_out, (size_t)B * N * sizeof(float), &d_gap));
   if (block_norms_out && S_tot > 0) SV_TRY(sv_out(ctx, block_norms_out, (size_t)S_tot * K * sizeof(float), &d_bn));
@@ -358,11 +371,57 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
       StageScope sc(ctx, "aggregate");
       SV_TRY(sv_launch_aggregate(ctx, ctx->s_xt.as<float>(), ctx->s_rnorm.as<float>(), (const uint8_t*)d_lab,
                                  ctx->s_colmask.as<uint64_t>(), ctx->vocab.as<float>(), K, D, ctx->s_segoff.as<int32_t>(),
-                                 ctx->s_gscale.as<float>(), B, N, SC, (float*)d_out, (float*)d_bn));
+                                 ctx->s_gscale.as<float>(), B, N, SC, (float*)d_out, (float*)d_bn,
+                                 fused ? ctx->pca_mean.as<float>() : nullptr, xscale,
+                                 fused ? ctx->s_xh1.as<uint16_t>() : nullptr, fused ? ctx->s_xh2.as<uint16_t>() : nullptr));
       sc.count();
+    }
+    if (fused) {
+      StageScope sc(ctx, "pca");
+      SV_TRY(sv_launch_gemm_f16x3(ctx, ctx->s_xh1.as<uint16_t>(), ctx->s_xh2.as<uint16_t>(), ctx->pca_w1.as<uint16_t>(),
+                                  ctx->pca_w2.as<uint16_t>(), S_tot, ctx->P, ctx->KD, 1.f / (xscale * ctx->pca_w_scale),
+                                  ctx->pca_scale.as<float>(), (float*)d_y));
+      sc.count(2);
+      if (l2norm) {
+        SV_TRY(sv_launch_normalize_rows(ctx, (const float*)d_y, S_tot, ctx->P, (float*)d_y));
+        sc.count();
+      }
     }
   }
   return sv_finish(ctx);
+}
+
+int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                   const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out, float* gap_out,
+                   float* block_norms_out) {
+  CHECK_CTX();
+  return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, out, labels_out, gap_out, block_norms_out, nullptr, 0);
+}
+
+int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                       const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
+                       uint8_t* labels_out, float* gap_out) {
+  CHECK_CTX();
+  if (ctx->P == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images_pca: call segvlad_pca_set first");
+  if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images_pca: call segvlad_set_vocab first");
+  if (ctx->KD != ctx->K * ctx->D)
+    return ctx->fail(SEGVLAD_ERR_ARG, "images_pca: the PCA model expects %d-d rows, the vocabulary gives %d", ctx->KD,
+                     ctx->K * ctx->D);
+  if (B > 0 && seg_offsets && !sv_is_device_ptr(seg_offsets) && seg_offsets[B] > 0 && !y)
+    return ctx->fail(SEGVLAD_ERR_ARG, "images_pca: null y");
+  const bool x3 = ctx->pca_w_scale > 0.f && getenv("SEGVLAD_PCA_FP32") == nullptr;
+  if (x3) return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc_out, labels_out, gap_out, nullptr, y, l2norm);
+  // shapes the split GEMM does not take (or the fp32 knob): descriptor to HBM, then the plain projection
+  if (B <= 0 || !seg_offsets || sv_is_device_ptr(seg_offsets))
+    return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc_out, labels_out, gap_out, nullptr, nullptr, 0);
+  const int S_tot = seg_offsets[B];
+  float* desc = desc_out;
+  if (!desc && S_tot > 0) {
+    SV_HIP(ctx->s_desc.reserve((size_t)S_tot * ctx->KD * sizeof(float)));
+    desc = ctx->s_desc.as<float>();
+  }
+  SV_TRY(images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc, labels_out, gap_out, nullptr, nullptr, 0));
+  return S_tot > 0 ? segvlad_pca_apply(ctx, desc, S_tot, y, l2norm) : SEGVLAD_OK;
 }
 
 // ---- K-parametric aggregation of given residuals + labels (vlad_matmuls_per_cluster) --------------------

@@ -104,7 +104,7 @@ struct segvlad_ctx {
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2;
+      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -149,7 +149,8 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
 // centres == nullptr: the inputs are residuals already (x * rnorm - 0)
 int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
                         const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
-                        const float* gscale, int B, int N, int SC, float* out, float* block_norms);
+                        const float* gscale, int B, int N, int SC, float* out, float* block_norms,
+                        const float* mean = nullptr, float xscale = 0.f, uint16_t* h1 = nullptr, uint16_t* h2 = nullptr);
 
 // gemm_kernels.hip
 int sv_launch_row_sumsq(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* out);

@@ -616,13 +616,19 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
 //   B[kk][j] = fma(Xt[t_kk][dcol + 4 j + q], rn, -C[k][...])   q = N-tile; one 16-B load feeds 4 N-tiles
 // then ||V[s,k,:]|| (LDS reduction across the waves), scale by gscale[s]/max(norm,1e-12), store packed.
 // ------------------------------------------------------------------------------------------------
+// PLANES: additionally (or instead: out may be NULL) emit the PCA input planes of the block,
+//   (v - mean) * xscale = h1 + h2 (two fp16 terms, see gemm_f16x3_kernels.hip), so that the projection GEMM reads the
+//   descriptor without a separate max-abs + split pass and the fp32 descriptor need not reach HBM at all
+//   (|v| <= 1 by construction, which is what makes the scale known in advance).
+template <bool PLANES>
 __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
                                                         const uint8_t* __restrict__ labels,
                                                         const uint64_t* __restrict__ colmask,
                                                         const float* __restrict__ C, const int32_t* __restrict__ seg_off,
                                                         const float* __restrict__ gscale, int N, int D, int K, int SC,
                                                         int Ncap, float* __restrict__ out,
-                                                        float* __restrict__ block_norms) {
+                                                        float* __restrict__ block_norms, const float* __restrict__ mean,
+                                                        float xscale, _Float16* __restrict__ h1, _Float16* __restrict__ h2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int k = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -668,6 +674,8 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
   const bool dvalid = dcol < D;
   float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (dvalid && C != nullptr) c4 = *reinterpret_cast<const float4*>(C + (size_t)k * D + dcol);
+  float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PLANES && dvalid && mean != nullptr) mu4 = *reinterpret_cast<const float4*>(mean + (size_t)k * D + dcol);
   const float* Xb = Xt + (size_t)b * N * D + dcol;
   const size_t KD = (size_t)K * D;
   const int SCb = (S + 63) >> 6;
@@ -745,7 +753,20 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
           if (row < Sc) {
             const float a = alpha[row];
             float4 v = make_float4(acc[mt][0][r] * a, acc[mt][1][r] * a, acc[mt][2][r] * a, acc[mt][3][r] * a);
-            *reinterpret_cast<float4*>(out + (size_t)(s0 + 64 * sc + row) * KD + (size_t)k * D + dcol) = v;
+            const size_t o = (size_t)(s0 + 64 * sc + row) * KD + (size_t)k * D + dcol;
+            if (!PLANES || out != nullptr) *reinterpret_cast<float4*>(out + o) = v;
+            if (PLANES) {
+              typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+              const float f[4] = {(v.x - mu4.x) * xscale, (v.y - mu4.y) * xscale, (v.z - mu4.z) * xscale, (v.w - mu4.w) * xscale};
+              h4 p1, p2;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                p1[e] = (_Float16)f[e];
+                p2[e] = (_Float16)(f[e] - (float)p1[e]);
+              }
+              *reinterpret_cast<h4*>(h1 + o) = p1;
+              *reinterpret_cast<h4*>(h2 + o) = p2;
+            }
           }
         }
       }
@@ -756,7 +777,8 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
 
 int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
                         const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
-                        const float* gscale, int B, int N, int SC, float* out, float* block_norms) {
+                        const float* gscale, int B, int N, int SC, float* out, float* block_norms, const float* mean,
+                        float xscale, uint16_t* h1, uint16_t* h2) {
   const int nwaves = (D + 127) / 128;
   if (nwaves > 12)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: D=%d exceeds the 1536-wide workgroup of this build", D);
@@ -764,11 +786,12 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, c
   const int PW = nwaves * 8 + 1;
   const size_t lds = (size_t)Ncap * 16 + (size_t)(64 * PW + 64) * sizeof(float) + 16 * sizeof(int);
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: N=%d tokens need %zu B of LDS (limit 160 KiB)", N, lds);
+  auto kern = (h1 != nullptr) ? aggregate_kernel<true> : aggregate_kernel<false>;
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-  hipLaunchKernelGGL(aggregate_kernel, dim3(K, B), dim3(nwaves * 64), lds, ctx->stream, xt, rnorm, labels, colmask,
-                     centres, seg_off_dev, gscale, N, D, K, SC, Ncap, out, block_norms);
+    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(K, B), dim3(nwaves * 64), lds, ctx->stream, xt, rnorm, labels, colmask, centres, seg_off_dev,
+                     gscale, N, D, K, SC, Ncap, out, block_norms, mean, xscale, reinterpret_cast<_Float16*>(h1),
+                     reinterpret_cast<_Float16*>(h2));
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

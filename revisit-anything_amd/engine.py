@@ -197,6 +197,44 @@ class SegVLADEngine:
             res["block_norms"] = bn
         return res
 
+    def seg_vlad_pca(self, tokens, inc_bits, seg_offsets: Sequence[int], adj=None, l2norm: bool = True, want_desc=False,
+                     want_labels=False, want_gap=False):
+        """Fused seg_vlad + pca_apply (segvlad_images_pca): returns dict(out=[S_tot,P] projected (and normalised)
+        descriptors, desc?=[S_tot,K*D], labels?, gap?).  Without want_desc the K*D-wide descriptor never reaches HBM."""
+        if self.K == 0:
+            raise SegVLADError("seg_vlad_pca: set_vocab first")
+        if self.P == 0:
+            raise SegVLADError("seg_vlad_pca: pca_set first")
+        t = _as(tokens, np.float32, torch.float32)
+        if t.ndim == 2:
+            t = t[None]
+        B, D, N = t.shape
+        if D != self.D:
+            raise ValueError(f"tokens have D={D}, vocabulary has D={self.D}")
+        so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+        assert so.shape == (B + 1,)
+        S_tot = int(so[-1])
+        ib = inc_bits if isinstance(inc_bits, torch.Tensor) else np.ascontiguousarray(inc_bits)
+        a = None
+        if adj is not None:
+            a = adj.to(torch.uint8).contiguous() if isinstance(adj, torch.Tensor) else np.ascontiguousarray(adj).astype(np.uint8)
+        y = self._empty((S_tot, self.P), torch.float32)
+        desc = self._empty((S_tot, self.K * self.D), torch.float32) if want_desc else None
+        lab = self._empty((B, N), torch.uint8) if want_labels else None
+        gap = self._empty((B, N), torch.float32) if want_gap else None
+        self._stream()
+        self._check(self.lib.segvlad_images_pca(self._h, _ptr(t), B, N, _ptr(ib), _ptr(so), _ptr(a), _ptr(y), int(bool(l2norm)),
+                                                _ptr(desc), _ptr(lab), _ptr(gap)), "images_pca")
+        self._keep = [t, ib, a]
+        res = {"out": y}
+        if want_desc:
+            res["desc"] = desc
+        if want_labels:
+            res["labels"] = lab
+        if want_gap:
+            res["gap"] = gap
+        return res
+
     def cluster_aggregate(self, num_c: int, res, labels, inc_bits, adj=None) -> torch.Tensor:
         """vlad_matmuls_per_cluster surface: res [N,D] fp32 residuals, labels [N] (< num_c), inc_bits [S,nw]."""
         r = _as(res, np.float32, torch.float32)

@@ -42,13 +42,14 @@ def adjacency_batch(centroids: np.ndarray, seg_offsets: Sequence[int], order: in
 
 class SegVLADPipeline:
     def __init__(self, engine: SegVLADEngine, H: int, W: int, patch: int = 14, order: int = 3, use_pca: bool = True,
-                 adj_workers: int = 8, host_adjacency: bool = False):
+                 adj_workers: int = 8, host_adjacency: bool = False, fuse_pca: bool = True):
         self.eng = engine
         self.H, self.W, self.patch = H, W, patch
         self.order = order
         self.use_pca = use_pca
         self.adj_workers = adj_workers
         self.host_adjacency = host_adjacency
+        self.fuse_pca = fuse_pca
         self.N = (H // patch) * (W // patch)
 
     # ---- a2..a9: images -> (normalised) segment descriptors ------------------------------------------
@@ -68,6 +69,8 @@ class SegVLADPipeline:
             bits = eng.incidence(masks, self.H, self.W, self.patch)
             if not self.order:
                 adj = None
+        if self.use_pca and self.fuse_pca:   # aggregation feeds the projection GEMM directly (segvlad_images_pca)
+            return eng.seg_vlad_pca(tokens, bits, seg_offsets, adj, l2norm=l2norm)["out"]
         desc = eng.seg_vlad(tokens, bits, seg_offsets, adj)["out"]
         if self.use_pca:
             desc = eng.pca_apply(desc, l2norm=l2norm)

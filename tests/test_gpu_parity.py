@@ -581,3 +581,44 @@ def test_pca_f16_split_path_is_fp32_class(eng):
     assert e16 < 2e-5 and e16 < 4 * e32 + 1e-6, (e16, e32)
     cos = (y16 * ref).sum(1) / (np.linalg.norm(y16, axis=1) * np.linalg.norm(ref, axis=1))
     assert (1 - cos).max() < 5e-7   # fp32 outputs: the cosine itself is only resolved to ~1e-7
+
+
+# ------------------------------------------------------------------------------------------------
+# fused segment-VLAD -> PCA (segvlad_images_pca): the aggregation kernel emits the projection GEMM's fp16 planes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P", [64, 40])   # 64: fused split-GEMM path; 40: shapes it does not take -> unfused inside the call
+def test_images_pca_fused_equals_two_calls_and_oracle(eng, P):
+    D, K, N = 128, 32, 15 * 20
+    C = synth().make_vocab(K, D, seed=91)
+    rng = np.random.Generator(np.random.PCG64(92))
+    toks, incs, adjs = [], [], []
+    for b, S in enumerate([5, 0, 33, 70]):
+        toks.append(synth().make_tokens(C[:7] if b == 2 else C, N, seed=950 + b, noise=0.3))   # b==2: empty clusters
+        inc = rng.random((S, N)) < 0.15
+        if S > 2:
+            inc[1] = False                      # token-less segment: its descriptor row is 0, its projection -mean.W
+        incs.append(inc)
+        adjs.append(np.eye(S, dtype=bool) | (rng.random((S, S)) < 0.05))
+    mean, comps, var = synth().make_pca_model(K * D, P, seed=9)
+    eng.set_vocab(C)
+    eng.pca_set(mean, comps, var, whiten=True)
+    offs = np.concatenate([[0], np.cumsum([i.shape[0] for i in incs])]).astype(np.int32)
+    bits = np.concatenate([O().pack_bits_u64(i) for i in incs]).view(np.int64)
+    adj = cat_adj(adjs)
+    tk = np.stack(toks)
+    for l2 in (True, False):
+        fused = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=l2, want_desc=True, want_labels=True)
+        desc = eng.seg_vlad(tk, bits, offs, adj, want_labels=True)
+        two = eng.pca_apply(desc["out"], l2norm=l2).cpu().numpy()
+        y = fused["out"].cpu().numpy()
+        assert np.array_equal(fused["desc"].cpu().numpy(), desc["out"].cpu().numpy())
+        assert np.array_equal(fused["labels"].cpu().numpy(), desc["labels"].cpu().numpy())
+        assert np.abs(y - two).max() <= 2e-5 * np.abs(two).max()
+        ref = np.concatenate([O().seg_vlad(toks[b], incs[b], C, adjs[b]) for b in range(4) if incs[b].shape[0]])
+        ref = O().pca_transform(ref, mean, comps, var, True)
+        if l2:
+            ref = O().normalize_feat(ref)
+        assert np.abs(y - ref).max() <= 3e-5 * np.abs(ref).max()
+        # without the descriptor output the projection is unchanged
+        y2 = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=l2)["out"].cpu().numpy()
+        assert np.array_equal(y, y2)
