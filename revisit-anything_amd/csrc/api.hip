@@ -821,6 +821,20 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
                                        ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
           sc.count();
         }
+        if (getenv("SEGVLAD_DEBUG_SEARCH")) {  // debug: candidate-list statistics of this level (synchronises)
+          std::vector<uint32_t> hc(m);
+          SV_HIP(hipStreamSynchronize(ctx->stream));
+          SV_HIP(hipMemcpy(hc.data(), ctx->s_cand_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+          uint64_t tot = 0;
+          uint32_t mx = 0, over = 0;
+          for (uint32_t c : hc) {
+            tot += c;
+            if (c > mx) mx = c;
+            if (c > (uint32_t)CAP) ++over;
+          }
+          fprintf(stderr, "[search] q0=%d m=%d level %d/%d ns=%lld: candidates mean %.1f max %u, %u lists over cap %d\n", q0, m, lv,
+                  levels, (long long)ns, (double)tot / m, mx, over, CAP);
+        }
         StageScope sc(ctx, "knn_select");
         SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
                                        ctx->s_cand_id.as<uint32_t>(), m, CAP, k, last ? 1 : 0, qn + q0, c_eps, rn_max, thr,

@@ -20,6 +20,8 @@
 //   refine_exact_kernel      per query: exact fp32 distances of the refine list, sort, top-k
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "ctx.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -360,6 +362,15 @@ __device__ __forceinline__ void wait_vm_lgkm0() {  // s_waitcnt needs a literal 
 // group then covers all 16 bank slots).
 //   BM x BN tile, WM x WN waves, HBK k per tile, two A stages (queries: L2 resident) and NB B stages (database
 //   rows stream from HBM/MALL; NB = 3 keeps their DMA two k-tiles ahead via a counted vmcnt).
+// ABL == 9: phase timing (s_memtime of wave 0 at the phase boundaries, summed over workgroups; SEGVLAD_F16_CFG=90 prints it)
+__device__ unsigned long long sv_f16_phase_cycles[8];
+#define SV_PHASE(k)                                                                          \
+  if (ABL >= 9) {                                                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
+    if (threadIdx.x == 0) atomicAdd(&sv_f16_phase_cycles[k], now_ - phase_t0);               \
+    phase_t0 = now_;                                                                         \
+  }
+
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
@@ -375,8 +386,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   constexpr int PA = BM * RB, PB = BN * RB;
   constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and operand
   static_assert(JA * RP * NW == BM && JB * RP * NW == BN && (JA + JB) % KS == 0, "tile/wave geometry");
-  constexpr int BMW = (TM * TN * 16 + 31) / 32;  // survivor bitmap words per lane
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned long long phase_t0 = (ABL >= 9) ? __builtin_amdgcn_s_memtime() : 0ull;
   // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2); the 32
   // workgroups an XCD runs side by side form one gm x (32/gm) block of tiles, so that they share their query and
   // database rows in that L2 while they march over k (tm-fastest order made every XCD fetch every database row).
@@ -406,6 +417,21 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // epilogue inputs, requested now so that their latency hides under the main loop (one workgroup per CU: nothing
+  // else would cover it): row tid's ||q||^2 and threshold, this lane's column norms
+  static_assert(BM <= 64 * NW, "one thread per query row stages the epilogue's row record");
+  float pre_q2 = 0.f, pre_thr = 0.f;
+  if (tid < BM && m0 + tid < M) {
+    pre_q2 = qn[m0 + tid];
+    pre_thr = thr[(m0 + tid) * thr_ld];
+  }
+  float cn[TN];
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    const int64_t colj = n0 + wn * (32 * TN) + nt * 32 + i;
+    cn[nt] = (colj < N) ? rn[colj * b_stride] : INFINITY;  // +inf: columns beyond N never pass
+  }
 
   // per-lane source rows of this wave's DMA pieces (clamped: edge rows are never emitted)
   const int lrow_p = l / CH, lch = l % CH;
@@ -456,6 +482,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     wait_vm_lgkm0<0>();
   }
   __builtin_amdgcn_s_barrier();
+  SV_PHASE(0)  // prologue: first tiles landed
 
   int ia = 0, ib = 0;
   const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
@@ -502,7 +529,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     ib = (ib + 1 >= NB) ? 0 : ib + 1;
   }
 
-  if (ABL >= 1) {  // ablation: no epilogue (accumulators stay live)
+  SV_PHASE(1)  // main loop
+  if (ABL >= 1 && ABL <= 3) {  // ablation: no epilogue (accumulators stay live)
     float t = 0.f;
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
@@ -512,75 +540,97 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     return;
   }
   // ---- epilogue: keep d2~ <= thr + eps_mult * eps(q) -----------------------------------------------------------
-  // Per-row quantities are staged ONCE per workgroup in LDS (free after the last barrier).  Pass 1 screens every
-  // accumulator element with one fma + compare against a conservative per-row bound, re-tests the (rare) hits
-  // exactly, records them in a per-lane bitmap and counts them per row in LDS (non-returning adds); ONE global
-  // atomic per row and workgroup then reserves a slot range; pass 2 walks the bitmap and writes the survivors at
-  // range + LDS ticket.  (One returning global atomic per survivor parked the wave for ~1.5 us each.)  The list
-  // order is arbitrary: every consumer ranks or sorts it.
-  float* rq2 = reinterpret_cast<float*>(lds);                // [BM] ||q||^2
-  float* rlim = rq2 + BM;                                     // [BM] exact limit
-  float* rtau = rlim + BM;                                    // [BM] screening bound on the raw accumulator (minus slack)
-  uint32_t* lcnt = reinterpret_cast<uint32_t*>(rtau + BM);    // [BM] survivors of this tile per query row
-  uint32_t* gbase = lcnt + BM;                                // [BM] first slot reserved in the global list
+  // The epilogue is VALU-issue bound (s_memtime phase timing, SEGVLAD_F16_CFG=90: every instruction of the sparse
+  // per-survivor paths is paid by the whole wave), so it is organised around instruction count and everything
+  // per-survivor happens on DENSE lanes:
+  //  * per-row quantities {||q||^2, exact limit, screening bound} and the tile's column norms are staged once per
+  //    workgroup in LDS (their global loads were issued before the main loop);
+  //  * pass 1 screens every accumulator element with one fma + compare against the row's bound; the (rare) waves
+  //    that see a hit compact the raw {accumulator, row | column} pairs by ballot/mbcnt into a wave-private LDS
+  //    list -- three instructions per element on the common path, no atomics, no exact arithmetic;
+  //  * pass 2a walks that list 64 records at a time (all lanes busy): exact d2~, exact limit test, LDS count per row;
+  //  * ONE global atomic per row and workgroup reserves a slot range in that query's candidate list;
+  //  * pass 2b walks the list again and stores the survivors at range + LDS ticket.
+  // (History: one returning global atomic per survivor parked the wave ~1.5 us each; re-walking the 128 accumulator
+  // elements under a per-lane bitmap cost 20 % of the kernel; ~100-instruction exact-test bodies per hit row 25 %.)
+  // A wave whose 64 x 128 block holds more than LCAP hits (databases are spatially coherent: the 50 segments of a
+  // query image against the rows of the same place) abandons its list and walks its accumulators directly
+  // (per-hit LDS atomics: slow, but only for the handful of dense blocks).  The list order is arbitrary: every
+  // consumer ranks or sorts it.
+  constexpr int LCAP = (TM * TN * 256 < 2048) ? TM * TN * 256 : 2048;   // records per wave (a quarter of its elements)
+  float4* rrec = reinterpret_cast<float4*>(lds);                         // [BM] {||q||^2, exact limit, screening bound, -}
+  uint32_t* rowcnt = reinterpret_cast<uint32_t*>(rrec + BM);             // [BM] survivors per row -> next free global slot
+  float* cnl = reinterpret_cast<float*>(rowcnt + BM);                    // [BN] column norms
+  uint2* wlist = reinterpret_cast<uint2*>(cnl + BN) + (size_t)w * (LCAP + 1);  // this wave's hit list (+1 dump slot)
   const float half_scale = 0.5f / inv_scale;
   const float rmax_hs = rn_max * half_scale;
-  for (int j = tid; j < BM; j += 64 * NW) {
-    const int64_t row = m0 + j;
+  if (tid < BM) {
+    const int j = tid;
     float q2 = 0.f, lim = -INFINITY, tau = INFINITY;
-    if (row < M) {
-      q2 = qn[row];
-      lim = thr[row * thr_ld] + eps_mult * c_eps * sqrtf(q2 * rn_max);
-      // v <= lim  <=>  acc >= ((q2 - lim) + cn) * half_scale; the slack (relative 2^-17 of the largest possible
-      // magnitude) makes rounding of this shortcut only ever ADD candidates
+    if (m0 + j < M) {
+      q2 = pre_q2;
+      lim = pre_thr + eps_mult * c_eps * sqrtf(q2 * rn_max);
+      // v <= lim  <=>  acc - cn * half_scale >= (q2 - lim) * half_scale; the slack (relative 2^-17 of the largest
+      // possible magnitude) makes rounding of this shortcut only ever ADD candidates
       const float base = (q2 - lim) * half_scale;
       tau = base - 7.7e-6f * (fabsf(base) + rmax_hs);
     }
-    rq2[j] = q2;
-    rlim[j] = lim;
-    rtau[j] = tau;
-    lcnt[j] = 0;
+    rrec[j] = make_float4(q2, lim, tau, 0.f);
+    rowcnt[j] = 0u;
   }
-  float cnh[TN], cn[TN];
-  int64_t col[TN];
+  float cnh[TN];
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
-    col[nt] = n0 + wn * (32 * TN) + nt * 32 + i;
-    cn[nt] = (col[nt] < N) ? rn[col[nt] * b_stride] : INFINITY;  // +inf: columns beyond N never pass
     cnh[nt] = cn[nt] * half_scale;
+    if (wm == 0) cnl[wn * (32 * TN) + nt * 32 + i] = cn[nt];   // both half-waves hold the same value
   }
   __syncthreads();
-  uint32_t bm[BMW];
-#pragma unroll
-  for (int t = 0; t < BMW; ++t) bm[t] = 0u;
+  SV_PHASE(2)  // row records staged
+  uint32_t wave_cnt = 0;  // wave-uniform: only updated under wave-uniform control flow
+  uint32_t dbg_bodies = 0;
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int lrow = wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-      const float tau = rtau[lrow];
+      const uint32_t lrow16 = (uint32_t)(wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) << 16;
+      const float tau = rrec[lrow16 >> 16].z;
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
-        if (acc[mt][nt][r] >= tau + cnh[nt]) {
-          if (sv_d2(rq2[lrow], cn[nt], acc[mt][nt][r] * inv_scale) <= rlim[lrow]) {
-            const int e = (mt * TN + nt) * 16 + r;
-            bm[e >> 5] |= 1u << (e & 31);
-            atomicAdd(&lcnt[lrow], 1u);
-          }
+        const float a = acc[mt][nt][r];
+        const bool hit = (ABL == 12) ? false : (a - cnh[nt] >= tau);   // ABL 12: timing ablation (wrong results)
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+        if (mk != 0ull) {
+          if (ABL >= 9) ++dbg_bodies;
+          uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+          pos = pos < (uint32_t)LCAP ? pos : (uint32_t)LCAP;   // beyond the list: the dump slot (overflow is flagged below)
+          if (hit) wlist[pos] = make_uint2(__float_as_uint(a), lrow16 | (uint32_t)(wn * (32 * TN) + nt * 32 + i));
+          wave_cnt += (uint32_t)__popcll(mk);
         }
       }
     }
-  __syncthreads();
-  for (int j = tid; j < BM; j += 64 * NW) {
-    const uint32_t c = lcnt[j];
-    gbase[j] = (c > 0 && m0 + j < M) ? atomicAdd(&cand_cnt[m0 + j], c) : 0u;
-    lcnt[j] = 0;
+  if (ABL >= 9 && tid == 0) atomicAdd(&sv_f16_phase_cycles[6], (unsigned long long)dbg_bodies);
+  SV_PHASE(3)  // pass 1
+  // pass 2a: exact test of this wave's hits, dense (the list is wave-private: no barrier needed before reading it)
+  const uint32_t n_w = wave_cnt <= (uint32_t)LCAP ? wave_cnt : 0u;   // a dense block abandons its (truncated) list
+  for (uint32_t t = (uint32_t)l; t < n_w; t += 64u) {
+    uint2 rec = wlist[t];
+    const int lrow = (int)(rec.y >> 16);
+    const float4 rr = rrec[lrow];
+    const float v = sv_d2(rr.x, cnl[rec.y & 0xffffu], __uint_as_float(rec.x) * inv_scale);
+    if (v <= rr.y && v < INFINITY) {   // +inf: padding columns beyond N (admitted by the screen when thr = +inf)
+      atomicAdd(&rowcnt[lrow], 1u);
+      rec.x = __float_as_uint(v);
+    } else {
+      rec.y = 0xffffffffu;   // screened in by the slack only
+    }
+    wlist[t] = rec;
   }
-  __syncthreads();
-  uint32_t any = 0u;
-#pragma unroll
-  for (int t = 0; t < BMW; ++t) any |= bm[t];
-  if (any != 0u) {
+  const bool dense = wave_cnt > (uint32_t)LCAP;   // wave-uniform
+  if (dense) {
+    // (the scale is laundered through an empty asm so that the compiler does not keep 128 values of pass 1 or of this
+    //  walk alive for the next one: that spilled the common path)
+    float isc = inv_scale;
+    asm volatile("" : "+v"(isc));
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -588,18 +638,59 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         const int lrow = wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-          const int e = (mt * TN + nt) * 16 + r;
-          if ((bm[e >> 5] >> (e & 31)) & 1u) {
-            const uint32_t slot = gbase[lrow] + atomicAdd(&lcnt[lrow], 1u);
-            if (slot < (uint32_t)cap) {
-              const int64_t row = m0 + lrow;
-              cand_d2[row * cap + slot] = sv_d2(rq2[lrow], cn[nt], acc[mt][nt][r] * inv_scale);
-              cand_id[row * cap + slot] = (uint32_t)(col[nt] * b_stride);
+          const float4 rr = rrec[lrow];
+          const float v = sv_d2(rr.x, cn[nt], acc[mt][nt][r] * isc);
+          if (v <= rr.y && v < INFINITY) atomicAdd(&rowcnt[lrow], 1u);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the 32 row-record loads from being hoisted (register pressure)
+      }
+  }
+  __syncthreads();
+  SV_PHASE(4)  // pass 2a
+  if (tid < BM) {
+    const uint32_t c = rowcnt[tid];
+    rowcnt[tid] = (c > 0u) ? atomicAdd(&cand_cnt[m0 + tid], c) : 0u;  // rows >= M never count
+  }
+  __syncthreads();
+  for (uint32_t t = (uint32_t)l; t < n_w; t += 64u) {
+    const uint2 rec = wlist[t];
+    if (rec.y != 0xffffffffu) {
+      const int lrow = (int)(rec.y >> 16);
+      const uint32_t slot = atomicAdd(&rowcnt[lrow], 1u);
+      if (slot < (uint32_t)cap) {
+        const int64_t row = m0 + lrow;
+        cand_d2[row * cap + slot] = __uint_as_float(rec.x);
+        cand_id[row * cap + slot] = (uint32_t)((n0 + (int64_t)(rec.y & 0xffffu)) * b_stride);
+      }
+    }
+  }
+  if (dense) {
+    float isc = inv_scale;
+    asm volatile("" : "+v"(isc));
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const float4 rr = rrec[lrow];
+          {
+            const float v = sv_d2(rr.x, cn[nt], acc[mt][nt][r] * isc);
+            if (v <= rr.y && v < INFINITY) {
+              const uint32_t slot = atomicAdd(&rowcnt[lrow], 1u);
+              if (slot < (uint32_t)cap) {
+                const int64_t row = m0 + lrow;
+                cand_d2[row * cap + slot] = v;
+                cand_id[row * cap + slot] = (uint32_t)((n0 + wn * (32 * TN) + nt * 32 + i) * b_stride);
+              }
             }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
   }
+  SV_PHASE(5)  // reservation + pass 2b
 }
 
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0>
@@ -620,7 +711,12 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   }
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
   size_t lds = 2 * (size_t)BM * HBK * 2 + (size_t)NB * BN * HBK * 2;  // two A stages + NB B stages
-  if (lds < (size_t)BM * 20) lds = (size_t)BM * 20;                   // epilogue scratch
+  {  // epilogue: row records + per-row counters + one survivor list per wave
+    constexpr int TMl = BM / (32 * WM), TNl = BN / (32 * WN);
+    constexpr int LCAPl = (TMl * TNl * 256 < 2048) ? TMl * TNl * 256 : 2048;
+    const size_t elds = (size_t)BM * 20 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
+    if (lds < elds) lds = elds;
+  }
   auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL>;
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -642,6 +738,23 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 10: return launch_f16_filter<256, 256, 4, 2, 64, 3, 1>(SV_F16_ARGS);  // ablations of config 0 (WRONG results)
     case 20: return launch_f16_filter<256, 256, 4, 2, 64, 3, 2>(SV_F16_ARGS);
     case 30: return launch_f16_filter<256, 256, 4, 2, 64, 3, 3>(SV_F16_ARGS);
+    case 90:
+    case 120: {  // phase timing of config 0 (debug: synchronises and prints; 110 / 120 also ablate pass 1)
+      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c8[8];
+      SV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sv_f16_phase_cycles), z, sizeof(z)));
+      const int rc = c == 90 ? launch_f16_filter<256, 256, 4, 2, 64, 3, 9>(SV_F16_ARGS)
+                             : launch_f16_filter<256, 256, 4, 2, 64, 3, 12>(SV_F16_ARGS);
+      SV_HIP(hipStreamSynchronize(ctx->stream));
+      SV_HIP(hipMemcpyFromSymbol(c8, HIP_SYMBOL(sv_f16_phase_cycles), sizeof(c8)));
+      double tot = 0;
+      for (int k = 0; k < 6; ++k) tot += (double)c8[k];
+      fprintf(stderr, "[f16 filter phases] M=%d n=%d: prologue %.1f%% main %.1f%% stage %.1f%% pass1 %.1f%% pass2a %.1f%% reserve+pass2b %.1f%% (%.3g cycles/WG-sum)\n",
+              M, n_sample, 100 * c8[0] / tot, 100 * c8[1] / tot, 100 * c8[2] / tot, 100 * c8[3] / tot, 100 * c8[4] / tot,
+              100 * c8[5] / tot, tot);
+      fprintf(stderr, "[f16 filter phases]   wave 0: %.2f hit bodies per tile\n",
+              (double)c8[6] / ((double)((M + 255) / 256) * ((n_sample + 255) / 256)));
+      return rc;
+    }
     case 1: return launch_f16_filter<256, 256, 4, 2, 32, 2>(SV_F16_ARGS);  //  64 KiB LDS, 2 workgroups / CU
     case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
     case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB

@@ -420,7 +420,33 @@ def test_knn_raw_descriptor_width_refines_without_lds_query_cache(eng):
     assert (idx == ridx).mean() > 0.98
 
 
-@pytest.mark.parametrize("d", [16, 32])
+def test_knn_dense_block_of_neighbours_in_consecutive_rows(eng):
+    """Spatially coherent database (the 50 segments of a place sit in consecutive rows): 64 similar queries whose 200
+    nearest rows are the SAME 200 consecutive rows.  One wave's 64 x 128 block of the fp16 filter then holds far more hits
+    than its LDS list (2048): the block must take the direct path and the search must stay exact, without a fall-back."""
+    rng = np.random.Generator(np.random.PCG64(205))
+    n, nq, k, d = 70001, 64, 200, 64
+    R = rng.standard_normal((n, d)).astype(np.float32)
+    b = rng.standard_normal(d).astype(np.float32) * 3.0
+    R[5000:5260] = b + 0.05 * rng.standard_normal((260, d)).astype(np.float32)
+    Q = (b + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    eng.db_reset()
+    eng.db_add(R)
+    eng.set_profiling(True)
+    eng.profile_reset()
+    d2, idx = (t.cpu().numpy() for t in eng.search(Q, k))
+    launches = eng.stage_ms("knn_gemm")[1]
+    eng.set_profiling(False)
+    rd2, ridx = O().knn_l2(R, Q, k)
+    assert launches == 2, launches            # level-0 matrix GEMM + one filter level: no exact-path fall-back
+    assert np.all((idx >= 5000) & (idx < 5260))
+    assert np.abs(d2 - rd2).max() < 1e-4 * rd2.max()
+    sep = np.minimum(np.diff(rd2, axis=1, prepend=-1), np.diff(rd2, axis=1, append=1e9)) > 1e-4
+    assert np.array_equal(idx[sep], ridx[sep])
+    assert (idx == ridx).mean() > 0.97
+
+
+@pytest.mark.parametrize("d", [16, 32, 64])   # fp32 / bf16x3 / fp16 filter (the last also overflows its per-wave hit lists)
 def test_knn_filter_overflow_falls_back_to_exact(eng, d):
     """Adversarial layout: every sampled row (id % 16 == 0) is far away, all other rows are near -> the sampled
     threshold admits everything, the candidate lists overflow, and the search must still be exact."""
