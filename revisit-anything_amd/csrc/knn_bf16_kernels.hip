@@ -594,17 +594,25 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     for (int r = 0; r < 16; ++r) {
       const uint32_t lrow16 = (uint32_t)(wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) << 16;
       const float tau = rrec[lrow16 >> 16].z;
+      float dd[TN];
 #pragma unroll
-      for (int nt = 0; nt < TN; ++nt) {
-        const float a = acc[mt][nt][r];
-        const bool hit = (ABL == 12) ? false : (a - cnh[nt] >= tau);   // ABL 12: timing ablation (wrong results)
-        const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
-        if (mk != 0ull) {
-          if (ABL >= 9) ++dbg_bodies;
-          uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-          pos = pos < (uint32_t)LCAP ? pos : (uint32_t)LCAP;   // beyond the list: the dump slot (overflow is flagged below)
-          if (hit) wlist[pos] = make_uint2(__float_as_uint(a), lrow16 | (uint32_t)(wn * (32 * TN) + nt * 32 + i));
-          wave_cnt += (uint32_t)__popcll(mk);
+      for (int nt = 0; nt < TN; ++nt) dd[nt] = acc[mt][nt][r] - cnh[nt];
+      float best = dd[0];
+#pragma unroll
+      for (int nt = 1; nt < TN; ++nt) best = fmaxf(best, dd[nt]);
+      if (ABL != 12 && __builtin_amdgcn_ballot_w64(best >= tau) != 0ull) {   // ABL 12: timing ablation (wrong results)
+        if (ABL >= 9) ++dbg_bodies;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const bool hit = dd[nt] >= tau;
+          const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+          if (mk != 0ull) {
+            uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            pos = pos < (uint32_t)LCAP ? pos : (uint32_t)LCAP;   // beyond the list: the dump slot (the block turns dense below)
+            if (hit)
+              wlist[pos] = make_uint2(__float_as_uint(acc[mt][nt][r]), lrow16 | (uint32_t)(wn * (32 * TN) + nt * 32 + i));
+            wave_cnt += (uint32_t)__popcll(mk);
+          }
         }
       }
     }
