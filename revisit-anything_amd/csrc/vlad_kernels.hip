@@ -10,11 +10,20 @@
 //                      global norm, packed store                      (func_vpr.py:1151,1195-1205)
 //
 // Wave = 64 lanes.  The two GEMM-shaped stages run on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "ctx.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// cross-lane move inside a 16-lane DPP row (quad_perm / row mirrors): plain VALU, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
 
 // row of D-fragment register r for lane half kk (v_mfma_f32_32x32x2_f32 C/D layout)
 __device__ __forceinline__ int frag_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
@@ -397,7 +406,7 @@ int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg
 //   B operand  (2 d x 32 centres): pre-swizzled bt, 256 B contiguous per wave-load
 // The raw values are also staged through a wave-private LDS tile and written token-major (Xt).
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int ABL = 0>   // ABL: timing ablations (SEGVLAD_ASSIGN_ABL; wrong results)
 __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ T, int N, int D, int K,
                                                      const float* __restrict__ bt, float* __restrict__ Xt,
                                                      uint8_t* __restrict__ labels, float* __restrict__ rnorm,
@@ -442,11 +451,18 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ T
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const float bv = bp[n * 64];
-        acc[0][n] = MFMA32(x0, bv, acc[0][n]);
-        acc[1][n] = MFMA32(x1, bv, acc[1][n]);
+        if (ABL == 1) {
+          acc[0][n][0] += x0 * bv;
+          acc[1][n][0] += x1 * bv;
+        } else {
+          acc[0][n] = MFMA32(x0, bv, acc[0][n]);
+          acc[1][n] = MFMA32(x1, bv, acc[1][n]);
+        }
       }
-      tile[(2 * i) * 65 + 2 * st + kk] = x0;
-      tile[(2 * i + 1) * 65 + 2 * st + kk] = x1;
+      if (ABL != 2) {
+        tile[(2 * i) * 65 + 2 * st + kk] = x0;
+        tile[(2 * i + 1) * 65 + 2 * st + kk] = x1;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -455,7 +471,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ T
     for (int it = 0; it < 16; ++it) {
       const int idx = it * 64 + l;
       const int tok = idx >> 4, c4 = (idx & 15) << 2;
-      if (t0 + tok < N && dbase + c4 < D) {
+      if (ABL != 2 && ABL != 3 && t0 + tok < N && dbase + c4 < D) {
         const float* q = tile + tok * 65 + c4;
         float4 v = make_float4(q[0], q[1], q[2], q[3]);
         *reinterpret_cast<float4*>(Xt + ((size_t)b * N + t0 + tok) * D + dbase + c4) = v;
@@ -513,18 +529,147 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ T
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// assign, wide-load variant (D % 32 == 0, K <= 64): workgroup = (image, 128-token tile), wave w owns tokens
+// 32w..32w+31 for ALL d (no cross-wave reduction: one sequential fp32 chain per score, d = 0..D-1).
+//   * the [32 d][128 token] chunk is fetched with 16-B loads (512 contiguous bytes per d row; the old kernel's
+//     8-B loads ran at 1.25 TB/s) one chunk ahead into registers, then parked in a double-buffered LDS tile
+//     (row stride 130 floats: conflict-free for both access patterns below);
+//   * MFMA A operand = tile[d][token] (lanes = consecutive tokens), B = pre-swizzled centres from L2;
+//   * the token-major copy Xt is written from the same tile: a lane gathers 4 consecutive d of one token
+//     (banks 8 c4 + token: all 64 distinct) and stores 16 B; 8 lanes cover 128 contiguous bytes of a token row.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restrict__ T, int N, int D, int K,
+                                                          const float* __restrict__ bt, float* __restrict__ Xt,
+                                                          uint8_t* __restrict__ labels, float* __restrict__ rnorm,
+                                                          float* __restrict__ gap) {
+  constexpr int DC = 32, TS = 130;
+  __shared__ __attribute__((aligned(16))) float tile[2 * DC * TS];   // also [128][NT*32+1] scores at the end (NT <= 2)
+  __shared__ float ssum[128];
+  const int b = blockIdx.y, t0 = blockIdx.x * 128;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const float* Tb = T + (size_t)b * D * N;
+  const int lr = tid >> 5, lq = tid & 31;        // loader: rows lr + 8 j, tokens t0 + 4 lq .. + 3
+  const int tl0 = t0 + 4 * lq;
+  const int nvalid = N - tl0;                    // tokens of this lane's quad inside the image
+  f32x16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  float ss = 0.f;
+  const int nch = D / DC;
+  float4 v[4];
+#define SV_LOAD_CHUNK(c)                                                              \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+    const float* p = Tb + (size_t)((c) * DC + lr + 8 * j) * N + tl0;                  \
+    if (nvalid >= 4) {                                                                \
+      const f32x4u u = *reinterpret_cast<const f32x4u*>(p);                           \
+      v[j] = make_float4(u[0], u[1], u[2], u[3]);                                     \
+    } else {                                                                          \
+      v[j] = make_float4(nvalid > 0 ? p[0] : 0.f, nvalid > 1 ? p[1] : 0.f, nvalid > 2 ? p[2] : 0.f, 0.f); \
+    }                                                                                 \
+  }
+#define SV_PARK_CHUNK(buf)                                                            \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+    float* q = tile + (buf) * (DC * TS) + (lr + 8 * j) * TS + 4 * lq;                 \
+    *reinterpret_cast<float2*>(q) = make_float2(v[j].x, v[j].y);                      \
+    *reinterpret_cast<float2*>(q + 2) = make_float2(v[j].z, v[j].w);                  \
+  }
+  SV_LOAD_CHUNK(0)
+  SV_PARK_CHUNK(0)
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) { SV_LOAD_CHUNK(c + 1) }
+    const float* tl = tile + (c & 1) * (DC * TS);
+#pragma unroll 8
+    for (int st = 0; st < DC / 2; ++st) {
+      const float x = tl[(2 * st + kk) * TS + 32 * w + i];
+      ss = fmaf(x, x, ss);
+      const float* bp = bt + ((size_t)(c * (DC / 2) + st) * NT) * 64 + l;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = MFMA32(x, bp[n * 64], acc[n]);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * 256 + tid;
+      const int tok = idx >> 3, c4 = idx & 7;
+      if (t0 + tok < N) {
+        const float* q = tl + (4 * c4) * TS + tok;
+        const float4 o = make_float4(q[0], q[TS], q[2 * TS], q[3 * TS]);
+        *reinterpret_cast<float4*>(Xt + ((size_t)b * N + t0 + tok) * D + c * DC + 4 * c4) = o;
+      }
+    }
+    if (c + 1 < nch) { SV_PARK_CHUNK((c + 1) & 1) }
+    __syncthreads();
+  }
+#undef SV_LOAD_CHUNK
+#undef SV_PARK_CHUNK
+  // ---- scores -> LDS [token][cluster]; one thread per token takes the first maximum and the runner-up ----------
+  constexpr int KP = NT * 32;
+  float* sc = tile;   // [128][KP+1]
+  ss += __shfl_xor(ss, 32);
+  if (kk == 0) ssum[32 * w + i] = ss;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[(32 * w + frag_row(r, kk)) * (KP + 1) + n * 32 + i] = acc[n][r];
+  __syncthreads();
+  if (tid < 128 && t0 + tid < N) {
+    const float rn = 1.0f / fmaxf(sqrtf(ssum[tid]), 1e-12f);
+    float best = -INFINITY, second = -INFINITY;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+      const float sv = sc[tid * (KP + 1) + k];
+      if (sv > best) {
+        second = best;
+        best = sv;
+        bi = k;
+      } else if (sv > second) {
+        second = sv;
+      }
+    }
+    const size_t o = (size_t)b * N + t0 + tid;
+    labels[o] = (uint8_t)bi;
+    rnorm[o] = rn;
+    if (gap) gap[o] = (K > 1) ? (best - second) * rn : INFINITY;
+  }
+}
+
 int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float* xt, uint8_t* labels, float* rnorm,
                      float* gap) {
   const int NT = ctx->Kpad / 32;
   dim3 grid((N + 63) / 64, B), block(256);
   const float* bt = ctx->vocab_bt.as<float>();
+  if (NT <= 2 && ctx->D % 32 == 0 && getenv("SEGVLAD_ASSIGN_NARROW") == nullptr) {
+    dim3 gridw((N + 127) / 128, B);
+    if (NT == 1)
+      hipLaunchKernelGGL(assign_wide_kernel<1>, gridw, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+    else
+      hipLaunchKernelGGL(assign_wide_kernel<2>, gridw, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+    SV_HIP(hipGetLastError());
+    return SEGVLAD_OK;
+  }
   switch (NT) {
     case 1:
       hipLaunchKernelGGL(assign_kernel<1>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
       break;
-    case 2:
-      hipLaunchKernelGGL(assign_kernel<2>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+    case 2: {
+      const char* ab = getenv("SEGVLAD_ASSIGN_ABL");
+      const int a = ab ? atoi(ab) : 0;
+      if (a == 1)
+        hipLaunchKernelGGL((assign_kernel<2, 1>), grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      else if (a == 2)
+        hipLaunchKernelGGL((assign_kernel<2, 2>), grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      else if (a == 3)
+        hipLaunchKernelGGL((assign_kernel<2, 3>), grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      else
+        hipLaunchKernelGGL(assign_kernel<2>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
       break;
+    }
     case 4:
       hipLaunchKernelGGL(assign_kernel<4>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
       break;
@@ -545,7 +690,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ l
                                                    const int32_t* __restrict__ seg_off,
                                                    const int64_t* __restrict__ adj_off, const uint8_t* __restrict__ adj,
                                                    int N, int K, int S_max, int SC, uint64_t* __restrict__ colmask,
-                                                   float* __restrict__ gscale) {
+                                                   float* __restrict__ gscale, int32_t* __restrict__ tok_order,
+                                                   int32_t* __restrict__ lab_off, const float* __restrict__ rnorm,
+                                                   float* __restrict__ rn_sorted) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   const int nw = (N + 63) >> 6;
@@ -571,13 +718,50 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ l
     const int lab = labels[(size_t)b * N + t];
     atomicOr(reinterpret_cast<unsigned long long*>(&lbits[lab * nw + (t >> 6)]), 1ull << (t & 63));
   }
-  for (int t = tid; t < N; t += 256) {
+  __syncthreads();
+  // token order grouped by label (ascending token id inside a label): the aggregation workgroup of (k, b) reads its
+  // token list, the tokens' 1/||x|| and their segment masks from CONTIGUOUS ranges instead of re-scanning all N
+  // labels and gathering per token (one dependent global round trip instead of four)
+  __shared__ int kcnt[257];
+  int* ord = reinterpret_cast<int*>(lbits + (size_t)K * nw);   // [N]
+  for (int k = tid; k < K; k += 256) {
+    int c = 0;
+    for (int w = 0; w < nw; ++w) c += __popcll(lbits[k * nw + w]);
+    kcnt[k] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int k = 0; k < K; ++k) {
+      const int c = kcnt[k];
+      kcnt[k] = a;
+      a += c;
+    }
+    kcnt[K] = a;
+  }
+  __syncthreads();
+  for (int k = tid; k <= K; k += 256) lab_off[(size_t)b * (K + 1) + k] = kcnt[k];
+  for (int k = tid; k < K; k += 256) {
+    int pos = kcnt[k];
+    for (int w = 0; w < nw; ++w) {
+      uint64_t m = lbits[k * nw + w];
+      while (m) {
+        ord[pos++] = 64 * w + __builtin_ctzll(m);
+        m &= m - 1;
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < N; p += 256) {
+    const int t = ord[p];
     const int w = t >> 6, bit = t & 63;
+    tok_order[(size_t)b * N + p] = t;
+    rn_sorted[(size_t)b * N + p] = rnorm[(size_t)b * N + t];
     for (int sc = 0; sc < SC; ++sc) {
       uint64_t m = 0;
       const int lo = sc * 64, hi = min(S, lo + 64);
       for (int s = lo; s < hi; ++s) m |= ((inc2[s * nw + w] >> bit) & 1ull) << (s - lo);
-      colmask[((size_t)b * N + t) * SC + sc] = m;
+      colmask[((size_t)b * N + p) * SC + sc] = m;   // indexed by POSITION in the label-grouped order
     }
   }
   __syncthreads();
@@ -596,14 +780,19 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
                    const int64_t* adj_off_dev, const uint8_t* adj, int B, int N, int K, int S_max, int SC,
                    uint64_t* colmask, float* gscale) {
   const int nw = (N + 63) / 64;
-  const size_t lds = ((size_t)S_max + K) * nw * sizeof(uint64_t);
+  if (K > 256) return ctx->fail(SEGVLAD_ERR_LIMIT, "prep: K=%d > 256", K);
+  SV_HIP(ctx->s_tokorder.reserve((size_t)B * N * sizeof(int32_t)));
+  SV_HIP(ctx->s_laboff.reserve((size_t)B * (K + 1) * sizeof(int32_t)));
+  SV_HIP(ctx->s_rnsorted.reserve((size_t)B * N * sizeof(float)));
+  const size_t lds = ((size_t)S_max + K) * nw * sizeof(uint64_t) + (size_t)N * sizeof(int);
   if (lds > 160 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "prep: (S_max=%d + K=%d) x %d token words needs %zu B of LDS (limit 160 KiB)", S_max,
                      K, nw, lds);
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, ctx->stream, labels, inc_bits, seg_off_dev, adj_off_dev, adj, N,
-                     K, S_max, SC, colmask, gscale);
+                     K, S_max, SC, colmask, gscale, ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(),
+                     ctx->s_rnorm.as<float>(), ctx->s_rnsorted.as<float>());
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -620,50 +809,54 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
 //   (v - mean) * xscale = h1 + h2 (two fp16 terms, see gemm_f16x3_kernels.hip), so that the projection GEMM reads the
 //   descriptor without a separate max-abs + split pass and the fp32 descriptor need not reach HBM at all
 //   (|v| <= 1 by construction, which is what makes the scale known in advance).
-template <bool PLANES>
+typedef const __attribute__((address_space(1))) void* agg_gptr_t;
+typedef __attribute__((address_space(3))) void* agg_lptr_t;
+__device__ unsigned long long sv_agg_phase_cycles[8];   // ABL == 9: s_memtime phase sums of wave 0 (SEGVLAD_AGG_ABL=9 prints)
+#define SV_APHASE(k)                                                              \
+  if (ABL == 9) {                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                 \
+    if (threadIdx.x == 0) atomicAdd(&sv_agg_phase_cycles[k], now_ - phase_t0);    \
+    phase_t0 = now_;                                                              \
+  }
+
+template <bool PLANES, int ABL = 0>   // ABL: timing ablations (SEGVLAD_AGG_ABL; wrong results)
 __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
-                                                        const uint8_t* __restrict__ labels,
+                                                        const int32_t* __restrict__ tok_order,
+                                                        const int32_t* __restrict__ lab_off,
                                                         const uint64_t* __restrict__ colmask,
                                                         const float* __restrict__ C, const int32_t* __restrict__ seg_off,
                                                         const float* __restrict__ gscale, int N, int D, int K, int SC,
                                                         int Ncap, float* __restrict__ out,
                                                         float* __restrict__ block_norms, const float* __restrict__ mean,
-                                                        float xscale, _Float16* __restrict__ h1, _Float16* __restrict__ h2) {
+                                                        float xscale, _Float16* __restrict__ h1, _Float16* __restrict__ h2,
+                                                        int kpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int k = blockIdx.x, b = blockIdx.y;
+  const int b = blockIdx.y;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
   const int nwaves = blockDim.x >> 6;
-  const int PW = nwaves * 8 + 1;
+  const int PW = nwaves * 2 + 1;
   uint64_t* mskl = reinterpret_cast<uint64_t*>(smem);         // [Ncap]
   int* tokl = reinterpret_cast<int*>(mskl + Ncap);            // [Ncap]
   float* rnl = reinterpret_cast<float*>(tokl + Ncap);         // [Ncap]
   float* part = rnl + Ncap;                                   // [64][PW]
   float* alpha = part + 64 * PW;                              // [64]
   int* wcount = reinterpret_cast<int*>(alpha + 64);           // [16]
+  constexpr int QD = 6;                                       // token-pair rows in flight per wave
+  unsigned char* xq = reinterpret_cast<unsigned char*>(wcount + 16);  // [nwaves][QD][1 KiB] DMA queue (16-B aligned)
 
-  // ---- L_k: ordered compaction of the tokens assigned to cluster k --------------------------------
-  int base = 0;
-  for (int r0 = 0; r0 < N; r0 += blockDim.x) {
-    const int t = r0 + tid;
-    const bool flag = (t < N) && (labels[(size_t)b * N + t] == k);
-    const uint64_t bal = __ballot(flag);
-    const int wp = __popcll(bal & ((1ull << l) - 1ull));
-    if (l == 0) wcount[w] = __popcll(bal);
-    __syncthreads();
-    int off = base, tot = 0;
-    for (int ww = 0; ww < nwaves; ++ww) {
-      const int c = wcount[ww];
-      if (ww < w) off += c;
-      tot += c;
-    }
-    if (flag) {
-      tokl[off + wp] = t;
-      rnl[off + wp] = rnorm[(size_t)b * N + t];
-    }
-    base += tot;
-    __syncthreads();
+  // a workgroup walks kpb consecutive clusters of its image: the (fire-and-forget) block stores of cluster k drain
+  // while the lists and token rows of cluster k+1 are fetched -- with one workgroup per CU (registers) nothing else
+  // would overlap the two
+  const int k_end = min(K, ((int)blockIdx.x + 1) * kpb);
+  unsigned long long phase_t0 = (ABL == 9) ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int k = (int)blockIdx.x * kpb; k < k_end; ++k) {
+  // ---- L_k: the tokens assigned to cluster k, ascending (grouped by prep_kernel) ---------------------
+  const int o0 = lab_off[(size_t)b * (K + 1) + k];
+  const int n = lab_off[(size_t)b * (K + 1) + k + 1] - o0;
+  for (int j = tid; j < n; j += blockDim.x) {
+    tokl[j] = tok_order[(size_t)b * N + o0 + j];
+    rnl[j] = rnorm[(size_t)b * N + o0 + j];   // 1/||x|| in the label-grouped order (prep_kernel)
   }
-  const int n = base;
   if (tid == 0 && (n & 1)) {  // pad to an even count with a zero-weight entry
     tokl[n] = 0;
     rnl[n] = 0.f;
@@ -681,9 +874,10 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
   const int SCb = (S + 63) >> 6;
 
   for (int sc = 0; sc < SCb; ++sc) {
-    for (int j = tid; j < n; j += blockDim.x) mskl[j] = colmask[((size_t)b * N + tokl[j]) * SC + sc];
+    for (int j = tid; j < n; j += blockDim.x) mskl[j] = colmask[((size_t)b * N + o0 + j) * SC + sc];
     if (tid == 0 && (n & 1)) mskl[n] = 0;
     __syncthreads();
+    SV_APHASE(0)  // lists
     const int Sc = min(64, S - 64 * sc);
     const bool two = Sc > 32;
     f32x16 acc[2][4];
@@ -694,29 +888,49 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
 
-#pragma unroll 2
-    for (int p = 0; p < npairs; ++p) {
-      const int j = 2 * p + kk;
-      const int t = tokl[j];
-      const float rn = rnl[j];
-      const uint64_t m = mskl[j];
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (dvalid) x = *reinterpret_cast<const float4*>(Xb + (size_t)t * D);
-      const float b0 = fmaf(x.x, rn, -c4.x), b1 = fmaf(x.y, rn, -c4.y);
-      const float b2 = fmaf(x.z, rn, -c4.z), b3 = fmaf(x.w, rn, -c4.w);
-      const float a0 = ((m >> i) & 1ull) ? 1.f : 0.f;
-      acc[0][0] = MFMA32(a0, b0, acc[0][0]);
-      acc[0][1] = MFMA32(a0, b1, acc[0][1]);
-      acc[0][2] = MFMA32(a0, b2, acc[0][2]);
-      acc[0][3] = MFMA32(a0, b3, acc[0][3]);
-      if (two) {
-        const float a1 = ((m >> (32 + i)) & 1ull) ? 1.f : 0.f;
-        acc[1][0] = MFMA32(a1, b0, acc[1][0]);
-        acc[1][1] = MFMA32(a1, b1, acc[1][1]);
-        acc[1][2] = MFMA32(a1, b2, acc[1][2]);
-        acc[1][3] = MFMA32(a1, b3, acc[1][3]);
+    // token rows reach the MFMA through a wave-private LDS queue filled by global->LDS DMA (lane l's 16 B land at
+    // slot + 16 l and are read back by the same lane): QD pairs in flight per wave without spending VGPRs on them --
+    // with two register-staged loads in flight the loop was one HBM round trip per two token pairs
+    {
+      unsigned char* qbase = xq + (size_t)__builtin_amdgcn_readfirstlane(w) * (QD * 1024);   // wave-uniform: lives in M0
+      auto issue = [&](int p) {
+        const int t = tokl[2 * p + kk];
+        __builtin_amdgcn_global_load_lds((agg_gptr_t)(Xb + (size_t)t * D), (agg_lptr_t)(qbase + (p % QD) * 1024), 16, 0, 0);
+      };
+      if (ABL != 1)
+        for (int q = 0; q < QD && q < npairs; ++q) issue(q);
+      for (int p = 0; p < npairs; ++p) {
+        const int j = 2 * p + kk;
+        const float rn = rnl[j];
+        const uint64_t m = mskl[j];
+        const int rem = npairs - 1 - p;   // DMAs issued after pair p's
+        if (rem >= QD - 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (rem == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (rem == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float4 x = *reinterpret_cast<const float4*>(qbase + (p % QD) * 1024 + l * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is read before it is refilled
+        if (ABL != 1 && p + QD < npairs) issue(p + QD);
+        if (!dvalid || ABL == 1) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float b0 = fmaf(x.x, rn, -c4.x), b1 = fmaf(x.y, rn, -c4.y);
+        const float b2 = fmaf(x.z, rn, -c4.z), b3 = fmaf(x.w, rn, -c4.w);
+        const float a0 = ((m >> i) & 1ull) ? 1.f : 0.f;
+        acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+        acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+        acc[0][2] = MFMA32(a0, b2, acc[0][2]);
+        acc[0][3] = MFMA32(a0, b3, acc[0][3]);
+        if (two) {
+          const float a1 = ((m >> (32 + i)) & 1ull) ? 1.f : 0.f;
+          acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+          acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+          acc[1][2] = MFMA32(a1, b2, acc[1][2]);
+          acc[1][3] = MFMA32(a1, b3, acc[1][3]);
+        }
       }
     }
+    SV_APHASE(1)  // main loop
     // ---- block norms: quad reduce in registers, then across lanes/waves through LDS ----------------
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -727,22 +941,30 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
         p = fmaf(acc[mt][1][r], acc[mt][1][r], p);
         p = fmaf(acc[mt][2][r], acc[mt][2][r], p);
         p = fmaf(acc[mt][3][r], acc[mt][3][r], p);
-        p += __shfl_xor(p, 1);
-        p += __shfl_xor(p, 2);
-        if ((l & 3) == 0) part[(32 * mt + frag_row(r, kk)) * PW + w * 8 + (i >> 2)] = p;
+        // sum over the 16 lanes of a DPP row (quad swaps, then the two mirrors): VALU only -- ds_bpermute shuffles and
+        // 96 partials per row made this phase 40 % of the kernel
+        p += dpp_f32<0xB1>(p);    // quad_perm [1,0,3,2]
+        p += dpp_f32<0x4E>(p);    // quad_perm [2,3,0,1]
+        p += dpp_f32<0x141>(p);   // row_half_mirror
+        p += dpp_f32<0x140>(p);   // row_mirror
+        if ((l & 15) == 0) part[(32 * mt + frag_row(r, kk)) * PW + w * 2 + ((l >> 4) & 1)] = p;
       }
     }
+    SV_APHASE(5)  // partial norms computed
     __syncthreads();
+    SV_APHASE(6)  // barrier after partial norms
     if (tid < Sc) {
       float sum = 0.f;
-      const int cnt = nwaves * 8;
+      const int cnt = nwaves * 2;
       for (int c = 0; c < cnt; ++c) sum += part[tid * PW + c];
       const float nrm = sqrtf(sum);
       const int sg = s0 + 64 * sc + tid;
       alpha[tid] = gscale[sg] / fmaxf(nrm, 1e-12f);
       if (block_norms) block_norms[(size_t)sg * K + k] = nrm;
     }
+    SV_APHASE(7)  // row sums
     __syncthreads();
+    SV_APHASE(2)  // barrier
     if (dvalid) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -754,8 +976,8 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
             const float a = alpha[row];
             float4 v = make_float4(acc[mt][0][r] * a, acc[mt][1][r] * a, acc[mt][2][r] * a, acc[mt][3][r] * a);
             const size_t o = (size_t)(s0 + 64 * sc + row) * KD + (size_t)k * D + dcol;
-            if (!PLANES || out != nullptr) *reinterpret_cast<float4*>(out + o) = v;
-            if (PLANES) {
+            if ((!PLANES || out != nullptr) && ABL != 2) *reinterpret_cast<float4*>(out + o) = v;
+            if (PLANES && ABL != 2) {
               typedef _Float16 h4 __attribute__((ext_vector_type(4)));
               const float f[4] = {(v.x - mu4.x) * xscale, (v.y - mu4.y) * xscale, (v.z - mu4.z) * xscale, (v.w - mu4.w) * xscale};
               h4 p1, p2;
@@ -771,11 +993,15 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
         }
       }
     }
+    SV_APHASE(3)  // stores issued
     __syncthreads();
+    SV_APHASE(4)  // barrier
+  }
   }
 }
 
-int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
+int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm: label-grouped copy from prep*/,
+                        const uint8_t* /*labels: grouped by prep*/,
                         const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
                         const float* gscale, int B, int N, int SC, float* out, float* block_norms, const float* mean,
                         float xscale, uint16_t* h1, uint16_t* h2) {
@@ -783,15 +1009,43 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, c
   if (nwaves > 12)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: D=%d exceeds the 1536-wide workgroup of this build", D);
   const int Ncap = (N + 2) & ~1;
-  const int PW = nwaves * 8 + 1;
-  const size_t lds = (size_t)Ncap * 16 + (size_t)(64 * PW + 64) * sizeof(float) + 16 * sizeof(int);
+  const int PW = nwaves * 2 + 1;
+  size_t lds = (size_t)Ncap * 16 + (size_t)(64 * PW + 64) * sizeof(float) + 16 * sizeof(int);
+  lds = (lds + 15) & ~(size_t)15;
+  lds += (size_t)nwaves * 6 * 1024;   // DMA queue
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: N=%d tokens need %zu B of LDS (limit 160 KiB)", N, lds);
   auto kern = (h1 != nullptr) ? aggregate_kernel<true> : aggregate_kernel<false>;
+  bool phases = false;
+  if (const char* ab = getenv("SEGVLAD_AGG_ABL")) {
+    if (atoi(ab) == 1) kern = aggregate_kernel<false, 1>;
+    if (atoi(ab) == 2) kern = aggregate_kernel<false, 2>;
+    if (atoi(ab) == 9) {
+      kern = aggregate_kernel<false, 9>;
+      phases = true;
+      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      SV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sv_agg_phase_cycles), z, sizeof(z)));
+    }
+  }
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(K, B), dim3(nwaves * 64), lds, ctx->stream, xt, rnorm, labels, colmask, centres, seg_off_dev,
+  const char* kpe = getenv("SEGVLAD_AGG_KPB");   // clusters per workgroup
+  int kpb = kpe ? atoi(kpe) : 4;
+  if (kpb < 1) kpb = 1;
+  hipLaunchKernelGGL(kern, dim3((K + kpb - 1) / kpb, B), dim3(nwaves * 64), lds, ctx->stream, xt, ctx->s_rnsorted.as<float>(),
+                     ctx->s_tokorder.as<int32_t>(),
+                     ctx->s_laboff.as<int32_t>(), colmask, centres, seg_off_dev,
                      gscale, N, D, K, SC, Ncap, out, block_norms, mean, xscale, reinterpret_cast<_Float16*>(h1),
-                     reinterpret_cast<_Float16*>(h2));
+                     reinterpret_cast<_Float16*>(h2), kpb);
   SV_HIP(hipGetLastError());
+  if (phases) {
+    unsigned long long c8[8];
+    SV_HIP(hipStreamSynchronize(ctx->stream));
+    SV_HIP(hipMemcpyFromSymbol(c8, HIP_SYMBOL(sv_agg_phase_cycles), sizeof(c8)));
+    double tot = 0;
+    for (int q = 0; q < 8; ++q) tot += (double)c8[q];
+    fprintf(stderr, "[aggregate phases] lists %.1f%% main %.1f%% | partial norms %.1f%% barrier %.1f%% row sums %.1f%% barrier %.1f%% | stores %.1f%% barrier %.1f%% (%.0f cycles per (k, image))\n",
+            100 * c8[0] / tot, 100 * c8[1] / tot, 100 * c8[5] / tot, 100 * c8[6] / tot, 100 * c8[7] / tot, 100 * c8[2] / tot,
+            100 * c8[3] / tot, 100 * c8[4] / tot, tot / ((double)K * B));
+  }
   return SEGVLAD_OK;
 }
