@@ -39,18 +39,20 @@ __device__ __forceinline__ bool better(double sa, uint32_t ta, double sb, uint32
   return sa > sb || (sa == sb && ta < tb);
 }
 
-__global__ __launch_bounds__(256) void vote_kernel(const int64_t* __restrict__ idx, const float* __restrict__ sims,
+constexpr int VOTE_THREADS = 1024;
+
+__global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(const int64_t* __restrict__ idx, const float* __restrict__ sims,
                                                    const int32_t* __restrict__ img_of_seg, int64_t n_ref_seg,
                                                    const int32_t* __restrict__ qoff, int k,
                                                    const float* __restrict__ minmax, int n_top, int mode,
                                                    Run* __restrict__ runs_scratch, int64_t runs_stride,
-                                                   int32_t* __restrict__ pred, double* __restrict__ score) {
+                                                   int32_t* __restrict__ pred, double* __restrict__ score, int use_wl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
   __shared__ uint32_t s_nruns;
-  __shared__ double r_score[256];
-  __shared__ uint32_t r_tie[256];
-  __shared__ int r_pos[256];
+  __shared__ double r_score[VOTE_THREADS];
+  __shared__ uint32_t r_tie[VOTE_THREADS];
+  __shared__ int r_pos[VOTE_THREADS];
   const int tid = threadIdx.x;
   const int qi = blockIdx.x;
   const int q0 = qoff[qi], Sq = qoff[qi + 1] - q0;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void vote_kernel(const int64_t* __restrict__ i
   const float den = smax - smin;
 
   // visiting order o = rank * Sq + seg  (rank-major, then segment: func_vpr.py:216 zips the transposed lists)
-  for (int o = tid; o < Epad; o += 256) {
+  for (int o = tid; o < Epad; o += VOTE_THREADS) {
     uint64_t key = ~0ull;
     if (o < E) {
       const int rank = o / Sq, seg = o - rank * Sq;
@@ -71,10 +73,27 @@ __global__ __launch_bounds__(256) void vote_kernel(const int64_t* __restrict__ i
     keys[o] = key;
   }
   if (tid == 0) s_nruns = 0;
-  bitonic_u64(keys, Epad, tid, 256);
+  bitonic_u64(keys, Epad, tid, VOTE_THREADS);
+
+  // the weights of the sorted entries, in parallel (the fp64 run sums below must stay sequential to reproduce the
+  // reference's order of additions; fetching sims[] inside that serial walk was one exposed global load per entry)
+  float* wl = reinterpret_cast<float*>(keys + Epad);   // [E]
+  if (mode == SEGVLAD_VOTE_WT_BORDA_IM && use_wl) {
+    for (int p = tid; p < E; p += VOTE_THREADS) {
+      const uint64_t key = keys[p];
+      float wgt = 0.f;
+      if (key != ~0ull) {
+        const uint32_t o = (uint32_t)key;
+        const int rank = o / Sq, seg = o - rank * Sq;
+        wgt = (sims[(int64_t)(q0 + seg) * k + rank] - smin) / den;
+      }
+      wl[p] = wgt;
+    }
+    __syncthreads();
+  }
 
   Run* runs = runs_scratch + (int64_t)qi * runs_stride;
-  for (int p = tid; p < E; p += 256) {
+  for (int p = tid; p < E; p += VOTE_THREADS) {
     const uint64_t key = keys[p];
     if (key == ~0ull) continue;
     const uint32_t img = (uint32_t)(key >> 32);
@@ -86,11 +105,13 @@ __global__ __launch_bounds__(256) void vote_kernel(const int64_t* __restrict__ i
       const uint64_t ke = keys[e];
       if (ke == ~0ull || (uint32_t)(ke >> 32) != img) break;
       if (mode == SEGVLAD_VOTE_WT_BORDA_IM) {
-        const uint32_t o = (uint32_t)ke;
-        const int rank = o / Sq, seg = o - rank * Sq;
-        const float s = sims[(int64_t)(q0 + seg) * k + rank];
-        const float wgt = (s - smin) / den;
-        acc += (double)wgt;
+        if (use_wl) {
+          acc += (double)wl[e];
+        } else {   // > 8192 entries per image: no room for the weight array
+          const uint32_t o = (uint32_t)ke;
+          const int rank = o / Sq, seg = o - rank * Sq;
+          acc += (double)((sims[(int64_t)(q0 + seg) * k + rank] - smin) / den);
+        }
       }
       ++cnt;
       ++e;
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(256) void vote_kernel(const int64_t* __restrict__ i
     double bs = -INFINITY;
     uint32_t bt = ~0u;
     int bp = -1;
-    for (int j = tid; j < R; j += 256) {
+    for (int j = tid; j < R; j += VOTE_THREADS) {
       const Run r = runs[j];
       if (r.score == -INFINITY) continue;
       if (bp < 0 || better(r.score, r.first, bs, bt)) {
@@ -122,7 +143,7 @@ __global__ __launch_bounds__(256) void vote_kernel(const int64_t* __restrict__ i
     r_tie[tid] = bt;
     r_pos[tid] = bp;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = VOTE_THREADS / 2; o > 0; o >>= 1) {
       if (tid < o) {
         const int pb = r_pos[tid + o];
         if (pb >= 0 && (r_pos[tid] < 0 || better(r_score[tid + o], r_tie[tid + o], r_score[tid], r_tie[tid]))) {
@@ -161,15 +182,17 @@ int sv_launch_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, cons
   const int64_t E = (int64_t)maxS * k;
   int Epad = 2;
   while (Epad < E) Epad <<= 1;
-  const size_t lds = (size_t)Epad * 8;
+  size_t lds = (size_t)Epad * 12;   // sort keys + the entries' weights
+  const int use_wl = lds <= 128 * 1024;
+  if (!use_wl) lds = (size_t)Epad * 8;
   if (lds > 128 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "vote: %d segments x k=%d entries per query image exceed the 16384-entry LDS sort", maxS, k);
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t stride = E > 0 ? E : 1;
   SV_HIP(ctx->s_misc.reserve((size_t)n_img * stride * sizeof(Run)));
-  hipLaunchKernelGGL(vote_kernel, dim3(n_img), dim3(256), lds, ctx->stream, idx, sims, img_of_seg, n_ref_seg, qoff_dev, k,
-                     minmax_dev, n_top, mode, ctx->s_misc.as<Run>(), stride, pred, score);
+  hipLaunchKernelGGL(vote_kernel, dim3(n_img), dim3(VOTE_THREADS), lds, ctx->stream, idx, sims, img_of_seg, n_ref_seg, qoff_dev, k,
+                     minmax_dev, n_top, mode, ctx->s_misc.as<Run>(), stride, pred, score, use_wl);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
