@@ -371,9 +371,10 @@ __device__ unsigned long long sv_f16_phase_cycles[8];
     phase_t0 = now_;                                                                         \
   }
 
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
+    int seq_total,
     float inv_scale, const float* __restrict__ qn, const float* __restrict__ rn, const float* __restrict__ thr,
     int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* __restrict__ cand_cnt,
     float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap) {
@@ -391,24 +392,83 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2); the 32
   // workgroups an XCD runs side by side form one gm x (32/gm) block of tiles, so that they share their query and
   // database rows in that L2 while they march over k (tm-fastest order made every XCD fetch every database row).
-  int tm, tn;
-  if (gm > 0) {
-    const int b = blockIdx.x, xcd = b & 7, s = b >> 3, within = s & 31, st = (s >> 5) * 8 + xcd;
-    const int gn = 32 / gm, sm_cnt = (tiles_m + gm - 1) / gm;
-    tm = (st % sm_cnt) * gm + within % gm;
-    tn = (st / sm_cnt) * gn + within / gm;
-    if (tm >= tiles_m || tn >= (N + BN - 1) / BN) return;
-  } else {
-    tm = blockIdx.x % tiles_m;
-    tn = blockIdx.x / tiles_m;
-  }
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  // PERSIST: 8 x 32 workgroups stay resident and walk their XCD's sequence 32 positions at a time; the head of the next
+  // tile (A(0), B(0), B(1)) is requested before the epilogue of the current one, which hides the ~2 us a fresh
+  // workgroup spends waiting for its first operands (6 % of the kernel: one workgroup per CU, nothing else covers it).
   const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS DMA bases live in M0
   const int wm = w / WN, wn = w % WN;
   const int64_t ldb = (int64_t)d * b_stride;
   const int ntiles = d / HBK;
+  const int tiles_n = (N + BN - 1) / BN;
   auto swz = [](int r, int c) { return CH == 8 ? (c ^ ((r >> 1) & 7)) : (c ^ ((r >> 2) & 3)); };
+  auto tile_of = [&](int sq, int& tm_, int& tn_) -> bool {   // sq: position in this XCD's sequence
+    const int xcd = blockIdx.x & 7, within = sq & 31, st = (sq >> 5) * 8 + xcd;
+    const int gn = 32 / gm, sm_cnt = (tiles_m + gm - 1) / gm;
+    tm_ = (st % sm_cnt) * gm + within % gm;
+    tn_ = (st / sm_cnt) * gn + within / gm;
+    return tm_ < tiles_m && tn_ < tiles_n;
+  };
+  int tm, tn;
+  int seq = (int)(blockIdx.x >> 3);
+  if (PERSIST) {
+    while (seq < seq_total && !tile_of(seq, tm, tn)) seq += 32;
+    if (seq >= seq_total) return;
+  } else if (gm > 0) {
+    if (!tile_of(seq, tm, tn)) return;
+  } else {
+    tm = blockIdx.x % tiles_m;
+    tn = blockIdx.x / tiles_m;
+  }
+  // LDS stages.  Plain: A stages at 0, PA; B stages behind them.  PERSIST (five 32-KiB slots): the first stages of both
+  // operands and B's second sit in slots 3, 4, 2 -- outside the epilogue's scratch (slots 0, 1) -- so that the next
+  // tile's head can land while the epilogue runs.
+  static_assert(!PERSIST || (PA == PB && NB == 3 && 5 * PA <= 160 * 1024), "persistent layout: five equal slots");
+  auto a_off = [](int st_) { return PERSIST ? (st_ == 0 ? 3 * PA : 0) : st_ * PA; };
+  auto b_off = [](int st_) { return PERSIST ? (st_ == 0 ? 4 * PA : (st_ == 1 ? 2 * PA : PA)) : 2 * PA + st_ * PB; };
+  const int lrow_p = l / CH, lch = l % CH;
+  // head of a tile: A(0), B(0) and (NB == 3) B(1), by global->LDS DMA
+  auto issue_head = [&](int tm_, int tn_) {
+    const int64_t m0_ = (int64_t)tm_ * BM, n0_ = (int64_t)tn_ * BN;
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const int row = (w * JA + j) * RP + lrow_p;
+      const int64_t qa = (m0_ + row < M) ? (m0_ + row) : (int64_t)(M - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Qh + qa * d + 8 * swz(row, lch)), (lptr_t)(lds + a_off(0) + (w * JA + j) * 1024), 16,
+                                       0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int row = (w * JB + j) * RP + lrow_p;
+      const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch)), (lptr_t)(lds + b_off(0) + (w * JB + j) * 1024), 16,
+                                       0, 0);
+    }
+    if (NB == 3 && ntiles > 1) {
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const int row = (w * JB + j) * RP + lrow_p;
+        const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch) + HBK),
+                                         (lptr_t)(lds + b_off(1) + (w * JB + j) * 1024), 16, 0, 0);
+      }
+    }
+  };
+  issue_head(tm, tn);
+  if (NB == 3 && ntiles > 1)
+    wait_vm_lgkm0<JB>();
+  else
+    wait_vm_lgkm0<0>();
+  // (the barrier that publishes the head to the other waves is the one at the top of the tile loop)
+
+  for (;;) {   // PERSIST: one iteration per tile; otherwise a single pass
+  __builtin_amdgcn_s_barrier();   // head of this tile landed for every wave; (PERSIST) every wave left the previous epilogue
+  // the lane id is re-derived from an opaque copy in every iteration: otherwise the hundreds of constant addresses of
+  // the unrolled epilogue are hoisted out of the tile loop and spill (713 VGPRs)
+  int lane_opaque = (int)threadIdx.x;
+  asm volatile("" : "+v"(lane_opaque));
+  const int tid = lane_opaque, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -434,7 +494,6 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   }
 
   // per-lane source rows of this wave's DMA pieces (clamped: edge rows are never emitted)
-  const int lrow_p = l / CH, lch = l % CH;
   const uint16_t* srcA[JA];
   const uint16_t* srcB[JB];
 #pragma unroll
@@ -449,8 +508,6 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
     srcB[j] = Rh + rb * ldb + 8 * swz(row, lch);
   }
-  unsigned char* const Abase = lds;
-  unsigned char* const Bbase = lds + 2 * PA;
   constexpr int BAHEAD = NB - 1;  // how many k-tiles ahead the B DMA runs (A always runs one ahead)
   // DMA piece p of iteration kt: pieces 0..JA-1 belong to A(kt+1), JA..JA+JB-1 to B(kt+BAHEAD)
   auto dma_piece = [&](int piece, int kt, int ia_next, int ib_next) {
@@ -458,38 +515,22 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     if (piece < JA) {
       if (kt + 1 < ntiles)
         __builtin_amdgcn_global_load_lds((gptr_t)(srcA[piece] + (kt + 1) * HBK),
-                                         (lptr_t)(Abase + ia_next * PA + (w * JA + piece) * 1024), 16, 0, 0);
+                                         (lptr_t)(lds + a_off(ia_next) + (w * JA + piece) * 1024), 16, 0, 0);
     } else {
       const int j = piece - JA;
       if (kt + BAHEAD < ntiles)
         __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (kt + BAHEAD) * HBK),
-                                         (lptr_t)(Bbase + ib_next * PB + (w * JB + j) * 1024), 16, 0, 0);
+                                         (lptr_t)(lds + b_off(ib_next) + (w * JB + j) * 1024), 16, 0, 0);
     }
   };
-  // prologue: A(0), B(0) [, B(1)]
-#pragma unroll
-  for (int j = 0; j < JA; ++j)
-    __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j]), (lptr_t)(Abase + (w * JA + j) * 1024), 16, 0, 0);
-#pragma unroll
-  for (int j = 0; j < JB; ++j)
-    __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j]), (lptr_t)(Bbase + (w * JB + j) * 1024), 16, 0, 0);
-  if (NB == 3 && ntiles > 1) {
-#pragma unroll
-    for (int j = 0; j < JB; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + HBK), (lptr_t)(Bbase + PB + (w * JB + j) * 1024), 16, 0, 0);
-    wait_vm_lgkm0<JB>();
-  } else {
-    wait_vm_lgkm0<0>();
-  }
-  __builtin_amdgcn_s_barrier();
   SV_PHASE(0)  // prologue: first tiles landed
 
   int ia = 0, ib = 0;
   const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
-    const unsigned char* SA = Abase + ia * PA;
-    const unsigned char* SB = Bbase + ib * PB;
+    const unsigned char* SA = lds + a_off(ia);
+    const unsigned char* SB = lds + b_off(ib);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int cl = 2 * ks + kk;  // logical 16-B chunk (8 consecutive k) of this lane
@@ -539,6 +580,13 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     if (t == 12345.678f) cand_cnt[0] = 1;
     return;
   }
+  // PERSIST: the next tile of this workgroup; its head is requested now and lands under the epilogue
+  int tm_next = 0, tn_next = 0, seq_next = seq_total;
+  if (PERSIST) {
+    seq_next = seq + 32;
+    while (seq_next < seq_total && !tile_of(seq_next, tm_next, tn_next)) seq_next += 32;
+    if (seq_next < seq_total) issue_head(tm_next, tn_next);
+  }
   // ---- epilogue: keep d2~ <= thr + eps_mult * eps(q) -----------------------------------------------------------
   // The epilogue is VALU-issue bound (s_memtime phase timing, SEGVLAD_F16_CFG=90: every instruction of the sparse
   // per-survivor paths is paid by the whole wave), so it is organised around instruction count and everything
@@ -557,7 +605,9 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // query image against the rows of the same place) abandons its list and walks its accumulators directly
   // (per-hit LDS atomics: slow, but only for the handful of dense blocks).  The list order is arbitrary: every
   // consumer ranks or sorts it.
-  constexpr int LCAP = (TM * TN * 256 < 2048) ? TM * TN * 256 : 2048;   // records per wave (a quarter of its elements)
+  // records per wave: a quarter of its elements at most; PERSIST keeps the whole scratch inside LDS slots 0 and 1
+  constexpr int LCAP = PERSIST ? 896 : ((TM * TN * 256 < 2048) ? TM * TN * 256 : 2048);
+  static_assert(!PERSIST || (size_t)BM * 20 + (size_t)BN * 4 + (size_t)NW * (LCAP + 1) * 8 <= 2 * (size_t)PA, "epilogue scratch");
   float4* rrec = reinterpret_cast<float4*>(lds);                         // [BM] {||q||^2, exact limit, screening bound, -}
   uint32_t* rowcnt = reinterpret_cast<uint32_t*>(rrec + BM);             // [BM] survivors per row -> next free global slot
   float* cnl = reinterpret_cast<float*>(rowcnt + BM);                    // [BN] column norms
@@ -653,6 +703,9 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         __builtin_amdgcn_sched_barrier(0);   // keep the 32 row-record loads from being hoisted (register pressure)
       }
   }
+  // PERSIST: this wave's DMA pieces of the next tile's head have landed by now (requested before pass 1; loads retire
+  // in order); the barrier below makes that true for every wave, so the next tile starts without a memory wait
+  if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   SV_PHASE(4)  // pass 2a
   if (tid < BM) {
@@ -699,9 +752,14 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       }
   }
   SV_PHASE(5)  // reservation + pass 2b
+  if (!PERSIST || seq_next >= seq_total) break;
+  seq = seq_next;
+  tm = tm_next;
+  tn = tn_next;
+  }   // tile loop
 }
 
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -710,26 +768,31 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   int64_t tiles = (int64_t)tiles_m * tiles_n;
   const char* gme = getenv("SEGVLAD_F16_GM");  // tile-block height of the XCD-aware order (0 = plain tm-fastest order)
   int gm = gme ? atoi(gme) : 4;
+  if (PERSIST && gm <= 0) gm = 4;
+  int seq_total = 0;
   if (gm > 0) {
     gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
     while (gm > 1 && gm / 2 >= tiles_m) gm >>= 1;
     const int gn = 32 / gm;
     const int64_t st = (int64_t)((tiles_m + gm - 1) / gm) * ((tiles_n + gn - 1) / gn);
     tiles = (st + 7) / 8 * 8 * 32;
+    if (tiles / 8 > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
+    seq_total = (int)(tiles / 8);
+    if (PERSIST) tiles = 256;   // 8 XCDs x 32 resident workgroups, each walks its XCD's sequence
   }
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
   size_t lds = 2 * (size_t)BM * HBK * 2 + (size_t)NB * BN * HBK * 2;  // two A stages + NB B stages
-  {  // epilogue: row records + per-row counters + one survivor list per wave
+  if (!PERSIST) {  // epilogue: row records + per-row counters + one survivor list per wave
     constexpr int TMl = BM / (32 * WM), TNl = BN / (32 * WN);
     constexpr int LCAPl = (TMl * TNl * 256 < 2048) ? TMl * TNl * 256 : 2048;
     const size_t elds = (size_t)BM * 20 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST>;
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
-                     gm, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
+                     gm, seq_total, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -743,6 +806,12 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   const int c = cfg ? atoi(cfg) : (M > 128 ? 0 : 3);
   switch (c) {
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
+    case 200:   // persistent workgroups that request the next tile's head before their epilogue: -4 % on unstructured
+                // data (probe_knn.py), +2 % on the bench's place-structured database (the smaller per-wave hit lists
+                // send more blocks down the dense path) -> not the default
+      if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true>(SV_F16_ARGS);
+      return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);
     case 10: return launch_f16_filter<256, 256, 4, 2, 64, 3, 1>(SV_F16_ARGS);  // ablations of config 0 (WRONG results)
     case 20: return launch_f16_filter<256, 256, 4, 2, 64, 3, 2>(SV_F16_ARGS);
     case 30: return launch_f16_filter<256, 256, 4, 2, 64, 3, 3>(SV_F16_ARGS);
