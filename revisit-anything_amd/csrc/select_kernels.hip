@@ -50,12 +50,16 @@ __device__ __forceinline__ void bitonic_sort_lds(T* a, int n /*pow2*/, int tid, 
   __syncthreads();
 }
 
+// STAGED: the row (n <= 12288 distances: the sampled level of the large-database search) is converted to keys once
+// and kept in LDS, so the four radix passes and the collection pass do not go back to L2/HBM
+template <bool STAGED>
 __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restrict__ dist, int64_t ld, int64_t n, int k,
                                                           int kpad, float* __restrict__ d2_out,
                                                           int64_t* __restrict__ idx_out, int64_t out_ld,
                                                           int64_t id_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* cand = reinterpret_cast<uint64_t*>(smem);  // [kpad]
+  uint32_t* skey = reinterpret_cast<uint32_t*>(cand + kpad);  // [n] when STAGED
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_digit, s_krem, s_ceq, s_nless, s_neq;
   __shared__ uint32_t wcnt[4];
@@ -63,6 +67,11 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
   const int64_t row = blockIdx.x;
   const float* x = dist + row * ld;
   const int kk = (int)((int64_t)k < n ? k : n);
+  if (STAGED) {
+    for (int64_t j = tid; j < n; j += 256) skey[j] = f2key(x[j]);
+    __syncthreads();
+  }
+  auto key_at = [&](int64_t j) -> uint32_t { return STAGED ? skey[j] : f2key(x[j]); };
 
   uint32_t prefix = 0, mask = 0, krem = (uint32_t)kk, ceq = 0;
   if (kk > 0) {
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
       for (int64_t j0 = 0; j0 < n; j0 += 256) {
         const int64_t j = j0 + tid;
         bool act = j < n;
-        uint32_t key = act ? f2key(x[j]) : 0u;
+        uint32_t key = act ? key_at(j) : 0u;
         act = act && ((key & mask) == prefix);
         hist_add(hist, act, (key >> shift) & 255u);
       }
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
       for (int64_t j0 = 0; j0 < n; j0 += 256) {
         const int64_t j = j0 + tid;
         if (j < n) {
-          const uint32_t key = f2key(x[j]);
+          const uint32_t key = key_at(j);
           if (key <= prefix) {
             const uint32_t slot = atomicAdd(&s_nless, 1u);
             cand[slot] = ((uint64_t)key << 32) | (uint32_t)j;
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
       for (int64_t j0 = 0; j0 < n; j0 += 256) {
         const int64_t j = j0 + tid;
         const bool in = j < n;
-        const uint32_t key = in ? f2key(x[j]) : ~0u;
+        const uint32_t key = in ? key_at(j) : ~0u;
         if (in && key < prefix) {
           const uint32_t slot = atomicAdd(&s_nless, 1u);
           cand[slot] = ((uint64_t)key << 32) | (uint32_t)j;
@@ -172,8 +181,12 @@ int sv_launch_select_topk(segvlad_ctx* ctx, const float* dist, int64_t ld, int n
   if (nq <= 0) return SEGVLAD_OK;
   if (n >= (1ll << 32)) return ctx->fail(SEGVLAD_ERR_LIMIT, "select: more than 2^32-1 rows per shard");
   const int kpad = next_pow2(k < 2 ? 2 : k);
-  hipLaunchKernelGGL(select_topk_kernel, dim3(nq), dim3(256), (size_t)kpad * 8, ctx->stream, dist, ld, n, k, kpad, d2_out,
-                     idx_out, out_ld, id_base);
+  if (n <= 12288)
+    hipLaunchKernelGGL(select_topk_kernel<true>, dim3(nq), dim3(256), (size_t)kpad * 8 + (size_t)n * 4, ctx->stream, dist, ld, n, k,
+                       kpad, d2_out, idx_out, out_ld, id_base);
+  else
+    hipLaunchKernelGGL(select_topk_kernel<false>, dim3(nq), dim3(256), (size_t)kpad * 8, ctx->stream, dist, ld, n, k, kpad, d2_out,
+                       idx_out, out_ld, id_base);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
