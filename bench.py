@@ -69,8 +69,8 @@ def pmc_traffic(kernel_prefix: str, workload_key: str):
             continue
         for k in j.get("kernels", []):
             if k["name"].startswith(kernel_prefix):
-                return k["hbm_bytes_per_launch"]
-    return None
+                return k["hbm_bytes_per_launch"], os.path.basename(f) + (": " + j["provenance"] if j.get("provenance") else "")
+    return None, None
 
 
 def parse():
@@ -332,8 +332,9 @@ def main():
         else:
             ach, peak, unit_note = f32_equiv, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA"
         wl_key = f"q{nQ}x{S}_db{nR * S}_d{d_knn}_k{K}_w{world}"
+        traffic, traffic_src = pmc_traffic(kern.split(" ")[0], wl_key)
         roof = {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": pmc_traffic(kern.split(" ")[0], wl_key), "avg_launch_ms": avg_ms, "launches_per_step": launches, "dominant_stage": dom,
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "launches_per_step": launches, "dominant_stage": dom,
                 "arithmetic": unit_note, "fp32_equivalent_tflops": f32_equiv,
                 "fp32_equivalent_vs_fp32_mfma_peak": f32_equiv / PEAK_F32_MFMA_TFLOPS}
     elif dom is not None:
