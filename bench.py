@@ -288,7 +288,7 @@ def main():
 
     # ---- per-stage device time (HIP events on the engine stream, summed over the timed steps) ----------------
     stages = {}
-    for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote"):
+    for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "vote"):
         try:
             ms, n = eng.stage_ms(s)
             stages[s] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps}
@@ -321,8 +321,11 @@ def main():
                     "whitening scale)" if eng_pca_products(K * D, P) == 3 else
                     "gemm_nt_kernel<0> (PCA projection, fp32 MFMA, fused mean-subtract + whitening scale)")
         launches = stages[key]["launches_per_step"]
-        avg_ms = stages[key]["ms_per_step"] / max(launches, 1)
-        f32_equiv = flops_step / (stages[key]["ms_per_step"] * 1e-3) / 1e12
+        avg_ms = stages[key]["ms_per_step"] / max(launches, 1)      # the named kernel's own launches (rocprofv3 "AverageNs")
+        stage_ms_ = stages[key]["ms_per_step"]
+        if key == "knn_gemm" and "knn_level0" in stages:             # + the sampled level's exact fp32 GEMM (another kernel):
+            stage_ms_ += stages["knn_level0"]["ms_per_step"]         #   overhead of the pass, charged to `achieved`
+        f32_equiv = flops_step / (stage_ms_ * 1e-3) / 1e12
         if key == "knn_gemm":
             # the filter GEMM runs on the 16-bit MFMA pipe: PRODUCTS_PER_FMA MFMA products per algorithmic fp32 fma
             prods = eng_filter_products()
@@ -365,6 +368,10 @@ def main():
             eng.search(qd1, 200)
         torch.cuda.synchronize()
         g_ms = eng.stage_ms("knn_gemm")[0] / reps
+        try:
+            g_ms += eng.stage_ms("knn_level0")[0] / reps   # the sampled level's exact fp32 GEMM belongs to the pass
+        except Exception:
+            pass
         s_ms = eng.stage_ms("knn_select")[0] / reps
         eng.set_profiling(False)
         alg = 4.0 * n_local_rows * d_knn + 4.0 * S * d_knn + 8.0 * S * 200     # fp32 DB rows read once

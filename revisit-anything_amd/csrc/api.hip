@@ -790,7 +790,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     float* thr = ctx->s_thr_d2.as<float>();
     {  // level 0: exact (fp32) top-k of the coarsest sample -> thr[q][k-1]
       {
-        StageScope sc(ctx, "knn_gemm");
+        StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
         SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn + q0, rn, (int)stride0));
         sc.count();
       }

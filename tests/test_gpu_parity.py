@@ -435,7 +435,7 @@ def test_knn_dense_block_of_neighbours_in_consecutive_rows(eng):
     eng.set_profiling(True)
     eng.profile_reset()
     d2, idx = (t.cpu().numpy() for t in eng.search(Q, k))
-    launches = eng.stage_ms("knn_gemm")[1]
+    launches = eng.stage_ms("knn_gemm")[1] + eng.stage_ms("knn_level0")[1]
     eng.set_profiling(False)
     rd2, ridx = O().knn_l2(R, Q, k)
     assert launches == 2, launches            # level-0 matrix GEMM + one filter level: no exact-path fall-back

@@ -19,4 +19,8 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / reps
 gm = eng.stage_ms("knn_gemm")[0] / reps
+try:
+    gm += eng.stage_ms("knn_level0")[0] / reps   # the sampled level's exact GEMM (only on the large-database path)
+except Exception:
+    pass
 print(f"search nq={nq} nr={nr} d={d}: wall {dt*1e3:.2f} ms, gemm {gm:.2f} ms -> {2*nq*nr*d/gm/1e9:.1f} TF (algorithmic), select {eng.stage_ms('knn_select')[0]/reps:.2f} ms")
