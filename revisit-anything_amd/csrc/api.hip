@@ -680,13 +680,25 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_TRY(sv_launch_row_sumsq(ctx, (const float*)dq, nq, d, ctx->s_qnorm.as<float>()));
   const float* qn = ctx->s_qnorm.as<float>();
 
-  // level plan: strides 16^L, ..., 16, 1 with the coarsest sample <= 32768 rows (and >= 2048 > k)
+  // level plan: strides 16^L, ..., 16, 1.  The coarsest sample goes through the exact fp32 matrix path (an order of
+  // magnitude dearer per row than the fp16 filter), so take as many levels as keep it selective: a sample of s rows
+  // admits a fraction k/s of the next level, which must stay below the filter's per-wave list capacity (25 % of a
+  // block) -> s >= 4.8 k.  Databases of <= 32768 rows keep the plain matrix path; the sample never exceeds 32768 rows.
+  // (Row shards of 250 k - 500 k rows -- the 1 M-row database on 2 or 4 GPUs -- get two levels instead of a 15 k - 31 k
+  // row exact level.)
   constexpr int RATIO = 16, CAP = 8192;
   int levels = 0;
   int64_t stride0 = 1;
-  while (n / stride0 > 32768) {
-    stride0 *= RATIO;
-    ++levels;
+  if (n > 32768) {
+    const int64_t want = std::max<int64_t>((24 * (int64_t)k + 4) / 5, 512);
+    while (n / (stride0 * RATIO) >= want) {
+      stride0 *= RATIO;
+      ++levels;
+    }
+    while (n / stride0 > 32768) {
+      stride0 *= RATIO;
+      ++levels;
+    }
   }
   if (levels == 0 || n / stride0 < 4 * (int64_t)k) {
     SV_TRY(search_matrix(ctx, (const float*)dq, nq, n, d, k, qn, (float*)dd2, (int64_t*)didx));
