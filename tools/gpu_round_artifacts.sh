@@ -21,11 +21,13 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   cd /tmp && export TMPDIR=/tmp
-  # HBM traffic: one PMC pass per counter (never combined with other trace domains); a small reference set keeps the
-  # database build (thousands of serialised dispatches under counter collection) short
+  # HBM traffic of the dominant kernel: one PMC pass per counter (never combined with other trace domains) over the
+  # SEARCH of the bench workload only (tools/probe_knn.py: 10 000 query segments x 1 M rows x 1024, a few dozen
+  # dispatches) -- counter collection over the whole bench (600 k torch dispatches of the synthetic-image factory)
+  # is what stalled in round 1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -- python $REPO/bench.py --no-cpu-baseline \
-       --steps 2 --warmup 1 --pmc-calibrate > /tmp/prof_$c.json 2> /tmp/prof_$c.err || echo "PMC pass $c: timeout or failure"
+    NR=1000000 NQ=10000 REPS=2 PMC_CAL=1 timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -- \
+       python $REPO/tools/probe_knn.py > /tmp/prof_$c.log 2> /tmp/prof_$c.err || echo "PMC pass $c: timeout or failure"
   done
   ff=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' 2>/dev/null | head -1)
   fw=$(find /tmp/prof_WRITE_SIZE -name '*counter_collection.csv' 2>/dev/null | head -1)

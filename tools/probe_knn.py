@@ -23,4 +23,10 @@ try:
     gm += eng.stage_ms("knn_level0")[0] / reps   # the sampled level's exact GEMM (only on the large-database path)
 except Exception:
     pass
+if os.environ.get("PMC_CAL"):   # known 1 GiB read + 1 GiB write for tools/pmc_summary.py (run under rocprofv3 --pmc)
+    cal = torch.empty(1 << 28, dtype=torch.float32, device=eng.device).normal_()
+    torch.cuda.synchronize()
+    cal2 = cal.sign()
+    torch.cuda.synchronize()
+    del cal, cal2
 print(f"search nq={nq} nr={nr} d={d}: wall {dt*1e3:.2f} ms, gemm {gm:.2f} ms -> {2*nq*nr*d/gm/1e9:.1f} TF (algorithmic), select {eng.stage_ms('knn_select')[0]/reps:.2f} ms")
