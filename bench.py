@@ -233,14 +233,8 @@ def main():
     # ---- one step ---------------------------------------------------------------------------------------------
     def step():
         qd = pipe.describe(q_tok, q_msk, q_off_local)
-        if world > 1:
-            rows = [int(qb[r + 1] - qb[r]) * S for r in range(world)]
-            mx = max(rows)
-            if qd.shape[0] < mx:   # all_gather needs equal shapes: pad the short slices
-                qd = torch.cat([qd, qd.new_zeros((mx - qd.shape[0], P))])
-            parts = [torch.empty((mx, P), device=dev) for _ in range(world)]
-            dist.all_gather(parts, qd.contiguous())
-            qd = torch.cat([p_[:n_] for p_, n_ in zip(parts, rows)])
+        if world > 1:   # every rank needs all query descriptors: one all_gather of the ragged slices
+            qd = index.gather_rows(qd, [int(qb[r + 1] - qb[r]) * S for r in range(world)])
         return index.retrieve(qd, q_off_all, 200, 50, 5)
 
     def fence():

@@ -77,6 +77,26 @@ class ShardedSegmentIndex:
     def n_total(self) -> int:
         return int(self.row_start[-1])
 
+    # ---- query descriptors: every rank describes a slice of the query images, all ranks need all rows -----------
+    def gather_rows(self, local_rows: torch.Tensor, rows_per_rank: Sequence[int]) -> torch.Tensor:
+        """Concatenation, in rank order, of every rank's ``local_rows`` ([rows_per_rank[r], d]) -- one all_gather
+        (RCCL over xGMI with the nccl backend).  Slices may be ragged: short ones are padded to the longest for the
+        collective and trimmed afterwards."""
+        rows_per_rank = [int(r) for r in rows_per_rank]
+        if len(rows_per_rank) != self.world:
+            raise ValueError("rows_per_rank must have one entry per rank")
+        if int(local_rows.shape[0]) != rows_per_rank[self.rank]:
+            raise ValueError(f"rank {self.rank} holds {int(local_rows.shape[0])} rows, rows_per_rank says {rows_per_rank[self.rank]}")
+        if self.world == 1:
+            return local_rows
+        mx = max(rows_per_rank)
+        x = local_rows.contiguous()
+        if x.shape[0] < mx:
+            x = torch.cat([x, x.new_zeros((mx - x.shape[0],) + tuple(x.shape[1:]))])
+        parts = [torch.empty_like(x) for _ in range(self.world)]
+        dist.all_gather(parts, x, group=self.group)
+        return torch.cat([p[:n] for p, n in zip(parts, rows_per_rank)])
+
     # ---- query --------------------------------------------------------------------------------------
     def search(self, Q, k: int, k_local: Optional[int] = None):
         """Global top-k over all shards: (d2 [nq,k] ascending, idx [nq,k] GLOBAL ids), identical on every rank.

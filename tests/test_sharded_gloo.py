@@ -76,8 +76,14 @@ def worker(rank, world, port, out_dir):
     idx.build(R[rows], img[rows])
     assert idx.n_total == R.shape[0] and int(idx.row_start[rank]) == rows.start
     assert np.array_equal(idx.img_of_seg_global.numpy(), img)
-    d2, ids = idx.search(Q, 20)
-    pred, sc, m, sims = idx.retrieve(Q, off, k_search=20, k_vote=10, n_top=3, want_scores=True)
+    # every rank "describes" a ragged slice of the query rows (as bench.py does per query image); gather_rows must hand
+    # every rank the full matrix in rank order
+    qb = shard_images(Q.shape[0], world) if Q.shape[0] % 7 else (shard_images(Q.shape[0] // 7, world) * 7)
+    q_local = torch.from_numpy(Q[qb[rank]:qb[rank + 1]])
+    Qg = idx.gather_rows(q_local, [int(qb[r + 1] - qb[r]) for r in range(world)])
+    assert np.array_equal(Qg.numpy(), Q)
+    d2, ids = idx.search(Qg, 20)
+    pred, sc, m, sims = idx.retrieve(Qg, off, k_search=20, k_vote=10, n_top=3, want_scores=True)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), d2=d2.numpy(), ids=ids.numpy(), pred=pred.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -91,8 +97,11 @@ def free_port():
     return p
 
 
-def test_two_rank_gloo_equals_single_index(tmp_path):
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_gloo_equals_single_index(tmp_path, world):
     mp.spawn(worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     from oracle import segvlad_oracle as O
 
@@ -115,6 +124,9 @@ def test_single_process_fallback_has_no_collective():
     R, img, Q, tau, off = make_problem()
     idx = ShardedSegmentIndex(OracleBackend(), rank=0, world=1)
     idx.build(R, img)
+    assert idx.gather_rows(torch.from_numpy(Q), [Q.shape[0]]).shape == Q.shape
+    with pytest.raises(ValueError):
+        idx.gather_rows(torch.from_numpy(Q), [Q.shape[0] - 1])
     d2, ids = idx.search(Q, 5)
     from oracle import segvlad_oracle as O
 
