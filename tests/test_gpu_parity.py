@@ -529,14 +529,17 @@ def test_pipeline_device_adjacency_equals_host_qhull(eng):
     assert np.array_equal(d_dev, d_host)
 
 
-def test_knn_bf16_path_two_levels_unit_vectors(eng):
-    """> 524288 rows: two filter levels (strides 256, 16, 1); unit-norm 128-d rows like the PCA'd descriptors.
+@pytest.mark.parametrize("n", [600000, 250000])
+def test_knn_bf16_path_two_levels_unit_vectors(eng, n):
+    """Two filter levels (strides 256, 16, 1); unit-norm 128-d rows like the PCA'd descriptors.  600 000 rows: the
+    sample of 2343 rows admits 8.5 % of the next level; 250 000 rows (the 1 M-row database on 4 GPUs): the level plan's
+    smallest sample for k = 200, 976 rows, admits 20.5 % -- just below the filter's per-wave list capacity.
     The fp16 and the bf16x3 filters (+ fp32 refinement) must reproduce the all-fp32 path bit for bit."""
     import torch
 
     g = torch.Generator(device=eng.device)
     g.manual_seed(7)
-    n, d, nq, k = 600000, 128, 64, 200
+    d, nq, k = 128, 64, 200
     R = torch.nn.functional.normalize(torch.randn(n, d, device=eng.device, generator=g), dim=1)
     Q = torch.nn.functional.normalize(R[torch.randint(0, n, (nq,), device=eng.device, generator=g)] +
                                       0.3 * torch.randn(nq, d, device=eng.device, generator=g) / d ** 0.5, dim=1)
