@@ -895,7 +895,9 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
       unsigned char* qbase = xq + (size_t)__builtin_amdgcn_readfirstlane(w) * (QD * 1024);   // wave-uniform: lives in M0
       auto issue = [&](int p) {
         const int t = tokl[2 * p + kk];
-        __builtin_amdgcn_global_load_lds((agg_gptr_t)(Xb + (size_t)t * D), (agg_lptr_t)(qbase + (p % QD) * 1024), 16, 0, 0);
+        // lanes beyond D (a partial last wave) fetch a valid dummy address: their 16 B are never used
+        const float* src = dvalid ? Xb + (size_t)t * D : Xt;
+        __builtin_amdgcn_global_load_lds((agg_gptr_t)src, (agg_lptr_t)(qbase + (p % QD) * 1024), 16, 0, 0);
       };
       if (ABL != 1)
         for (int q = 0; q < QD && q < npairs; ++q) issue(q);
