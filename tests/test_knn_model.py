@@ -1,0 +1,97 @@
+"""NumPy model of the mixed-precision leveled search: real fp16 operand rounding, fp32 accumulation,
+the margins and threshold rules of csrc/api.hip -- and the claim that the refined result equals the exact fp32 top-k.
+This checks the MATH on the CPU (the kernels themselves are checked bit for bit in tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+
+def pow2_scale(maxabs):
+    if not (maxabs > 0 and np.isfinite(maxabs)):
+        return 1.0
+    m, e = np.frexp(np.float32(maxabs))
+    return float(np.ldexp(1.0, 14 - int(e)))
+
+
+def exact_d2(Q, R):
+    """fp32 distances as the matrix path forms them: fma(-2, q.r, q2 + r2) with an fp32 dot product."""
+    q2 = (Q * Q).sum(1, dtype=np.float32)
+    r2 = (R * R).sum(1, dtype=np.float32)
+    dot = (Q @ R.T).astype(np.float32)
+    return (q2[:, None] + r2[None, :]) - np.float32(2) * dot, q2, r2
+
+
+def approx_d2(Q, R, q2, r2):
+    sq, sr = pow2_scale(np.abs(Q).max()), pow2_scale(np.abs(R).max())
+    Qh = (Q * np.float32(sq)).astype(np.float16).astype(np.float32)
+    Rh = (R * np.float32(sr)).astype(np.float16).astype(np.float32)
+    dot = (Qh @ Rh.T).astype(np.float32) * np.float32(1.0 / (sq * sr))
+    return (q2[:, None] + r2[None, :]) - np.float32(2) * dot
+
+
+def leveled_search(Q, R, k, ratio=16):
+    """One sampled exact level + one fp16 filter level over all rows + exact refinement (the two-level plan adds an
+    approximate level in between: same rule with eps_mult = 2)."""
+    n, d = R.shape
+    D, q2, r2 = exact_d2(Q, R)
+    Dt = approx_d2(Q, R, q2, r2)
+    c_eps = 2.5 * (2.0 ** -10 + 2.0 ** -22 + 2.0 * d * 2.0 ** -24)
+    eps = c_eps * np.sqrt(q2 * r2.max())
+    out_d, out_i, n_ref = [], [], []
+    for qi in range(Q.shape[0]):
+        sample = np.arange(0, n, ratio * ratio)
+        T0 = np.sort(D[qi, sample])[k - 1]                        # exact k-th of the coarsest sample
+        mid = np.arange(0, n, ratio)                              # approximate level (stride 16)
+        c1 = mid[Dt[qi, mid] <= T0 + eps[qi]]
+        A1 = np.sort(Dt[qi, c1])[k - 1]
+        c2 = np.nonzero(Dt[qi] <= A1 + 2 * eps[qi])[0]            # last level: every row
+        A2 = np.sort(Dt[qi, c2])[k - 1]
+        ref = c2[Dt[qi, c2] <= A2 + 2 * eps[qi]]                  # refine list
+        order = np.lexsort((ref, D[qi, ref]))[:k]
+        out_d.append(D[qi, ref][order])
+        out_i.append(ref[order])
+        n_ref.append(len(ref))
+    return np.array(out_d), np.array(out_i), np.array(n_ref), D
+
+
+def brute(D, k):
+    idx = np.array([np.lexsort((np.arange(D.shape[1]), D[i]))[:k] for i in range(D.shape[0])])
+    return np.take_along_axis(D, idx, 1), idx
+
+
+@pytest.mark.parametrize("case", ["unit_random", "near_duplicates", "mixed_norms"])
+def test_leveled_fp16_search_model_is_exact(case):
+    rng = np.random.Generator(np.random.PCG64(77))
+    n, d, nq, k = 12000, 64, 24, 20
+    R = rng.standard_normal((n, d)).astype(np.float32)
+    if case == "unit_random":
+        R /= np.linalg.norm(R, axis=1, keepdims=True)
+        Q = R[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d)).astype(np.float32) / np.sqrt(d)
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    elif case == "near_duplicates":                      # many rows within the fp16 margin of the k-th distance
+        R /= np.linalg.norm(R, axis=1, keepdims=True)
+        base = R[:40].copy()
+        R[1000:1000 + 40 * 50] = (base[:, None, :] + 2e-4 * rng.standard_normal((40, 50, d))).reshape(-1, d)
+        R = R.astype(np.float32)
+        Q = (base[:nq] + 1e-4 * rng.standard_normal((nq, d))).astype(np.float32)
+    else:                                                # rows of different norms (the margin uses max ||r||)
+        R *= rng.uniform(0.2, 3.0, (n, 1)).astype(np.float32)
+        Q = (R[rng.integers(0, n, nq)] * 0.9 + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    d_l, i_l, n_ref, D = leveled_search(Q, R, k)
+    d_b, i_b = brute(D, k)
+    assert np.array_equal(d_l, d_b)
+    assert np.array_equal(i_l, i_b)
+    assert n_ref.min() >= k                              # the refine list always holds at least the answer
+
+
+def test_margin_bounds_the_observed_fp16_error():
+    """|d2~ - d2| <= 2 delta ||q|| ||r|| with delta = 2^-10 + 2^-22 + 2 d 2^-24, on data that stresses the rounding."""
+    rng = np.random.Generator(np.random.PCG64(78))
+    for d in (64, 1024):
+        R = (rng.standard_normal((2000, d)) * rng.uniform(0.5, 2.0, (2000, 1))).astype(np.float32)
+        Q = (rng.standard_normal((50, d))).astype(np.float32)
+        D, q2, r2 = exact_d2(Q, R)
+        Dt = approx_d2(Q, R, q2, r2)
+        delta = 2.0 ** -10 + 2.0 ** -22 + 2.0 * d * 2.0 ** -24
+        bound = 2 * delta * np.sqrt(q2[:, None] * r2[None, :])
+        assert (np.abs(Dt - D) <= bound).all()
+        assert np.abs(Dt - D).max() > 0                   # the approximation is really approximate
