@@ -95,3 +95,35 @@ def test_margin_bounds_the_observed_fp16_error():
         bound = 2 * delta * np.sqrt(q2[:, None] * r2[None, :])
         assert (np.abs(Dt - D) <= bound).all()
         assert np.abs(Dt - D).max() > 0                   # the approximation is really approximate
+
+
+def test_two_term_fp16_split_projection_is_fp32_class():
+    """The PCA projection's arithmetic (gemm_f16x3_kernels.hip): x*s = h1 + h2 (two fp16 terms), products
+    h1.g1 + h1.g2 + h2.g1 accumulated in fp32.  Its error against float64 must be of the order of a plain fp32
+    GEMM's, not of fp16's (2^-11)."""
+    rng = np.random.Generator(np.random.PCG64(79))
+    n, kd, p = 64, 8192, 48
+    X = rng.standard_normal((n, kd)).astype(np.float32)
+    X[:, ::5] *= 1e-3                                            # wide dynamic range inside a row
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    mean = (0.01 * rng.standard_normal(kd)).astype(np.float32)
+    W = (rng.standard_normal((p, kd)) / np.sqrt(kd)).astype(np.float32)
+
+    def split(a, scale):
+        f = a * np.float32(scale)
+        h1 = f.astype(np.float16).astype(np.float32)
+        h2 = (f - h1).astype(np.float16).astype(np.float32)
+        return h1, h2
+
+    sx = pow2_scale(np.abs(X).max() + np.abs(mean).max())
+    sw = pow2_scale(np.abs(W).max())
+    a1, a2 = split(X - mean, sx)
+    b1, b2 = split(W, sw)
+    y3 = ((a1 @ b1.T).astype(np.float32) + (a1 @ b2.T).astype(np.float32) + (a2 @ b1.T).astype(np.float32)) / np.float32(sx * sw)
+    y32 = ((X - mean) @ W.T).astype(np.float32)
+    ref = (X.astype(np.float64) - mean.astype(np.float64)) @ W.astype(np.float64).T
+    scale = np.abs(ref).max()
+    e3, e32 = np.abs(y3 - ref).max() / scale, np.abs(y32 - ref).max() / scale
+    e16 = np.abs((a1 @ b1.T) / (sx * sw) - ref).max() / scale       # single fp16 product, for contrast
+    assert e3 < 2e-6 and e3 < 8 * e32 + 1e-7, (e3, e32)
+    assert e16 > 20 * e3                                             # one product alone is fp16-class
