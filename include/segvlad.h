@@ -162,7 +162,7 @@ int segvlad_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const 
                  int32_t* pred_out, double* score_out);
 
 /* ---- instrumentation: with profiling on, every kernel group of a stage ("incidence", "adjacency",
- *      "assign", "prep", "aggregate", "pca", "knn_gemm", "knn_select", "vote") is bracketed by a HIP event pair
+ *      "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "knn_fallback", "vote") is bracketed by a HIP event pair
  *      on the context stream.  segvlad_stage_ms returns the SUM of the elapsed times (ms) and the number
  *      of kernel launches recorded for the stage since the last segvlad_profile_reset; it returns
  *      SEGVLAD_ERR_STATE if the stage has not run.  Replaces the (discarded) time.time() pair of
@@ -170,6 +170,27 @@ int segvlad_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const 
 int segvlad_set_profiling(segvlad_ctx* ctx, int on);
 int segvlad_profile_reset(segvlad_ctx* ctx);
 int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* launches_out);
+
+/* ---- switches (no reference counterpart: the reference has one arithmetic, fp32/fp64 torch + faiss).
+ *      Read ONCE: the environment variables SEGVLAD_KNN_FILTER / SEGVLAD_KNN_FP32 / SEGVLAD_PCA_FP32 /
+ *      SEGVLAD_F16_CFG / ... give a context its defaults at segvlad_create; this call overrides them.
+ *      None of them changes a result: every kNN filter is followed by the exact fp32 refinement and
+ *      the PCA variants are both fp32-class (tests assert bit-equality / tolerance between them).
+ *        "knn_filter"   auto | f16 | bf16x3 | fp32     arithmetic of the candidate filter GEMM
+ *        "pca_arith"    auto | f16x3 | fp32            projection GEMM arithmetic
+ *        "search_stats" 0 | 1                          record list occupancies (segvlad_search_stats)
+ *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning   */
+int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
+
+/* ---- statistics of the last segvlad_search on this context (HOST array, up to 8 values):
+ *      [0] filter levels run after the sampled exact level (0 = distance-matrix path)
+ *      [1] filter arithmetic used (0 none, 1 f16, 2 bf16x3, 3 fp32)
+ *      [2] query rows whose candidate / refine list overflowed and that were redone, alone, on the
+ *          exact distance-matrix path (the other rows keep their filtered result)
+ *      [3] max and [4] sum of the last level's candidate-list lengths   (option search_stats = 1)
+ *      [5] max and [6] sum of the exact-refinement list lengths         (option search_stats = 1)
+ *      [7] number of query rows                                                                       */
+int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n);
 
 #ifdef __cplusplus
 }

@@ -240,6 +240,39 @@ def normalize_feat(rfts):
 # --------------------------------------------------------------------------------------------
 # a10  exact kNN (faiss.IndexFlatL2 semantics restated)    place_rec_main.py:53-60
 # --------------------------------------------------------------------------------------------
+def l2_matrix(R, Q, rows_block=0):
+    """[nq, nr] squared L2 distances: inputs coerced to fp32 (as faiss does), evaluated in fp64, rounded to fp32.
+    rows_block > 0 bounds the fp64 copy of R (large databases)."""
+    R32 = np.ascontiguousarray(R, dtype=np.float32)
+    q = np.ascontiguousarray(Q, dtype=np.float32).astype(np.float64)
+    q2 = (q * q).sum(1)[:, None]
+    nr = R32.shape[0]
+    out = np.empty((q.shape[0], nr), dtype=np.float32)
+    step = rows_block if rows_block > 0 else max(nr, 1)
+    for a in range(0, nr, step):
+        Rd = R32[a:a + step].astype(np.float64)
+        out[:, a:a + step] = (q2 + (Rd * Rd).sum(1)[None, :] - 2.0 * (q @ Rd.T)).astype(np.float32)
+    return out
+
+
+def topk_from_d2(d2, k):
+    """Ascending top-k of each row of a distance matrix, ties -> lower index (a stable argsort's first k columns),
+    found by partition + sort of the tie-complete candidate set; rows with fewer than k columns pad with (inf, -1)."""
+    nq, nr = d2.shape
+    D2 = np.full((nq, k), np.inf, dtype=np.float32)
+    I = np.full((nq, k), -1, dtype=np.int64)
+    kk = min(k, nr)
+    if kk == 0:
+        return D2, I
+    kth = np.partition(d2, kk - 1, axis=1)[:, kk - 1]
+    for r in range(nq):
+        cand = np.nonzero(d2[r] <= kth[r])[0]                       # ascending ids, includes every boundary tie
+        order = cand[np.argsort(d2[r, cand], kind="stable")][:kk]
+        D2[r, :kk] = d2[r, order]
+        I[r, :kk] = order
+    return D2, I
+
+
 def knn_l2(R, Q, k, block=2048):
     """Exact squared-L2 top-k, ascending, ties -> lower index.  Inputs are coerced to fp32 (as
     faiss does), distances evaluated in fp64 and rounded to fp32.  Rows beyond n_r are (inf, -1)."""

@@ -49,6 +49,8 @@ SIGNATURES = {
     "segvlad_set_profiling": (C.c_int, [c_ctx_p, C.c_int]),
     "segvlad_profile_reset": (C.c_int, [c_ctx_p]),
     "segvlad_stage_ms": (C.c_int, [c_ctx_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "segvlad_set_option": (C.c_int, [c_ctx_p, C.c_char_p, C.c_char_p]),
+    "segvlad_search_stats": (C.c_int, [c_ctx_p, C.POINTER(C.c_int64), C.c_int]),
 }
 
 _lib = None

@@ -39,6 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
                "-c", os.path.join(CSRC, src), "-o", obj]
+        if os.environ.get("SEGVLAD_BUILD_ABLATIONS"):   # development only: timing ablations with WRONG results
+            cmd.insert(1, "-DSEGVLAD_ABLATIONS")
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

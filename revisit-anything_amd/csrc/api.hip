@@ -100,7 +100,7 @@ StageScope::~StageScope() {
 
 extern "C" {
 
-int segvlad_version(void) { return 100; }
+int segvlad_version(void) { return 200; }
 
 int segvlad_create(segvlad_ctx** out, int device_id) {
   if (!out) return SEGVLAD_ERR_ARG;
@@ -111,7 +111,63 @@ int segvlad_create(segvlad_ctx** out, int device_id) {
   segvlad_ctx* c = new (std::nothrow) segvlad_ctx();
   if (!c) return SEGVLAD_ERR_NOMEM;
   c->device = device_id;
+  // environment defaults of the tuning switches, read once here (segvlad_set_option overrides them later)
+  static const char* const env_keys[][2] = {{"SEGVLAD_KNN_FILTER", "knn_filter"},   {"SEGVLAD_F16_CFG", "f16_cfg"},
+                                            {"SEGVLAD_F16_GM", "f16_gm"},           {"SEGVLAD_X3_TILE", "x3_tile"},
+                                            {"SEGVLAD_X3_GM", "x3_gm"},             {"SEGVLAD_SEARCH_STATS", "search_stats"},
+                                            {"SEGVLAD_ASSIGN_NARROW", "assign_narrow"}, {"SEGVLAD_DEBUG_SEARCH", "debug_search"},
+                                            {"SEGVLAD_AGG_KPB", "agg_kpb"}};
+  for (auto& kv : env_keys)
+    if (const char* v = getenv(kv[0])) (void)segvlad_set_option(c, kv[1], v);
+  if (getenv("SEGVLAD_KNN_FP32")) (void)segvlad_set_option(c, "knn_filter", "fp32");
+  if (getenv("SEGVLAD_PCA_FP32")) (void)segvlad_set_option(c, "pca_arith", "fp32");
+  c->err[0] = 0;
   *out = c;
+  return SEGVLAD_OK;
+}
+
+int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
+  if (!ctx) return SEGVLAD_ERR_ARG;
+  if (!key || !value) return ctx->fail(SEGVLAD_ERR_ARG, "set_option: null key/value");
+  SvOptions& o = ctx->opt;
+  auto as_int = [&](int* dst) -> int {
+    char* end = nullptr;
+    const long v = strtol(value, &end, 10);
+    if (end == value || *end) return ctx->fail(SEGVLAD_ERR_ARG, "set_option(%s): '%s' is not an integer", key, value);
+    *dst = (int)v;
+    return SEGVLAD_OK;
+  };
+  if (!strcmp(key, "knn_filter")) {
+    if (!strcmp(value, "auto")) o.knn_filter = 0;
+    else if (!strcmp(value, "f16")) o.knn_filter = 1;
+    else if (!strcmp(value, "bf16x3")) o.knn_filter = 2;
+    else if (!strcmp(value, "fp32")) o.knn_filter = 3;
+    else return ctx->fail(SEGVLAD_ERR_ARG, "set_option(knn_filter): want auto|f16|bf16x3|fp32, got '%s'", value);
+    return SEGVLAD_OK;
+  }
+  if (!strcmp(key, "pca_arith")) {
+    if (!strcmp(value, "auto") || !strcmp(value, "f16x3")) o.pca_fp32 = 0;
+    else if (!strcmp(value, "fp32")) o.pca_fp32 = 1;
+    else return ctx->fail(SEGVLAD_ERR_ARG, "set_option(pca_arith): want auto|f16x3|fp32, got '%s'", value);
+    return SEGVLAD_OK;
+  }
+  if (!strcmp(key, "f16_cfg")) return as_int(&o.f16_cfg);
+  if (!strcmp(key, "f16_gm")) return as_int(&o.f16_gm);
+  if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);
+  if (!strcmp(key, "x3_gm")) return as_int(&o.x3_gm);
+  if (!strcmp(key, "search_stats")) return as_int(&o.search_stats);
+  if (!strcmp(key, "assign_narrow")) return as_int(&o.assign_narrow);
+  if (!strcmp(key, "agg_kpb")) return as_int(&o.agg_kpb);
+  if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
+  return ctx->fail(SEGVLAD_ERR_ARG, "set_option: unknown key '%s'", key);
+}
+
+int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n) {
+  if (!ctx) return SEGVLAD_ERR_ARG;
+  if (!stats_out || n < 0) return ctx->fail(SEGVLAD_ERR_ARG, "search_stats: bad arguments");
+  const SvSearchStats& t = ctx->sstats;
+  const int64_t v[8] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries};
+  for (int j = 0; j < n && j < 8; ++j) stats_out[j] = v[j];
   return SEGVLAD_OK;
 }
 
@@ -125,7 +181,9 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff, &ctx->s_cand_cnt, &ctx->s_cand_d2,
                     &ctx->s_cand_id, &ctx->s_thr_d2, &ctx->s_thr_idx, &ctx->s_flag,   &ctx->s_qh,     &ctx->s_ql,
                     &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo,    &ctx->db_f16,   &ctx->s_qf16,
-                    &ctx->pca_w1,    &ctx->pca_w2,   &ctx->s_xh1,     &ctx->s_xh2};
+                    &ctx->pca_w1,    &ctx->pca_w2,   &ctx->s_xh1,     &ctx->s_xh2,    &ctx->s_desc,   &ctx->s_tokorder,
+                    &ctx->s_laboff,  &ctx->s_rnsorted, &ctx->s_ovf,   &ctx->s_fb_q,   &ctx->s_fb_d2,  &ctx->s_fb_idx,
+                    &ctx->s_fb_rows};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -409,7 +467,7 @@ int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
                      ctx->K * ctx->D);
   if (B > 0 && seg_offsets && !sv_is_device_ptr(seg_offsets) && seg_offsets[B] > 0 && !y)
     return ctx->fail(SEGVLAD_ERR_ARG, "images_pca: null y");
-  const bool x3 = ctx->pca_w_scale > 0.f && getenv("SEGVLAD_PCA_FP32") == nullptr;
+  const bool x3 = ctx->pca_w_scale > 0.f && !ctx->opt.pca_fp32;
   if (x3) return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc_out, labels_out, gap_out, nullptr, y, l2norm);
   // shapes the split GEMM does not take (or the fp32 knob): descriptor to HBM, then the plain projection
   if (B <= 0 || !seg_offsets || sv_is_device_ptr(seg_offsets))
@@ -522,7 +580,7 @@ int segvlad_pca_apply(segvlad_ctx* ctx, const float* X, int n, float* Y, int l2n
   void* dy;
   SV_TRY(sv_in(ctx, X, (size_t)n * ctx->KD * sizeof(float), &dx));
   SV_TRY(sv_out(ctx, Y, (size_t)n * ctx->P * sizeof(float), &dy));
-  const bool x3 = ctx->pca_w_scale > 0.f && getenv("SEGVLAD_PCA_FP32") == nullptr;
+  const bool x3 = ctx->pca_w_scale > 0.f && !ctx->opt.pca_fp32;
   float xscale = 1.f;
   if (x3) {  // scale so that |x - mean| * s < 2^15: no fp16 overflow, sub-normal losses far below fp32 epsilon
     float xmax = 0.f;
@@ -637,8 +695,8 @@ int segvlad_db_size(segvlad_ctx* ctx, int64_t* n_rows, int* d) {
 // exact UPPER bound T0[q] of the k-th smallest distance; each finer level re-runs the distance GEMM with the
 // epilogue keeping only entries <= T[q] (about 16 k per query), whose exact top-k tightens T for the next level;
 // the last level covers every row, so the final top-k is exact (ties included: all entries <= T are candidates
-// and the final order is (distance, id)).  If a candidate list overflows (adversarial data) the chunk is redone
-// on the matrix path.
+// and the final order is (distance, id)).  A query whose candidate or refine list overflows (adversarial data) is
+// redone -- alone -- on the matrix path; the other queries keep their filtered result.
 static int search_matrix(segvlad_ctx* ctx, const float* dq, int m, int64_t n, int d, int k, const float* qn, float* dd2,
                          int64_t* didx) {
   const int64_t ld = (n + 3) & ~3ll;
@@ -663,6 +721,26 @@ static int search_matrix(segvlad_ctx* ctx, const float* dq, int m, int64_t n, in
   return SEGVLAD_OK;
 }
 
+// rows of the overflow fallback: gather flagged query rows into a dense block, scatter their results back
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, const float* __restrict__ xn,
+                                                          const int32_t* __restrict__ rows, int d, float* __restrict__ Y,
+                                                          float* __restrict__ yn) {
+  const int r = blockIdx.x;
+  const int64_t src = rows[r];
+  for (int j = threadIdx.x; j < d; j += 256) Y[(int64_t)r * d + j] = X[src * d + j];
+  if (threadIdx.x == 0) yn[r] = xn[src];
+}
+__global__ __launch_bounds__(256) void scatter_topk_kernel(const float* __restrict__ d2, const int64_t* __restrict__ idx,
+                                                           const int32_t* __restrict__ rows, int k, float* __restrict__ d2_out,
+                                                           int64_t* __restrict__ idx_out) {
+  const int r = blockIdx.x;
+  const int64_t dst = rows[r];
+  for (int j = threadIdx.x; j < k; j += 256) {
+    d2_out[dst * k + j] = d2[(int64_t)r * k + j];
+    idx_out[dst * k + j] = idx[(int64_t)r * k + j];
+  }
+}
+
 int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_out, int64_t* idx_out) {
   CHECK_CTX();
   if (nq < 0 || k < 1 || k > 1024) return ctx->fail(SEGVLAD_ERR_ARG, "search: need nq>=0 and 1<=k<=1024 (k=%d)", k);
@@ -679,6 +757,8 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_HIP(ctx->s_qnorm.reserve((size_t)nq * 4));
   SV_TRY(sv_launch_row_sumsq(ctx, (const float*)dq, nq, d, ctx->s_qnorm.as<float>()));
   const float* qn = ctx->s_qnorm.as<float>();
+  ctx->sstats = SvSearchStats();
+  ctx->sstats.n_queries = nq;
 
   // level plan: strides 16^L, ..., 16, 1.  The coarsest sample goes through the exact fp32 matrix path (an order of
   // magnitude dearer per row than the fp16 filter), so take as many levels as keep it selective: a sample of s rows
@@ -707,12 +787,13 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   const float* R = ctx->db_rows.as<float>();
   const float* rn = ctx->db_norms.as<float>();
   const int chunk = 4096;
-  // filter arithmetic: "f16" (one fp16 product, d % 64 == 0), "bf16x3" (three bf16 products, d % 32 == 0), or
-  // plain fp32 (SEGVLAD_KNN_FP32=1 or unsupported d)
-  const char* fsel = getenv("SEGVLAD_KNN_FILTER");
-  const bool no16 = getenv("SEGVLAD_KNN_FP32") != nullptr;
-  const bool f16_path = !no16 && (d % 64 == 0) && !(fsel && strcmp(fsel, "bf16x3") == 0);
-  const bool bf16_path = !no16 && !f16_path && (d % 32 == 0);
+  // filter arithmetic (ctx->opt.knn_filter, see SvOptions): "f16" = one fp16 product (d % 64 == 0), "bf16x3" = three
+  // bf16 products (d % 32 == 0), else plain fp32
+  const int want_f = ctx->opt.knn_filter;
+  const bool f16_path = (want_f == 0 || want_f == 1) && (d % 64 == 0);
+  const bool bf16_path = !f16_path && want_f != 3 && (d % 32 == 0);
+  ctx->sstats.levels = levels;
+  ctx->sstats.filter = f16_path ? 1 : bf16_path ? 2 : 3;
   constexpr int RCAP = 512;
   float rn_max = 0.f, c_eps = 0.f, inv_scale = 1.f;
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
@@ -791,11 +872,16 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_HIP(ctx->s_cand_id.reserve((size_t)chunk * CAP * 4));
   SV_HIP(ctx->s_thr_d2.reserve((size_t)chunk * k * 4));
   SV_HIP(ctx->s_thr_idx.reserve((size_t)chunk * k * 8));
-  SV_HIP(ctx->s_flag.reserve(64));
-  SV_HIP(hipMemsetAsync(ctx->s_flag.p, 0, 4, ctx->stream));
+  // overflow bookkeeping: one flag per query row + their count (word nq).  A query whose candidate or refine list
+  // overflowed is redone ALONE on the exact matrix path after the levels; the others keep their filtered result.
+  SV_HIP(ctx->s_ovf.reserve(((size_t)nq + 1) * 4));
+  SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ((size_t)nq + 1) * 4, ctx->stream));
+  uint32_t* ovf_rows = ctx->s_ovf.as<uint32_t>();
+  uint32_t* ovf_count = ovf_rows + nq;
   const int64_t n0 = (n + stride0 - 1) / stride0;
   const int64_t ld0 = (n0 + 3) & ~3ll;
   SV_HIP(ctx->s_dist.reserve((size_t)chunk * ld0 * 4));
+  std::vector<uint32_t> hcnt;
   for (int q0 = 0; q0 < nq; q0 += chunk) {
     const int m = (nq - q0 < chunk) ? (nq - q0) : chunk;
     const float* qp = (const float*)dq + (size_t)q0 * d;
@@ -827,36 +913,50 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
                                         (int)stride, inv_scale, qn + q0, rn, thr_ptr, thr_ld, eps_mult, c_eps, rn_max,
                                         ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
           else
-          SV_TRY(sv_launch_bf16_filter(ctx, ctx->s_qh.as<uint16_t>() + (size_t)q0 * d, ctx->s_ql.as<uint16_t>() + (size_t)q0 * d,
-                                       ctx->db_hi.as<uint16_t>(), ctx->db_lo.as<uint16_t>(), m, (int)ns, d, (int)stride, qn + q0, rn,
-                                       thr_ptr, thr_ld, eps_mult, c_eps, rn_max, ctx->s_cand_cnt.as<uint32_t>(),
-                                       ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
+            SV_TRY(sv_launch_bf16_filter(ctx, ctx->s_qh.as<uint16_t>() + (size_t)q0 * d, ctx->s_ql.as<uint16_t>() + (size_t)q0 * d,
+                                         ctx->db_hi.as<uint16_t>(), ctx->db_lo.as<uint16_t>(), m, (int)ns, d, (int)stride, qn + q0, rn,
+                                         thr_ptr, thr_ld, eps_mult, c_eps, rn_max, ctx->s_cand_cnt.as<uint32_t>(),
+                                         ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
           sc.count();
         }
-        if (getenv("SEGVLAD_DEBUG_SEARCH")) {  // debug: candidate-list statistics of this level (synchronises)
-          std::vector<uint32_t> hc(m);
+        if (ctx->opt.debug_search || (ctx->opt.search_stats && last)) {  // candidate-list statistics (synchronises)
+          hcnt.resize(m);
           SV_HIP(hipStreamSynchronize(ctx->stream));
-          SV_HIP(hipMemcpy(hc.data(), ctx->s_cand_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+          SV_HIP(hipMemcpy(hcnt.data(), ctx->s_cand_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
           uint64_t tot = 0;
           uint32_t mx = 0, over = 0;
-          for (uint32_t c : hc) {
+          for (uint32_t c : hcnt) {
             tot += c;
             if (c > mx) mx = c;
             if (c > (uint32_t)CAP) ++over;
           }
-          fprintf(stderr, "[search] q0=%d m=%d level %d/%d ns=%lld: candidates mean %.1f max %u, %u lists over cap %d\n", q0, m, lv,
-                  levels, (long long)ns, (double)tot / m, mx, over, CAP);
+          if (last) {
+            ctx->sstats.cand_sum += (int64_t)tot;
+            if ((int64_t)mx > ctx->sstats.cand_max) ctx->sstats.cand_max = mx;
+          }
+          if (ctx->opt.debug_search)
+            fprintf(stderr, "[search] q0=%d m=%d level %d/%d ns=%lld: candidates mean %.1f max %u, %u lists over cap %d\n", q0, m, lv,
+                    levels, (long long)ns, (double)tot / m, mx, over, CAP);
         }
         StageScope sc(ctx, "knn_select");
         SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
                                        ctx->s_cand_id.as<uint32_t>(), m, CAP, k, last ? 1 : 0, qn + q0, c_eps, rn_max, thr,
-                                       ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), RCAP,
-                                       ctx->s_flag.as<uint32_t>()));
+                                       ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), RCAP, ovf_rows + q0,
+                                       ovf_count));
         sc.count();
         if (last) {
           SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn + q0, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(),
                                         RCAP, k, (float*)dd2 + (size_t)q0 * k, (int64_t*)didx + (size_t)q0 * k));
           sc.count();
+          if (ctx->opt.search_stats) {
+            hcnt.resize(m);
+            SV_HIP(hipStreamSynchronize(ctx->stream));
+            SV_HIP(hipMemcpy(hcnt.data(), ctx->s_ref_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+            for (uint32_t c : hcnt) {
+              ctx->sstats.refine_sum += c;
+              if ((int64_t)c > ctx->sstats.refine_max) ctx->sstats.refine_max = c;
+            }
+          }
         }
         // thresholds now hold approximate k-th distances A_k: the exact k-th is <= A_k + eps, and any true
         // neighbour has d2~ <= A_k + 2 eps
@@ -874,17 +974,45 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
         // the filter pass has consumed thr; the select may overwrite it with the tighter thresholds
         SV_TRY(sv_launch_select_cand(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(),
                                      m, CAP, k, last ? (float*)dd2 + (size_t)q0 * k : thr,
-                                     last ? (int64_t*)didx + (size_t)q0 * k : nullptr, ctx->s_flag.as<uint32_t>()));
+                                     last ? (int64_t*)didx + (size_t)q0 * k : nullptr, ovf_rows + q0, ovf_count));
         sc.count();
         thr_ptr = thr + (k - 1);
         thr_ld = k;
       }
     }
   }
-  uint32_t flag = 0;
-  SV_HIP(hipMemcpyAsync(&flag, ctx->s_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t n_ovf = 0;
+  SV_HIP(hipMemcpyAsync(&n_ovf, ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
   SV_HIP(hipStreamSynchronize(ctx->stream));
-  if (flag) SV_TRY(search_matrix(ctx, (const float*)dq, nq, n, d, k, qn, (float*)dd2, (int64_t*)didx));
+  if (n_ovf) {
+    // redo ONLY the flagged query rows on the exact matrix path
+    std::vector<uint32_t> hf(nq);
+    SV_HIP(hipMemcpy(hf.data(), ovf_rows, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> rows;
+    for (int q = 0; q < nq; ++q)
+      if (hf[q]) rows.push_back(q);
+    const int nf = (int)rows.size();
+    ctx->sstats.n_fallback = nf;
+    SV_HIP(ctx->s_fb_rows.reserve((size_t)nf * 4));
+    SV_HIP(ctx->s_fb_q.reserve((size_t)nf * ((size_t)d + 1) * 4));
+    SV_HIP(ctx->s_fb_d2.reserve((size_t)nf * k * 4));
+    SV_HIP(ctx->s_fb_idx.reserve((size_t)nf * k * 8));
+    SV_HIP(hipMemcpyAsync(ctx->s_fb_rows.p, rows.data(), (size_t)nf * 4, hipMemcpyHostToDevice, ctx->stream));
+    float* fq = ctx->s_fb_q.as<float>();
+    float* fqn = fq + (size_t)nf * d;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, ctx->stream, (const float*)dq, qn, ctx->s_fb_rows.as<int32_t>(), d,
+                       fq, fqn);
+    SV_HIP(hipGetLastError());
+    {
+      StageScope sc(ctx, "knn_fallback");
+      SV_TRY(search_matrix(ctx, fq, nf, n, d, k, fqn, ctx->s_fb_d2.as<float>(), ctx->s_fb_idx.as<int64_t>()));
+      sc.count(nf);
+    }
+    hipLaunchKernelGGL(scatter_topk_kernel, dim3(nf), dim3(256), 0, ctx->stream, ctx->s_fb_d2.as<float>(),
+                       ctx->s_fb_idx.as<int64_t>(), ctx->s_fb_rows.as<int32_t>(), k, (float*)dd2, (int64_t*)didx);
+    SV_HIP(hipGetLastError());
+    SV_HIP(hipStreamSynchronize(ctx->stream));  // rows[] lives on this frame
+  }
   return sv_finish(ctx);
 }
 

@@ -68,12 +68,41 @@ struct StageTimer {
   int launches = 0;
 };
 
+// Tuning / arithmetic switches.  Read ONCE (environment at segvlad_create, then segvlad_set_option); the hot
+// entry points never call getenv.
+struct SvOptions {
+  int knn_filter = 0;     // 0 auto (fp16 when d % 64 == 0, else bf16x3 when d % 32 == 0, else fp32), 1 f16, 2 bf16x3, 3 fp32
+  int pca_fp32 = 0;       // 1: plain fp32-MFMA projection instead of the fp16x3 split GEMM
+  int f16_cfg = -1;       // kNN fp16 filter tile configuration (-1 = chosen from the shape)
+  int f16_gm = 4;         // tile-block height of the XCD-aware order (0 = plain tm-fastest order)
+  int x3_tile = 0;        // PCA split GEMM tile (0 = from the shape, 128, 256)
+  int x3_gm = -1;         // PCA split GEMM XCD-aware block height (-1 = default of the kernel, 0 = plain order)
+  int search_stats = 0;   // 1: segvlad_search records list occupancies (synchronises once per chunk)
+  int assign_narrow = 0;  // 1: force the narrow assignment kernel
+  int agg_kpb = 4;        // clusters per aggregation workgroup
+  int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises)
+};
+
+// statistics of the last segvlad_search (segvlad_search_stats)
+struct SvSearchStats {
+  int64_t levels = 0;           // filter levels after the sampled exact level (0 = matrix path)
+  int64_t filter = 0;           // arithmetic of the filter levels: 0 none, 1 f16, 2 bf16x3, 3 fp32
+  int64_t n_fallback = 0;       // query rows redone on the exact matrix path (list overflow)
+  int64_t cand_max = 0;         // largest candidate list of the LAST level (search_stats only)
+  int64_t cand_sum = 0;         // sum of the last level's candidate-list lengths (search_stats only)
+  int64_t refine_max = 0;       // largest refine list (search_stats only)
+  int64_t refine_sum = 0;       // sum of refine-list lengths (search_stats only)
+  int64_t n_queries = 0;
+};
+
 struct segvlad_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   char err[512] = {0};
   bool profiling = false;
   std::map<std::string, StageTimer> timers;
+  SvOptions opt;
+  SvSearchStats sstats;
 
   // vocabulary
   int K = 0, D = 0, Kpad = 0;
@@ -104,7 +133,8 @@ struct segvlad_ctx {
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted;
+      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
+      s_fb_idx, s_fb_rows;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -179,7 +209,7 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
                           uint32_t* cand_id, int cap);
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int k, int mode, const float* qn, float c_eps, float rn_max, float* thr_out,
-                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* overflow);
+                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* ovf_rows, uint32_t* ovf_count);
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
@@ -195,9 +225,10 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
                          float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap);
 
 // select_kernels.hip
-// top-k of per-query candidate lists (LDS sort on (distance, id)); lists longer than cap set *overflow
+// top-k of per-query candidate lists (LDS sort on (distance, id)); a list longer than cap flags its query row in
+// ovf_rows (and counts it once in *ovf_count): that query is redone on the matrix path
 int sv_launch_select_cand(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id,
-                          int nq, int cap, int k, float* d2_out, int64_t* idx_out, uint32_t* overflow);
+                          int nq, int cap, int k, float* d2_out, int64_t* idx_out, uint32_t* ovf_rows, uint32_t* ovf_count);
 int sv_launch_select_topk(segvlad_ctx* ctx, const float* dist, int64_t ld, int nq, int64_t n, int k, float* d2_out,
                           int64_t* idx_out, int64_t out_ld, int64_t id_base);
 int sv_launch_merge_topk(segvlad_ctx* ctx, const float* d2_parts, const int64_t* idx_parts, int nq, int cand, int k,

@@ -250,8 +250,9 @@ static int launch_x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, c
   auto kern = gemm_f16x3_kernel<BM, BN, WM, WN>;
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const char* gme = getenv("SEGVLAD_X3_GM");  // tile-block height of the XCD-aware order (0 = plain order, k-split in grid.y)
-  int gm = gme ? atoi(gme) : 0;   // measured: the plain order is ~8 % faster here (probe_pca.py)
+  // tile-block height of the XCD-aware order (0 = plain order, k-split in grid.y); measured: the plain order is ~8 %
+  // faster here (probe_pca.py)
+  int gm = ctx->opt.x3_gm > 0 ? ctx->opt.x3_gm : 0;
   dim3 grid((unsigned)tiles, (unsigned)splits);
   if (gm > 0) {
     gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
@@ -277,8 +278,7 @@ static int launch_x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, c
 int sv_launch_gemm_f16x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, const uint16_t* B1, const uint16_t* B2, int M,
                          int N, int Kd, float out_scale, const float* col_scale, float* C) {
   if (M <= 0 || N <= 0) return SEGVLAD_OK;
-  const char* cfg = getenv("SEGVLAD_X3_TILE");
-  const bool big = cfg ? (atoi(cfg) == 256) : (M >= 1024);  // 256x256 tiles: 8.1 vs 12.6 ms at 10000 x 98304 x 1024
+  const bool big = ctx->opt.x3_tile ? (ctx->opt.x3_tile == 256) : (M >= 1024);  // 256x256 tiles: 8.1 vs 12.6 ms at 10000 x 98304 x 1024
   if (big) return launch_x3<256, 256, 4, 2>(ctx, A1, A2, B1, B2, M, N, Kd, out_scale, col_scale, C);
   return launch_x3<128, 128, 2, 2>(ctx, A1, A2, B1, B2, M, N, Kd, out_scale, col_scale, C);
 }

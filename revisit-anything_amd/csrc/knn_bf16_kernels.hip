@@ -277,10 +277,6 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
                           int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2,
                           uint32_t* cand_id, int cap) {
   if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
-  const char* dep = getenv("SEGVLAD_FILTER_DEPTH");
-  if (dep && atoi(dep) == 3)
-    return launch_filter<128, 128, 2, 2, 3>(ctx, Qh, Ql, Rh, Rl, M, n_sample, d, b_stride, qn, rn, thr, thr_ld, eps_mult, c_eps,
-                                            rn_max, cand_cnt, cand_d2, cand_id, cap);
   return launch_filter<128, 128, 2, 2, 1>(ctx, Qh, Ql, Rh, Rl, M, n_sample, d, b_stride, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max,
                                           cand_cnt, cand_d2, cand_id, cap);
 }
@@ -766,8 +762,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
                              int cap) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (n_sample + BN - 1) / BN;
   int64_t tiles = (int64_t)tiles_m * tiles_n;
-  const char* gme = getenv("SEGVLAD_F16_GM");  // tile-block height of the XCD-aware order (0 = plain tm-fastest order)
-  int gm = gme ? atoi(gme) : 4;
+  int gm = ctx->opt.f16_gm;  // tile-block height of the XCD-aware order (0 = plain tm-fastest order)
   if (PERSIST && gm <= 0) gm = 4;
   int seq_total = 0;
   if (gm > 0) {
@@ -802,8 +797,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
                          float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap) {
   if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
 #define SV_F16_ARGS ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap
-  const char* cfg = getenv("SEGVLAD_F16_CFG");  // tuning knob (default chosen from measurements)
-  const int c = cfg ? atoi(cfg) : (M > 128 ? 0 : 3);
+  // tile configuration: option "f16_cfg" (default chosen from measurements)
+  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 0 : 3);
   switch (c) {
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
     case 200:   // persistent workgroups that request the next tile's head before their epilogue: -4 % on unstructured
@@ -812,6 +807,7 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true>(SV_F16_ARGS);
       return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);
+#ifdef SEGVLAD_ABLATIONS   // timing ablations (WRONG results) and phase timing: development builds only
     case 10: return launch_f16_filter<256, 256, 4, 2, 64, 3, 1>(SV_F16_ARGS);  // ablations of config 0 (WRONG results)
     case 20: return launch_f16_filter<256, 256, 4, 2, 64, 3, 2>(SV_F16_ARGS);
     case 30: return launch_f16_filter<256, 256, 4, 2, 64, 3, 3>(SV_F16_ARGS);
@@ -832,14 +828,19 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
               (double)c8[6] / ((double)((M + 255) / 256) * ((n_sample + 255) / 256)));
       return rc;
     }
+#endif
     case 1: return launch_f16_filter<256, 256, 4, 2, 32, 2>(SV_F16_ARGS);  //  64 KiB LDS, 2 workgroups / CU
     case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
     case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB
     case 5: return launch_f16_filter<256, 256, 2, 2, 64, 3>(SV_F16_ARGS);  // 4 waves of 128 x 128: 0.5 LDS fragment / MFMA
+#ifdef SEGVLAD_ABLATIONS
     case 15: return launch_f16_filter<256, 256, 2, 2, 64, 3, 1>(SV_F16_ARGS);
+#endif
     case 6: return launch_f16_filter<256, 256, 2, 2, 32, 3>(SV_F16_ARGS);
     case 7: return launch_f16_filter<256, 128, 4, 1, 32, 3>(SV_F16_ARGS);  // 56 KiB, 4 waves: 2 independent workgroups / CU
+#ifdef SEGVLAD_ABLATIONS
     case 17: return launch_f16_filter<256, 128, 4, 1, 32, 3, 1>(SV_F16_ARGS);
+#endif
     case 8: return launch_f16_filter<256, 128, 4, 1, 32, 2>(SV_F16_ARGS);
     case 9: return launch_f16_filter<128, 256, 2, 2, 32, 3>(SV_F16_ARGS);
     default: return launch_f16_filter<128, 128, 2, 2, 32, 2>(SV_F16_ARGS); //  32 KiB
@@ -882,13 +883,14 @@ __device__ __forceinline__ void hist_add_(uint32_t* hist, bool active, uint32_t 
 // Candidate lists are only RANKED here, never sorted: an MSB-first radix select over the keys held in LDS
 // yields A_k, the k-th smallest approximate distance (+inf if fewer than k candidates).
 //   mode 0: thr_out[q] = A_k
-//   mode 1: refine list = ids with d2~ <= A_k + 2 eps(q) (unordered; at most rcap, more -> *overflow)
+//   mode 1: refine list = ids with d2~ <= A_k + 2 eps(q) (unordered; at most rcap, more -> the row is flagged in ovf_rows)
 __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
                                                             const uint32_t* __restrict__ cid, int cap, int k, int mode,
                                                             const float* __restrict__ qn, float c_eps, float rn_max,
                                                             float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
                                                             uint32_t* __restrict__ ref_id, int rcap,
-                                                            uint32_t* __restrict__ overflow) {
+                                                            uint32_t* __restrict__ ovf_rows,
+                                                            uint32_t* __restrict__ ovf_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);  // [cap]
   __shared__ uint32_t hist[256];
@@ -896,10 +898,13 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   const uint32_t c = cnt[row];
-  if (c > (uint32_t)cap) {
+  if (c > (uint32_t)cap || ovf_rows[row]) {
+    // overflow (now or at a coarser level): the query is redone ALONE on the matrix path; a threshold of -inf
+    // keeps its candidate list empty at the finer levels, an empty refine list makes the refinement a no-op
     if (tid == 0) {
-      atomicOr(overflow, 1u);
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
       if (mode == 1) ref_cnt[row] = 0;
+      else thr_out[row] = -INFINITY;
     }
     return;
   }
@@ -956,7 +961,7 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
   __syncthreads();
   if (tid == 0) {
     if (s_n > (uint32_t)rcap) {
-      atomicOr(overflow, 1u);
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
       ref_cnt[row] = 0;
     } else {
       ref_cnt[row] = s_n;
@@ -966,11 +971,11 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
 
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int k, int mode, const float* qn, float c_eps, float rn_max, float* thr_out,
-                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* overflow) {
+                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* ovf_rows, uint32_t* ovf_count) {
   if (nq <= 0) return SEGVLAD_OK;
   const size_t lds = (size_t)cap * 4;
   hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, k, mode, qn,
-                     c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, overflow);
+                     c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows, ovf_count);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

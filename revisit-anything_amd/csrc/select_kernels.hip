@@ -194,23 +194,28 @@ int sv_launch_select_topk(segvlad_ctx* ctx, const float* dist, int64_t ld, int n
 // ------------------------------------------------------------------------------------------------
 // top-k of a per-query candidate list produced by the filtered GEMM epilogue (unordered, <= cap
 // entries).  (key, id) pairs are sorted in LDS, so the result does not depend on the order in which
-// the atomics handed out the slots.  A list that overflowed its capacity raises *overflow and the
-// caller falls back to the matrix path.
+// the atomics handed out the slots.  A list that overflowed its capacity flags its query row
+// (ovf_rows, counted once in *ovf_count) and the caller redoes that row alone on the matrix path.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_cand_kernel(const uint32_t* __restrict__ cnt,
                                                           const float* __restrict__ cd2,
                                                           const uint32_t* __restrict__ cid, int cap, int k,
                                                           float* __restrict__ d2_out, int64_t* __restrict__ idx_out,
-                                                          uint32_t* __restrict__ overflow) {
+                                                          uint32_t* __restrict__ ovf_rows, uint32_t* __restrict__ ovf_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* a = reinterpret_cast<uint64_t*>(smem);
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   const uint32_t c = cnt[row];
   if (c > (uint32_t)cap) {
-    if (tid == 0) atomicOr(overflow, 1u);
+    if (tid == 0) {
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      // this query is redone on the matrix path: a threshold of -inf keeps its list empty at the finer levels
+      if (!idx_out) d2_out[row * k + (k - 1)] = -INFINITY;
+    }
     return;
   }
+  if (ovf_rows[row]) return;   // flagged at a coarser level: its result comes from the fallback
   int npad = 2;
   while (npad < (int)c) npad <<= 1;
   for (int j = tid; j < npad; j += 256)
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256) void select_cand_kernel(const uint32_t* __rest
 }
 
 int sv_launch_select_cand(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id,
-                          int nq, int cap, int k, float* d2_out, int64_t* idx_out, uint32_t* overflow) {
+                          int nq, int cap, int k, float* d2_out, int64_t* idx_out, uint32_t* ovf_rows, uint32_t* ovf_count) {
   if (nq <= 0) return SEGVLAD_OK;
   const size_t lds = (size_t)cap * 8;
   if (lds > 128 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "select_cand: cap=%d exceeds the LDS sort", cap);
@@ -237,7 +242,7 @@ int sv_launch_select_cand(segvlad_ctx* ctx, const uint32_t* cand_cnt, const floa
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_cand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
   hipLaunchKernelGGL(select_cand_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, k, d2_out,
-                     idx_out, overflow);
+                     idx_out, ovf_rows, ovf_count);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

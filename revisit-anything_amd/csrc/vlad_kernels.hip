@@ -644,7 +644,7 @@ int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float*
   const int NT = ctx->Kpad / 32;
   dim3 grid((N + 63) / 64, B), block(256);
   const float* bt = ctx->vocab_bt.as<float>();
-  if (NT <= 2 && ctx->D % 32 == 0 && getenv("SEGVLAD_ASSIGN_NARROW") == nullptr) {
+  if (NT <= 2 && ctx->D % 32 == 0 && !ctx->opt.assign_narrow) {
     dim3 gridw((N + 127) / 128, B);
     if (NT == 1)
       hipLaunchKernelGGL(assign_wide_kernel<1>, gridw, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
@@ -658,16 +658,21 @@ int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float*
       hipLaunchKernelGGL(assign_kernel<1>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
       break;
     case 2: {
+#ifdef SEGVLAD_ABLATIONS   // timing ablations (WRONG results): development builds only, never in the shipped library
       const char* ab = getenv("SEGVLAD_ASSIGN_ABL");
       const int a = ab ? atoi(ab) : 0;
-      if (a == 1)
+      if (a == 1) {
         hipLaunchKernelGGL((assign_kernel<2, 1>), grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
-      else if (a == 2)
+        break;
+      } else if (a == 2) {
         hipLaunchKernelGGL((assign_kernel<2, 2>), grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
-      else if (a == 3)
+        break;
+      } else if (a == 3) {
         hipLaunchKernelGGL((assign_kernel<2, 3>), grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
-      else
-        hipLaunchKernelGGL(assign_kernel<2>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+        break;
+      }
+#endif
+      hipLaunchKernelGGL(assign_kernel<2>, grid, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
       break;
     }
     case 4:
@@ -1018,6 +1023,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: N=%d tokens need %zu B of LDS (limit 160 KiB)", N, lds);
   auto kern = (h1 != nullptr) ? aggregate_kernel<true> : aggregate_kernel<false>;
   bool phases = false;
+#ifdef SEGVLAD_ABLATIONS   // timing ablations / phase timing: development builds only
   if (const char* ab = getenv("SEGVLAD_AGG_ABL")) {
     if (atoi(ab) == 1) kern = aggregate_kernel<false, 1>;
     if (atoi(ab) == 2) kern = aggregate_kernel<false, 2>;
@@ -1028,10 +1034,10 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
       SV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sv_agg_phase_cycles), z, sizeof(z)));
     }
   }
+#endif
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const char* kpe = getenv("SEGVLAD_AGG_KPB");   // clusters per workgroup
-  int kpb = kpe ? atoi(kpe) : 4;
+  int kpb = ctx->opt.agg_kpb;   // clusters per workgroup
   if (kpb < 1) kpb = 1;
   hipLaunchKernelGGL(kern, dim3((K + kpb - 1) / kpb, B), dim3(nwaves * 64), lds, ctx->stream, xt, ctx->s_rnsorted.as<float>(),
                      ctx->s_tokorder.as<int32_t>(),
@@ -1039,6 +1045,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
                      gscale, N, D, K, SC, Ncap, out, block_norms, mean, xscale, reinterpret_cast<_Float16*>(h1),
                      reinterpret_cast<_Float16*>(h2), kpb);
   SV_HIP(hipGetLastError());
+#ifdef SEGVLAD_ABLATIONS
   if (phases) {
     unsigned long long c8[8];
     SV_HIP(hipStreamSynchronize(ctx->stream));
@@ -1049,5 +1056,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
             100 * c8[0] / tot, 100 * c8[1] / tot, 100 * c8[5] / tot, 100 * c8[6] / tot, 100 * c8[7] / tot, 100 * c8[2] / tot,
             100 * c8[3] / tot, 100 * c8[4] / tot, tot / ((double)K * B));
   }
+#endif
+  (void)phases;
   return SEGVLAD_OK;
 }

@@ -53,6 +53,8 @@ class SegVLADEngine:
         self._h = h
         self.K = self.D = 0
         self.P = self.KD = 0
+        self.vocab_generation = 0   # bumped by every set_vocab / pca_set: lets callers cache "my model is resident"
+        self.pca_generation = 0
         self._keep = []  # tensors that must outlive async kernels of the last call
 
     # ---- plumbing ---------------------------------------------------------------------------------
@@ -89,6 +91,19 @@ class SegVLADEngine:
     def profile_reset(self):
         self.lib.segvlad_profile_reset(self._h)
 
+    def set_option(self, key: str, value):
+        """segvlad_set_option: arithmetic / tuning switches of this context (see include/segvlad.h)."""
+        self._check(self.lib.segvlad_set_option(self._h, str(key).encode(), str(value).encode()), f"set_option({key})")
+
+    def search_stats(self) -> dict:
+        """Statistics of the last search(): levels, filter arithmetic, rows redone on the exact path, list occupancies."""
+        v = (C.c_int64 * 8)()
+        self._check(self.lib.segvlad_search_stats(self._h, v, 8), "search_stats")
+        names = ("levels", "filter", "n_fallback", "cand_max", "cand_sum", "refine_max", "refine_sum", "n_queries")
+        d = dict(zip(names, [int(x) for x in v]))
+        d["filter"] = {0: "none", 1: "f16", 2: "bf16x3", 3: "fp32"}[d["filter"]]
+        return d
+
     def stage_ms(self, stage: str):
         """(total ms, kernel launches) of the stage since the last profile_reset()."""
         ms, n = C.c_float(), C.c_int()
@@ -105,6 +120,7 @@ class SegVLADEngine:
         if isinstance(c, torch.Tensor) and c.is_cuda:
             torch.cuda.current_stream(self.device).synchronize()
         self.K, self.D = int(K), int(D)
+        self.vocab_generation += 1
 
     # ---- masks ------------------------------------------------------------------------------------
     def incidence(self, masks, H: int, W: int, patch: int = 14) -> torch.Tensor:
@@ -261,6 +277,7 @@ class SegVLADEngine:
         self._stream()
         self._check(self.lib.segvlad_pca_set(self._h, _ptr(mean), _ptr(comps), _ptr(var), P, KD, int(bool(whiten))), "pca_set")
         self.P, self.KD = int(P), int(KD)
+        self.pca_generation += 1
 
     def pca_apply(self, X, l2norm=False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _as(X, np.float32, torch.float32)

@@ -12,6 +12,7 @@ pickle loading of the sklearn PCA model.
 """
 from __future__ import annotations
 
+import os
 import pickle
 import re
 import time
@@ -26,7 +27,8 @@ from ._lib import SegVLADError  # noqa: F401  (re-export)
 
 _ENGINE = None
 _VOCAB_KEY = None
-_PCA_CACHE = {}
+_VOCAB_REF = None   # strong reference to the tensor the key was taken from: its storage cannot be recycled under the key
+_PCA_KEY = None     # (path, mtime_ns, size, engine model generation) of the PCA model resident on the engine
 
 
 def engine() -> SegVLADEngine:
@@ -38,13 +40,22 @@ def engine() -> SegVLADEngine:
 
 
 def _set_vocab(c_centers):
-    """Upload the vocabulary once per distinct tensor (the reference passes the same c_centers every call)."""
-    global _VOCAB_KEY
-    c = c_centers.detach() if isinstance(c_centers, torch.Tensor) else torch.as_tensor(np.asarray(c_centers))
-    key = (c.data_ptr(), tuple(c.shape), c._version if isinstance(c, torch.Tensor) else 0)
-    if key != _VOCAB_KEY:
-        engine().set_vocab(c.to(torch.float32))
-        _VOCAB_KEY = key
+    """Upload the vocabulary once per distinct tensor (the reference passes the same c_centers every call).
+    The cache key is the object's identity + storage address + in-place version, and the keyed object is kept
+    alive (_VOCAB_REF), so a freed-and-reallocated tensor of the same shape can never alias the key; anything else
+    that re-programs the engine's vocabulary (engine().set_vocab elsewhere) bumps its generation and misses too."""
+    global _VOCAB_KEY, _VOCAB_REF
+    eng = engine()
+    if isinstance(c_centers, torch.Tensor):
+        c = c_centers.detach()
+        key = (id(c_centers), c.data_ptr(), tuple(c.shape), c_centers._version, eng.vocab_generation)
+    else:
+        c = torch.as_tensor(np.asarray(c_centers))
+        key = None   # arrays / lists: no cheap identity -> always upload (0.4 MB)
+    if key is None or key != _VOCAB_KEY:
+        eng.set_vocab(c.to(torch.float32))
+        _VOCAB_REF = c_centers
+        _VOCAB_KEY = None if key is None else key[:-1] + (eng.vocab_generation,)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -204,16 +215,23 @@ def vlad_matmuls_per_cluster(num_c, masks, res, clus_labels, adjMat=None, device
 # a8/a9  PCA apply, normalizeFeat
 # --------------------------------------------------------------------------------------------------
 def _load_pca(pca_model_path):
-    """The reference re-unpickles the model on every call (func_vpr.py:1434-1435); we cache the device copy."""
-    if pca_model_path not in _PCA_CACHE:
+    """The reference re-unpickles the model on every call (func_vpr.py:1434-1435); we keep the device copy while
+    it is provably the same model: same path, same file (mtime + size: place_rec_pca re-saves to the same name) and
+    nobody else has re-programmed the engine's PCA since (model generation).  The key is stored only after
+    pca_set succeeded."""
+    global _PCA_KEY
+    eng = engine()
+    st = os.stat(pca_model_path)
+    key = (os.path.abspath(pca_model_path), st.st_mtime_ns, st.st_size)
+    if _PCA_KEY is None or _PCA_KEY[:3] != key or _PCA_KEY[3] != eng.pca_generation:
         with open(pca_model_path, "rb") as f:
             pca = pickle.load(f)
-        _PCA_CACHE.clear()
-        _PCA_CACHE[pca_model_path] = True
+        _PCA_KEY = None
         whiten = bool(getattr(pca, "whiten", False))
-        engine().pca_set(np.asarray(pca.mean_, dtype=np.float32), np.asarray(pca.components_, dtype=np.float32),
-                         np.asarray(pca.explained_variance_, dtype=np.float32) if whiten else None, whiten)
-    return engine()
+        eng.pca_set(np.asarray(pca.mean_, dtype=np.float32), np.asarray(pca.components_, dtype=np.float32),
+                    np.asarray(pca.explained_variance_, dtype=np.float32) if whiten else None, whiten)
+        _PCA_KEY = key + (eng.pca_generation,)
+    return eng
 
 
 def apply_pca_transform_from_pkl(data_tensor, pca_model_path):

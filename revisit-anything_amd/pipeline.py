@@ -42,7 +42,7 @@ def adjacency_batch(centroids: np.ndarray, seg_offsets: Sequence[int], order: in
 
 class SegVLADPipeline:
     def __init__(self, engine: SegVLADEngine, H: int, W: int, patch: int = 14, order: int = 3, use_pca: bool = True,
-                 adj_workers: int = 8, host_adjacency: bool = False, fuse_pca: bool = True):
+                 adj_workers: int = 8, host_adjacency: bool = False, fuse_pca: bool = True, check_empty: bool = True):
         self.eng = engine
         self.H, self.W, self.patch = H, W, patch
         self.order = order
@@ -50,6 +50,9 @@ class SegVLADPipeline:
         self.adj_workers = adj_workers
         self.host_adjacency = host_adjacency
         self.fuse_pca = fuse_pca
+        # an empty mask has no centroid: the reference fails there (func_vpr.py:1314 -> Delaunay on NaN); with
+        # check_empty the device adjacency reports it (one 4-byte read-back per batch) and describe() raises ValueError
+        self.check_empty = check_empty
         self.N = (H // patch) * (W // patch)
 
     # ---- a2..a9: images -> (normalised) segment descriptors ------------------------------------------
@@ -64,7 +67,7 @@ class SegVLADPipeline:
             if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)
                 adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
             else:                     # device kernel: no host round trip
-                adj = eng.adjacency(cent, seg_offsets, self.order)
+                adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
         else:
             bits = eng.incidence(masks, self.H, self.W, self.patch)
             if not self.order:

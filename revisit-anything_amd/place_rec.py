@@ -1,7 +1,7 @@
 """Drop-in for the hot-path part of the reference's ``place_rec_main.py``: ``recall_segloc``
 (place_rec_main.py:44-96), a ``faiss.IndexFlatL2``-compatible exact index, the dataset/experiment
-config surface (place_rec_global_config.py) and the two ground-truth rules that need no dataset files
-(gt.py:60-64, 66-69)."""
+config surface (place_rec_global_config.py) and the ground-truth rules that need no dataset images
+(gt.py:60-64 17places, 66-69 AmsterTime, 71-73 VPAir's vpair_gt.npy)."""
 from __future__ import annotations
 
 import os
@@ -16,11 +16,19 @@ from . import func_vpr
 class IndexFlatL2:
     """faiss.IndexFlatL2 surface used by the reference (place_rec_main.py:53-60): ``add(x)``,
     ``search(x, k) -> (D2 float32 [n,k] ascending, I int64 [n,k])``, ``ntotal``, ``d``.  Exact,
-    brute force, on the MI355X (fp32 MFMA GEMM + exact top-k)."""
+    brute force, on the MI355X (16-bit MFMA candidate filter + exact fp32 refinement, or the fp32 distance-matrix
+    path for small indices).  Every index owns its own engine context (its own rows, planes and scratch), so several
+    indices can be alive at once -- as with faiss -- and none of them disturbs the vocabulary / PCA state of the
+    process-wide func_vpr engine."""
 
     def __init__(self, d: int):
+        from .engine import SegVLADEngine
+
         self.d = int(d)
-        self._eng = func_vpr.engine()
+        self._eng = SegVLADEngine(func_vpr.engine().device)
+        self.ntotal = 0
+
+    def reset(self):
         self._eng.db_reset()
         self.ntotal = 0
 
@@ -112,4 +120,11 @@ def get_gt(dataset, cfg=None, workdir_data=None, ims1_r=None, ims2_q=None, func_
         if ims1_r is None:
             raise ValueError("ims1_r must be provided for the AmsterTime dataset.")
         return [[i] for i in range(len(ims1_r))]
+    if dataset == "VPAir":
+        # gt.py:71-73 -> dataloaders/vpair_dataloader.py:93-98: `vpair_gt.npy` holds, per query, a pair whose second
+        # entry lists the soft-positive reference indices
+        if workdir_data is None:
+            raise ValueError("workdir_data must be provided for the VPAir dataset.")
+        gt_positives = np.load(os.path.join(workdir_data, "VPAir", "vpair_gt.npy"), allow_pickle=True)
+        return [gt_positives[i][1] for i in range(len(gt_positives))]
     raise NotImplementedError(f"ground truth for dataset {dataset!r} needs its metadata files (gt.py)")

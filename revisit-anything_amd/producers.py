@@ -87,9 +87,11 @@ def center_crop_to_patches(img: torch.Tensor, patch: int = 14) -> torch.Tensor:
     return img[..., top:top + hn, left:left + wn]
 
 
-def image_to_tokens(img_rgb: np.ndarray, extractor, cfg: Optional[dict] = None) -> torch.Tensor:
+def image_to_tokens(img_rgb: np.ndarray, extractor, cfg: Optional[dict] = None, normalize: bool = True) -> torch.Tensor:
     """``process_single_DINO`` + ``getAnyLocFt(..., upsample=False)`` (func_vpr.py:549-562, 489-506):
-    ``img_rgb`` uint8 ``[H, W, 3]`` (already RGB) -> float32 ``[1, D, h, w]`` on the extractor's device.
+    ``img_rgb`` uint8 ``[H, W, 3]`` (already RGB) -> float32 ``[1, D, h, w]`` on the extractor's device,
+    L2-normalised over the channel axis exactly as ``process_single_DINO`` returns it (func_vpr.py:561) -- i.e. what the
+    reference writes to ``/{key}/ift_dino``.  ``normalize=False`` gives ``getAnyLocFt``'s raw value-facet map.
     ``cfg['resize']`` / ``desired_width`` / ``desired_height`` as in place_rec_global_config.py; the resize is bilinear
     with pixel-centre alignment like ``cv2.resize``'s default (cv2 rounds the result to uint8, so does this)."""
     a = np.asarray(img_rgb)
@@ -107,4 +109,5 @@ def image_to_tokens(img_rgb: np.ndarray, extractor, cfg: Optional[dict] = None) 
     x = center_crop_to_patches(x)[None]
     hr, wr = x.shape[2] // 14, x.shape[3] // 14
     feat = extractor(x)                                                             # [1, hr*wr, D]
-    return feat.reshape(1, hr, wr, -1).permute(0, 3, 1, 2).contiguous().float()     # [1, D, hr, wr]
+    feat = feat.reshape(1, hr, wr, -1).permute(0, 3, 1, 2).contiguous().float()     # [1, D, hr, wr]
+    return torch.nn.functional.normalize(feat, dim=1) if normalize else feat

@@ -5,8 +5,8 @@ The reference is single-process; sharding is the build's 
 * the reference-segment rows are split into contiguous blocks, rank r keeps rows
   [row_start[r], row_start[r+1]) and answers queries against its block only;
 * every rank sees the full query batch, computes its local top-k (distance, GLOBAL segment id),
-  then ONE all_gather (RCCL over xGMI when the backend is "nccl") exchanges the per-shard lists:
-  nq * k * 12 B per rank;
+  then ONE all_gather (RCCL over xGMI when the backend is "nccl") exchanges the per-shard lists as
+  packed 12-byte records {fp32 distance bits, int64 id}: nq * k * 12 B per rank;
 * every rank merges the world*k candidates per query segment to the global top-k -- by distance,
   ties by lower global id, i.e. exactly what a single index over all rows returns -- and votes.
 
@@ -113,12 +113,15 @@ class ShardedSegmentIndex:
             idx = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
         if self.world == 1:
             return d2, idx
-        d2_parts = [torch.empty_like(d2) for _ in range(self.world)]
-        idx_parts = [torch.empty_like(idx) for _ in range(self.world)]
-        dist.all_gather(d2_parts, d2.contiguous(), group=self.group)
-        dist.all_gather(idx_parts, idx.contiguous(), group=self.group)
-        d2c = torch.cat(d2_parts, dim=1).contiguous()   # [nq, world*k], shard-major within a row
-        idc = torch.cat(idx_parts, dim=1).contiguous()
+        # ONE collective: (d2, global id) travel as a packed 12-byte record {fp32 bits, id low, id high}
+        rec = torch.empty((nq, k, 3), dtype=torch.int32, device=self.device)
+        rec[:, :, 0] = d2.contiguous().view(torch.int32)
+        rec[:, :, 1:] = idx.contiguous().view(torch.int32).view(nq, k, 2)
+        allrec = torch.empty((self.world * nq, k, 3), dtype=torch.int32, device=self.device)   # rank-major concatenation
+        dist.all_gather_into_tensor(allrec, rec, group=self.group)
+        allrec = allrec.view(self.world, nq, k, 3).permute(1, 0, 2, 3)                                 # [nq, world, k, 3]: shard-major within a row
+        d2c = allrec[..., 0].contiguous().view(torch.float32).view(nq, self.world * k)
+        idc = allrec[..., 1:].contiguous().view(torch.int64).view(nq, self.world * k)
         md, mi = self.be.merge_topk(d2c, idc, self.world, k)
         return torch.as_tensor(md), torch.as_tensor(mi)
 

@@ -66,3 +66,38 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.replace("segvlad_oracle", "oracle") or f == "_nothing_", (
                     f"{f} mentions the oracle: the product path must not route through it")
+
+
+def test_every_context_buffer_is_released_by_destroy():
+    """ADVICE r01: segvlad_destroy must free every grow-only device buffer the context declares (four were missing)."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ctx = open(os.path.join(root, "revisit-anything_amd", "csrc", "ctx.h")).read()
+    body = ctx[ctx.index("struct segvlad_ctx {"):]
+    body = body[:body.index("int fail(")]
+    declared = set()
+    for decl in re.findall(r"DevBuf\s+([^;]+);", body):
+        declared.update(n.strip() for n in re.sub(r"//[^\n]*", "", decl).split(","))
+    declared = {n for n in declared if n}
+    api = open(os.path.join(root, "revisit-anything_amd", "csrc", "api.hip")).read()
+    dtor = api[api.index("int segvlad_destroy("):api.index("const char* segvlad_last_error")]
+    released = set(re.findall(r"&ctx->(\w+)", dtor))
+    assert declared - released == set(), f"not released by segvlad_destroy: {sorted(declared - released)}"
+
+
+def test_hot_entry_points_never_read_the_environment():
+    """VERDICT r01 #12: switches are read once at context creation; ablation kernels only exist behind SEGVLAD_ABLATIONS."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "revisit-anything_amd", "csrc")
+    for f in os.listdir(d):
+        src = open(os.path.join(d, f)).read()
+        # strip the development-only blocks
+        src_ship = re.sub(r"#ifdef SEGVLAD_ABLATIONS.*?#endif", "", src, flags=re.S)
+        for m in re.finditer(r"getenv\(", src_ship):
+            line_start = src_ship.rfind("\n", 0, m.start())
+            ctx_txt = src_ship[max(0, src_ship.rfind("int segvlad_", 0, m.start())):m.start()]
+            assert f == "api.hip" and "segvlad_create" in ctx_txt.split("int segvlad_")[-1][:40] or "segvlad_create" in ctx_txt[-3000:], \
+                f"getenv outside segvlad_create in {f}: {src_ship[line_start:m.end() + 40]!r}"

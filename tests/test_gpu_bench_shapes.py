@@ -1,0 +1,297 @@
+"""GPU parity AT THE SHAPES bench.py MEASURES: the leveled fp16 filter at d = 1024 over the
+1 M-row database and its 125 k / 250 k / 500 k row shards, segment-VLAD and the fused VLAD->PCA at K = 64, D = 1536,
+N = 1530, S = 50, P = 1024 (KD = 98 304, split-K), the VPAir geometry (800x600, masks 300x400, N = 2394, P = 512),
+and the per-query overflow fallback.  Everything goes through the C-ABI (engine.py) and is checked against oracle/ and
+the reference-generated fixtures.  Run with `-m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device (no CPU fallback exists)"
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    e = SegVLADEngine(0)
+    yield e
+    e.close()
+
+
+def O():
+    from oracle import segvlad_oracle
+
+    return segvlad_oracle
+
+
+def synth():
+    from revisit_anything_amd import synth as s
+
+    return s
+
+
+def cos_rows(a, b):
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+# ------------------------------------------------------------------------------------------------
+# (a) exact kNN at d = 1024: 1 M planted rows and the shard sizes of the 2/4/8-GPU runs
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def planted_1m(eng):
+    """20 000 reference 'images' x 50 segments x 1024-d, groups of 4 near-duplicate places, generated on
+    the device; queries of three kinds: planted (sigma_q = 4), un-planted random unit vectors, and near-copies of
+    database rows (tight clusters)."""
+    import torch
+
+    dev = eng.device
+    n_img, S, d, group = 20000, 50, 1024, 4
+    g = torch.Generator(device=dev)
+    g.manual_seed(3000)
+    R = torch.empty(n_img * S, d, device=dev)
+    for g0 in range(0, n_img // group, 500):                                     # 500 groups (= 100 k rows) at a time
+        ng = min(500, n_img // group - g0)
+        base = torch.nn.functional.normalize(torch.randn(ng, 1, S, d, device=dev, generator=g), dim=3)
+        blk = base + (0.05 / d ** 0.5) * torch.randn(ng, group, S, d, device=dev, generator=g)
+        R[g0 * group * S:(g0 + ng) * group * S] = torch.nn.functional.normalize(blk, dim=3).reshape(-1, d)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4000)
+    n_pl, n_rand, n_dup = 320, 128, 64
+    tau = torch.randint(0, n_img * S, (n_pl,), device=dev, generator=gq)
+    q_pl = torch.nn.functional.normalize(R[tau] + (4.0 / d ** 0.5) * torch.randn(n_pl, d, device=dev, generator=gq), dim=1)
+    q_rand = torch.nn.functional.normalize(torch.randn(n_rand, d, device=dev, generator=gq), dim=1)
+    src = torch.randint(0, 125000, (n_dup,), device=dev, generator=gq)           # inside every shard prefix
+    q_dup = torch.nn.functional.normalize(R[src] + (0.02 / d ** 0.5) * torch.randn(n_dup, d, device=dev, generator=gq), dim=1)
+    Q = torch.cat([q_pl, q_rand, q_dup]).contiguous()
+    # oracle rows: a mix of the three kinds
+    sel = np.concatenate([np.arange(0, 40), n_pl + np.arange(0, 16), n_pl + n_rand + np.arange(0, 8)])
+    m = O().l2_matrix(R.cpu().numpy(), Q[torch.from_numpy(sel).to(dev)].cpu().numpy(), rows_block=100000)
+    return {"R": R, "Q": Q, "sel": sel, "d2_oracle": m}
+
+
+@pytest.mark.parametrize("n_rows", [1000000, 500000, 250000, 125000])
+def test_knn_f16_filter_d1024_bench_and_shard_sizes(eng, planted_1m, n_rows):
+    """segvlad_search (fp16 filter levels + exact refinement) over the first n_rows rows: bit-identical to the all-fp32
+    filter path for EVERY query, and equal to the fp64 oracle on a 64-query subset (distances within 1e-5, ids
+    identical wherever the oracle's neighbouring distances differ by more than fp32 rounding)."""
+    import torch
+
+    R, Q, sel = planted_1m["R"], planted_1m["Q"], planted_1m["sel"]
+    k = 200
+    eng.db_reset()
+    eng.db_add(R[:n_rows])
+    try:
+        eng.set_option("search_stats", 1)
+        d2, idx = eng.search(Q, k)
+        st = eng.search_stats()
+        # level plan (api.hip): strides 256, 16, 1 down to 250 k rows; 125 k rows (the 8-GPU shard) get strides 16, 1
+        assert st["filter"] == "f16" and st["levels"] == (1 if n_rows == 125000 else 2) and st["n_fallback"] == 0, st
+        # refine-list occupancy on planted + un-planted + clustered queries (cap 512 per query)
+        print(f"[{n_rows} rows] last-level candidates mean {st['cand_sum'] / st['n_queries']:.0f} max {st['cand_max']}; "
+              f"refine list mean {st['refine_sum'] / st['n_queries']:.0f} max {st['refine_max']} (cap 512)")
+        assert st["refine_max"] <= 512
+        eng.set_option("knn_filter", "fp32")
+        d2f, idxf = eng.search(Q, k)
+        assert eng.search_stats()["filter"] == "fp32"
+    finally:
+        eng.set_option("knn_filter", "auto")
+        eng.set_option("search_stats", 0)
+    assert torch.equal(idx, idxf) and torch.equal(d2, d2f)          # bit-identical to the fp32 filter path, all 512 queries
+    rd2, ridx = O().topk_from_d2(planted_1m["d2_oracle"][:, :n_rows], k)
+    dd = d2.cpu().numpy()[sel]
+    ii = idx.cpu().numpy()[sel]
+    assert np.abs(dd - rd2).max() < 1e-5                              # fp32 fma chain (1024 terms) vs fp64, unit vectors
+    # ids: identical wherever the ORACLE's neighbouring distances are further apart than fp32 rounding can swap
+    gap_prev = np.diff(rd2, axis=1, prepend=-1.0)
+    gap_next = np.diff(rd2, axis=1, append=10.0)
+    clear = np.minimum(gap_prev, gap_next) > 1e-5
+    assert clear.mean() > 0.9
+    assert np.array_equal(ii[clear], ridx[clear])
+    # ... and EVERY remaining mismatch is a near-tie, not a wrong neighbour: the row the device put at that rank has
+    # an oracle distance within 1e-5 of the oracle's distance at that rank
+    qq, rr = np.nonzero(ii != ridx)
+    if len(qq):
+        m = planted_1m["d2_oracle"]
+        assert np.abs(m[qq, ii[qq, rr]] - rd2[qq, rr]).max() < 1e-5
+
+
+def test_knn_one_overflowing_query_is_redone_alone(eng):
+    """300 queries against 200 k rows; ONE query has 600 exact duplicates of itself in the database, which overflow
+    its 512-entry refine list.  Only that row may take the exact matrix path (search_stats / stage counters), every
+    result must equal the oracle's (ties -> lower id)."""
+    import torch
+
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    n, d, nq, k = 200000, 256, 300, 50
+    R = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
+    star = torch.nn.functional.normalize(torch.randn(1, d, device=dev, generator=g), dim=1)
+    dup_rows = torch.arange(0, 600, device=dev) * 331 + 17          # 600 scattered rows
+    R[dup_rows] = star
+    src = torch.randint(0, n - 1, (nq,), device=dev, generator=g)
+    src = torch.where(src % 331 == 17, src + 1, src)               # never a duplicate row: only query 137 sees the 600-way tie
+    Q = torch.nn.functional.normalize(R[src] + (1.0 / d ** 0.5) * torch.randn(nq, d, device=dev, generator=g), dim=1)
+    Q[137] = star[0]
+    eng.db_reset()
+    eng.db_add(R)
+    eng.set_profiling(True)
+    eng.profile_reset()
+    d2, idx = eng.search(Q, k)
+    st = eng.search_stats()
+    ms, rows_redone = eng.stage_ms("knn_fallback")
+    eng.set_profiling(False)
+    assert st["levels"] >= 1 and st["filter"] == "f16"
+    assert st["n_fallback"] == 1 and rows_redone == 1, (st, rows_redone)
+    rd2, ridx = O().topk_from_d2(O().l2_matrix(R.cpu().numpy(), Q.cpu().numpy()), k)
+    dd, ii = d2.cpu().numpy(), idx.cpu().numpy()
+    assert np.abs(dd - rd2).max() < 1e-5
+    assert np.array_equal(ii[137], np.sort(dup_rows.cpu().numpy())[:k])    # 600-way tie: the k lowest ids
+    assert np.abs(dd[137]).max() < 1e-6
+    clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
+    clear[137] = False
+    assert np.array_equal(ii[clear], ridx[clear])
+    # with no overflow the stage does not exist / is not charged
+    eng.set_profiling(True)
+    eng.profile_reset()
+    eng.search(Q[:100], k)
+    assert eng.search_stats()["n_fallback"] == 0
+    with pytest.raises(Exception):
+        eng.stage_ms("knn_fallback")
+    eng.set_profiling(False)
+
+
+# ------------------------------------------------------------------------------------------------
+# (b) segment-VLAD and the fused VLAD -> PCA at the benchmarked shape
+# ------------------------------------------------------------------------------------------------
+def _bench_image(j):
+    C = synth().make_vocab(64, 1536, seed=1000)
+    tok = synth().make_tokens(C, 34 * 45, seed=2005 + 10 * j)
+    masks = synth().make_masks(50, 240, 320, seed=2105 + 10 * j)
+    return C, tok, masks
+
+
+def test_vlad_bench_shape_k64_d1536_golden(eng):
+    """K = 64 WITH D = 1536, N = 1530, S = 50, order 3 (assign_wide_kernel<2> + aggregate_kernel) against the fixture
+    generated by the reference's vlad_matmuls_per_cluster (func_vpr.py:1181-1210), and the K-parametric C-ABI entry
+    segvlad_cluster_aggregate on the same residuals."""
+    z = np.load(os.path.join(G, "vlad_bench_shape.npz"))
+    C, tok, masks = _bench_image(0)
+    K, D, N, S = 64, 1536, 1530, 50
+    eng.set_vocab(C)
+    bits = eng.incidence(masks.astype(np.uint8), 480, 640)
+    inc = O().unpack_bits_u64(bits.cpu().numpy().view(np.uint64), N)
+    assert np.array_equal(np.packbits(inc, axis=1), z["inc"])                       # bit-exact
+    cent = eng.mask_centroids(masks.astype(np.uint8))
+    adj = eng.adjacency(cent, np.array([0, S], np.int32), 3, check_empty=True).cpu().numpy().reshape(S, S)
+    assert np.array_equal(adj.astype(bool), z["adj"])                               # device Delaunay == Qhull fixture
+    r = eng.seg_vlad(tok[None], bits, np.array([0, S], np.int32), adj.reshape(-1), want_labels=True)
+    labels = r["labels"].cpu().numpy()[0]
+    assert np.array_equal(labels, z["labels"])
+    out = r["out"].cpu().numpy().astype(np.float64)
+    Gm = np.random.Generator(np.random.PCG64(778)).standard_normal((K * D, 16))
+
+    def check(o):
+        assert np.abs(o[:, ::127] - z["sub"]).max() < 1e-6          # fp32 device vs the reference's fp64, unit-norm rows
+        assert np.abs(o[:, :256] - z["head"]).max() < 1e-6
+        assert np.abs(o[:, -256:] - z["tail"]).max() < 1e-6
+        assert np.abs(o @ Gm - z["proj"]).max() < 2e-4
+
+    check(out)
+    ref = O().seg_vlad(tok, inc, C, z["adj"])
+    assert (1 - cos_rows(out, ref)).max() < 1e-6 and np.abs(out - ref).max() < 1e-6
+    # vlad_matmuls_per_cluster surface: given residuals + labels
+    xn = O().normalize_tokens_f32(tok)
+    res = (xn - C[labels]).astype(np.float32)
+    out2 = eng.cluster_aggregate(K, res, labels, bits, adj.reshape(S, S)).cpu().numpy().astype(np.float64)
+    check(out2)
+
+
+def test_images_pca_fused_bench_shape_split_k(eng):
+    """segvlad_images_pca at KD = 98 304 -> P = 1024 on 22 images (1100 rows: the 256x256-tile split-K GEMM the bench
+    runs), against oracle seg_vlad -> pca_transform -> normalizeFeat in fp64, and against the unfused two-call path."""
+    K, D, N, S, P, B = 64, 1536, 1530, 50, 1024, 22
+    C = synth().make_vocab(K, D, seed=1000)
+    mean, comps, var = synth().make_pca_model(K * D, P, seed=5000)
+    eng.set_vocab(C)
+    eng.pca_set(mean, comps, var, whiten=True)
+    toks, incs, adjs = [], [], []
+    for j in range(B):
+        _, tok, masks = _bench_image(j)
+        toks.append(tok)
+        incs.append(O().incidence(masks, 480, 640))
+        adjs.append(O().nbr_masks_agg_fast_single([m for m in masks], 3))
+    offs = (np.arange(B + 1) * S).astype(np.int32)
+    bits = np.concatenate([O().pack_bits_u64(i) for i in incs]).view(np.int64)
+    adj = np.concatenate([a.astype(np.uint8).reshape(-1) for a in adjs])
+    tk = np.stack(toks)
+    fused = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=True, want_desc=True)
+    y = fused["out"].cpu().numpy()
+    desc = fused["desc"].cpu().numpy()
+    two = eng.pca_apply(eng.seg_vlad(tk, bits, offs, adj)["out"], l2norm=True).cpu().numpy()
+    assert np.abs(y - two).max() <= 2e-5                                  # unit rows; both fp32-class
+    y_nodesc = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=True)["out"].cpu().numpy()
+    assert np.array_equal(y, y_nodesc)                                    # the descriptor output does not change y
+    compsd = comps.astype(np.float64)
+    worst = 0.0
+    for b in range(B):
+        ref_desc = O().seg_vlad(toks[b], incs[b], C, adjs[b])
+        assert np.abs(desc[b * S:(b + 1) * S] - ref_desc).max() < 1e-6
+        ref = O().normalize_feat(O().pca_transform(ref_desc, mean, compsd, var, True))
+        yb = y[b * S:(b + 1) * S].astype(np.float64)
+        worst = max(worst, np.abs(yb - ref).max())
+        assert (1 - cos_rows(yb, ref)).max() < 1e-6
+    assert worst < 1e-4          # north_star tolerance for cosine-scale quantities (unit rows); measured ~1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# (c) VPAir geometry + PCA 512 (BASELINE config 5)
+# ------------------------------------------------------------------------------------------------
+def test_vpair_geometry_and_pca512_golden(eng):
+    """800x600 image, masks 300x400, N = 42 * 57 = 2394 (place_rec_global_config.py:97-111), K = 32 real vocabulary,
+    order 3, then PCA-whitening to 512 -- every stage against the fixture produced by the reference's
+    seg_vlad_gpu_single_img + sklearn's PCA.transform."""
+    z = np.load(os.path.join(G, "vlad_vpair_shape.npz"))
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    H, W, S, N = 600, 800, 50, 42 * 57
+    tok = synth().make_tokens(voc, N, seed=2006)
+    masks = synth().make_masks(S, 300, 400, seed=2106, hmax=75, wmax=100).astype(np.uint8)
+    eng.set_vocab(voc)
+    bits, cent = eng.incidence_centroids(masks, H, W)
+    inc = O().unpack_bits_u64(bits.cpu().numpy().view(np.uint64), N)
+    assert np.array_equal(np.packbits(inc, axis=1), z["inc"])                        # bit-exact incidence at 2x upsample
+    adj = eng.adjacency(cent, np.array([0, S], np.int32), 3, check_empty=True).cpu().numpy()
+    assert np.array_equal(adj.reshape(S, S).astype(bool), z["adj"])
+    mean, comps, var = synth().make_pca_model(32 * 1536, 512, seed=5001)
+    eng.pca_set(mean, comps, var, whiten=True)
+    fused = eng.seg_vlad_pca(tok[None], bits, np.array([0, S], np.int32), adj, l2norm=False, want_desc=True, want_labels=True)
+    assert np.array_equal(fused["labels"].cpu().numpy()[0], z["labels"])
+    out = fused["desc"].cpu().numpy().astype(np.float64)
+    assert np.abs(out[:, ::61] - z["sub"]).max() < 1e-6
+    assert np.abs(out[:, :256] - z["head"]).max() < 1e-6
+    assert np.abs(out[:, -256:] - z["tail"]).max() < 1e-6
+    Gm = np.random.Generator(np.random.PCG64(779)).standard_normal((32 * 1536, 16))
+    assert np.abs(out @ Gm - z["proj"]).max() < 1e-4
+    y = fused["out"].cpu().numpy().astype(np.float64)
+    ref = z["pca512"]
+    # whitening by up to 1/sqrt(1e-6) amplifies the fp32 descriptor rounding (~1e-8 per entry) to ~1e-5 on outputs
+    # of magnitude ~10: relative tolerance 5e-5 of the largest output, cosine 1 - 1e-6 per row
+    assert np.abs(y - ref).max() < 5e-5 * np.abs(ref).max()
+    assert (1 - cos_rows(y, ref)).max() < 1e-6
+    # the two-call path (segvlad_images + segvlad_pca_apply) agrees
+    y2 = eng.pca_apply(fused["desc"], l2norm=False).cpu().numpy()
+    assert np.abs(y2 - y).max() < 5e-5 * np.abs(ref).max()
+    # a 512-d index over these descriptors (tiny: distance-matrix path), oracle-checked
+    yn = O().normalize_feat(y).astype(np.float32)
+    eng.db_reset()
+    eng.db_add(yn)
+    d2, idx = eng.search(yn, 5)
+    rd2, ridx = O().knn_l2(yn, yn, 5)
+    assert np.array_equal(idx.cpu().numpy()[:, 0], ridx[:, 0]) and np.abs(d2.cpu().numpy() - rd2).max() < 1e-5

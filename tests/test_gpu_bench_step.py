@@ -1,0 +1,54 @@
+"""bench.py's own step on the GPU box (VERDICT r01 #1d, #8): the device predictions of the benchmarked workload must
+equal the fp64 oracle's on >= 20 query images at a difficulty where the oracle's Recall@1 is well below 1 (the vote
+matters), and the N = 2 row-sharded path (two ranks sharing the one GPU, gloo collectives) must give the N = 1
+predictions."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, timeout):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_step_predictions_equal_oracle_on_20_images():
+    j = _run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--verify-images", "20"], 1500)
+    oc = j["oracle_check"]
+    assert oc["images"] == 20
+    assert oc["top1_identical"] == 20, oc                     # north_star: identical top-1 image ids
+    assert oc["sims_max_abs_diff"] < 1e-4, oc                 # north_star: cosine scores within 1e-4
+    assert oc["neighbour_id_mismatches_are_near_ties"], oc
+    assert oc["ok"]
+    assert oc["device_recall_at_1"] == oc["oracle_recall_at_1"]
+    # the workload is hard enough for the vote to matter (oracle Recall@1 ~ 0.8), on all 200 images
+    assert 0.55 <= j["recall_at_1"] <= 0.95, j["recall_at_1"]
+    assert j["filter_dtype"] == "f16" and j["dtype"] == "f32"
+    assert j["search_stats"]["n_fallback"] == 0 and j["search_stats"]["levels"] == 2
+    assert j["roofline"]["bound"] == "mfma" and j["cpu_baseline"]["kind"] == "port"
+
+
+def test_bench_two_ranks_one_gpu_equal_single_rank(tmp_path):
+    """--gpus 2 with both ranks on cuda:0 and gloo collectives: the sharded path (query-descriptor gather, packed
+    (d2, id) all-gather, merge, vote) must reproduce the single-rank predictions exactly."""
+    p1, p2 = str(tmp_path / "p1.npy"), str(tmp_path / "p2.npy")
+    common = ["--steps", "1", "--warmup", "1", "--db-images", "4000", "--query-images", "40", "--no-cpu-baseline"]
+    j1 = _run([sys.executable, "bench.py", *common, "--dump-preds", p1], 900)
+    port = 29500 + (os.getpid() % 2000)
+    j2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "2", "--same-device", "--dist-backend", "gloo", *common,
+               "--dump-preds", p2], 900)
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
+    assert np.array_equal(np.load(p1), np.load(p2))
+    assert j1["recall_at_1"] == j2["recall_at_1"]

@@ -89,6 +89,56 @@ def test_vlad_ref_shape():
     assert np.abs(out @ Gm - z["proj"]).max() < 1e-6
 
 
+def test_vlad_bench_shape_k64_d1536():
+    """The benchmarked shape (K=64, D=1536, N=1530, S=50, order 3): the reference's vlad_matmuls_per_cluster
+    (func_vpr.py:1181-1210, its only K-parametric entry) pins the oracle at KD = 98 304."""
+    z = L("vlad_bench_shape.npz")
+    K, D = int(z["K"]), int(z["D"])
+    C = synth.make_vocab(K, D, seed=1000)
+    tok = synth.make_tokens(C, 34 * 45, seed=2005)
+    masks = synth.make_masks(50, 240, 320, seed=2105)
+    inc = O.incidence(masks, 480, 640)
+    assert np.array_equal(np.packbits(inc, axis=1), z["inc"])
+    adj = O.nbr_masks_agg_fast_single([m for m in masks], 3)
+    assert np.array_equal(adj, z["adj"])
+    out, aux = O.seg_vlad(tok, inc, C, adj, return_aux=True)
+    assert out.shape == (50, K * D)
+    assert np.array_equal(aux["labels"].astype(np.uint8), z["labels"])
+    assert np.abs(out[:, ::127] - z["sub"]).max() < 1e-8
+    assert np.abs(out[:, :256] - z["head"]).max() < 1e-8
+    assert np.abs(out[:, -256:] - z["tail"]).max() < 1e-8
+    Gm = np.random.Generator(np.random.PCG64(778)).standard_normal((K * D, 16))
+    assert np.abs(out @ Gm - z["proj"]).max() < 1e-6
+
+
+def test_vlad_vpair_shape_and_pca512():
+    """VPAir geometry (place_rec_global_config.py:97-111: 800x600, masks 300x400, N = 42*57 = 2394) through the
+    reference's seg_vlad_gpu_single_img, then sklearn's PCA.transform with 512 whitened components (BASELINE config 5)."""
+    z = L("vlad_vpair_shape.npz")
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    tok = synth.make_tokens(voc, 42 * 57, seed=2006)
+    masks = synth.make_masks(50, 300, 400, seed=2106, hmax=75, wmax=100)
+    inc = O.incidence(masks, 600, 800)
+    assert inc.shape == (50, 2394)
+    assert np.array_equal(np.packbits(inc, axis=1), z["inc"])
+    adj = O.nbr_masks_agg_fast_single([m for m in masks], 3)
+    assert np.array_equal(adj, z["adj"])
+    out, aux = O.seg_vlad(tok, inc, voc, adj, return_aux=True)
+    assert np.array_equal(aux["labels"].astype(np.uint8), z["labels"])
+    assert np.abs(out[:, ::61] - z["sub"]).max() < 1e-8
+    assert np.abs(out[:, :256] - z["head"]).max() < 1e-8
+    assert np.abs(out[:, -256:] - z["tail"]).max() < 1e-8
+    Gm = np.random.Generator(np.random.PCG64(779)).standard_normal((32 * 1536, 16))
+    assert np.abs(out @ Gm - z["proj"]).max() < 1e-6
+    mean, comps, var = synth.make_pca_model(32 * 1536, 512, seed=5001)
+    y = O.pca_transform(out, mean, comps, var, True)
+    # the fixture transformed the REFERENCE's descriptor, the oracle transforms its own (<= 1e-8 apart, asserted above);
+    # whitening by 1/sqrt(1e-6) amplifies that to ~1e-5 absolute on outputs of magnitude ~10
+    assert np.abs(y - z["pca512"]).max() < 2e-5
+    cosr = (y * z["pca512"]).sum(1) / (np.linalg.norm(y, axis=1) * np.linalg.norm(z["pca512"], axis=1))
+    assert (1 - cosr).max() < 1e-12
+
+
 def test_vlad_ref_shape_adversarial_labels():
     """Isotropic tokens: near-tied assignments.  Labels must agree wherever the fp64 top-2 gap
     exceeds fp32 GEMM rounding; the descriptor must still agree where labels agree everywhere."""
@@ -189,3 +239,18 @@ def test_merge_topk_equals_global():
         ip.append(i + a)
     dm, im = O.merge_topk(dp, ip, 10)
     assert np.array_equal(im, idx) and np.array_equal(dm, d2)
+
+
+def test_knn_matrix_and_partition_topk_equal_the_argsort_form():
+    """l2_matrix + topk_from_d2 (what the GPU tests at 1 M rows use) == knn_l2 (stable argsort), ties included."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    R = rng.standard_normal((700, 24)).astype(np.float32)
+    R[100:140] = R[7]                     # 41 identical rows: ties straddle the k-th position
+    Q = np.concatenate([R[[7, 300]], rng.standard_normal((6, 24)).astype(np.float32)])
+    for k in (1, 5, 20, 60):
+        d2, idx = O.knn_l2(R, Q, k)
+        m = O.l2_matrix(R, Q, rows_block=256)
+        d2b, idxb = O.topk_from_d2(m, k)
+        assert np.array_equal(d2, d2b) and np.array_equal(idx, idxb)
+    d2s, idxs = O.topk_from_d2(O.l2_matrix(R[:3], Q), 5)      # fewer rows than k
+    assert np.all(idxs[:, 3:] == -1) and np.all(np.isinf(d2s[:, 3:]))

@@ -47,7 +47,10 @@ def test_image_to_tokens_layout_and_preprocessing(tiny):
     x = (x - torch.tensor(pr.IMAGENET_MEAN).view(3, 1, 1)) / torch.tensor(pr.IMAGENET_STD).view(3, 1, 1)
     x = x[:, 2:58, 2:72][None]
     ref = tiny(x).reshape(1, 4, 5, 48).permute(0, 3, 1, 2)
-    assert torch.allclose(out, ref, atol=1e-6)
+    assert torch.allclose(pr.image_to_tokens(img, tiny, normalize=False), ref, atol=1e-6)   # getAnyLocFt(upsample=False)
+    # process_single_DINO L2-normalises over the channel axis before the map is stored (func_vpr.py:561)
+    assert torch.allclose(out, torch.nn.functional.normalize(ref, dim=1), atol=1e-6)
+    assert torch.allclose(out.norm(dim=1), torch.ones(1, 4, 5), atol=1e-5)
     # the 17places geometry: 480 x 640 -> 476 x 630 -> 34 x 45 = 1530 tokens (bench.py's N)
     c = pr.center_crop_to_patches(torch.zeros(3, 480, 640))
     assert c.shape == (3, 476, 630) and (476 // 14) * (630 // 14) == 1530

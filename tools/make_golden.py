@@ -194,6 +194,44 @@ def main():
     np.savez_compressed(f"{OUT}/vlad_k64.npz", D=D, K=K, S=S, N=N, inc=inc64, adj=adj64, labels=lab.numpy(),
                         vlad=out64.numpy())
 
+    # ---- bench shape: K=64, D=1536, N=1530, S=50, order 3 through the only K-parametric entry --------------
+    # (vlad_single hard-codes 32 clusters, func_vpr.py:1142; the incidence is captured from a K=32 run of the
+    #  reference's seg_vlad_gpu_single_img over the same masks)
+    D, K, H, W, S = 1536, 64, 480, 640, 50
+    C64b = synth.make_vocab(K, D, seed=1000)
+    tokb = synth.make_tokens(C64b, 34 * 45, seed=2005)
+    masksb = synth.make_masks(S, 240, 320, seed=2105)
+    adjb = fv.nbrMasksAGGFastSingle([m for m in masksb], 3)
+    _, incb, _ = run_seg_vlad(fv, rec, tokb, masksb, voc, H, W, None, D)
+    xn = F.normalize(torch.from_numpy(tokb.T.copy()), dim=1)
+    cn = F.normalize(torch.from_numpy(C64b), dim=1)
+    labb = torch.argmax(xn @ cn.T, dim=1)
+    resb = xn - torch.from_numpy(C64b)[labb]
+    outb, _ = fv.vlad_matmuls_per_cluster(K, torch.from_numpy(incb).double(), resb.double(), labb, adjMat=adjb.double())
+    outb = outb.numpy()
+    Gb = np.random.Generator(np.random.PCG64(778)).standard_normal((K * D, 16))
+    np.savez_compressed(f"{OUT}/vlad_bench_shape.npz", S=S, K=K, D=D, adj=adjb.numpy(), labels=labb.numpy().astype(np.uint8),
+                        inc=np.packbits(incb, axis=1), proj=outb @ Gb, sub=outb[:, ::127], head=outb[:, :256], tail=outb[:, -256:])
+    print("bench-shape K=64 D=1536 descriptor", outb.shape)
+
+    # ---- VPAir geometry (place_rec_global_config.py:97-111): 800x600 image, masks 300x400, N = 42*57 = 2394 -------
+    D, K, H, W, S = 1536, 32, 600, 800, 50
+    tokv = synth.make_tokens(voc, 42 * 57, seed=2006)
+    masksv = synth.make_masks(S, 300, 400, seed=2106, hmax=75, wmax=100)
+    adjv = fv.nbrMasksAGGFastSingle([m for m in masksv], 3)
+    gdv, incv, labv = run_seg_vlad(fv, rec, tokv, masksv, voc, H, W, adjv, D)
+    Gv = np.random.Generator(np.random.PCG64(779)).standard_normal((K * D, 16))
+    # PCA-whitened 512-d descriptors (BASELINE config 5): sklearn's transform given a (synthetic, seeded) model
+    from sklearn.decomposition import PCA as _PCA
+    pm_mean, pm_comps, pm_var = synth.make_pca_model(K * D, 512, seed=5001)
+    pv = _PCA(n_components=512, whiten=True)
+    pv.mean_, pv.components_, pv.explained_variance_ = pm_mean.astype(np.float64), pm_comps.astype(np.float64), pm_var.astype(np.float64)
+    yv = pv.transform(gdv)
+    np.savez_compressed(f"{OUT}/vlad_vpair_shape.npz", S=S, adj=adjv.numpy(), labels=labv.astype(np.uint8),
+                        inc=np.packbits(incv, axis=1), proj=gdv @ Gv, sub=gdv[:, ::61], head=gdv[:, :256], tail=gdv[:, -256:],
+                        pca512=yv)
+    print("VPAir-shape descriptor", gdv.shape, "pca512", yv.shape)
+
     # ---- incidence cases (captured mask_idx) --------------------------------------------------------
     ic = {}
     cases = [("same", 112, 140, 112, 140), ("x2", 60, 80, 120, 160), ("x2clip", 63, 77, 126, 154),

@@ -1,65 +1,113 @@
 #!/usr/bin/env python3
-"""Summarise two rocprofv3 PMC passes (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; never combined with
-tracing of other domains) of `bench.py --pmc-calibrate` into HBM bytes per launch per kernel.
+"""Summarise separate rocprofv3 --pmc passes (never combined with other trace domains) over tools/probe_counters.py
+into per-kernel HBM bytes per launch and MFMA utilisation.
 
-    python tools/pmc_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv WORKLOAD_KEY > profiles/rNN_pmc_traffic.json
+    python tools/pmc_summary.py --key WORKLOAD_KEY --fetch F_counter_collection.csv --write W_counter_collection.csv \
+        [--sq SQ_counter_collection.csv --sq-trace SQ_kernel_trace.csv] > profiles/rNN_pmc_traffic.json
 
-Calibration: bench.py --pmc-calibrate ends with one torch.sign over a 1 GiB tensor (the only "sign_kernel" dispatch);
-its counter values are mapped to exactly 2^30 bytes read / written, which
-absorbs the counter's unit (KiB) and the gfx950 wide-load correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM section:
-FETCH_SIZE reports 1/2 of the bytes of 16 B/lane streaming reads).  Kernels with a different access width inherit the
-streaming calibration -- treat their absolute numbers as estimates, ratios between variants are unaffected."""
+* HBM bytes: FETCH_SIZE / WRITE_SIZE, calibrated IN THE SAME PASS on the probe's torch.sign over a 1 GiB tensor
+  (2^30 bytes read, 2^30 written): that absorbs the counter unit and the gfx950 wide-load correction
+  (/opt/skills/guides/MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports 1/2 of the bytes of 16 B/lane streaming
+  reads).  Kernels with another access width inherit the streaming calibration: treat absolutes as estimates.
+* MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipes were busy, summed over the chip's 1024 SIMDs)
+  / (1024 x GRBM_GUI_ACTIVE cycles of the dispatch).  GRBM_GUI_ACTIVE is reported per XCD or summed over the 8 XCDs
+  depending on the tool build; the ratio to the dispatch's wall time (kernel trace) tells which, and is recorded.
+* kernel_src_sha: sha256 over csrc/*.hip, *.h at collection time; bench.py quotes a summary only if it matches."""
+import argparse
 import csv
+import hashlib
 import json
-import sys
+import os
 from collections import defaultdict
 
-
-def load(path, counter):
-    rows = []
-    with open(path, newline="") as f:
-        for r in csv.DictReader(f):
-            if r.get("Counter_Name") != counter:
-                continue
-            rows.append((r["Kernel_Name"], float(r["Counter_Value"]), int(r.get("Grid_Size", 0) or 0)))
-    return rows
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def summarise(rows):
-    cal = None
-    for name, v, grid in rows:
-        if "sign_kernel" in name:
-            cal = v   # bench.py --pmc-calibrate: torch.sign over 2^28 floats
-    agg = defaultdict(lambda: [0, 0.0])
-    for name, v, _ in rows:
-        a = agg[name]
-        a[0] += 1
-        a[1] += v
-    return cal, agg
+def kernel_src_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "revisit-anything_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
+def load_counters(path):
+    """{kernel: {counter: [values per dispatch]}}"""
+    out = defaultdict(lambda: defaultdict(list))
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def load_durations(path):
+    out = defaultdict(list)
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            out[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return out
+
+
+def avg(v):
+    return sum(v) / len(v) if v else None
+
+
 def main():
-    fpath, wpath, key = sys.argv[1], sys.argv[2], sys.argv[3]
-    fcal, fagg = summarise(load(fpath, "FETCH_SIZE"))
-    wcal, wagg = summarise(load(wpath, "WRITE_SIZE"))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--key", required=True)
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--sq", default=None)
+    ap.add_argument("--sq-trace", default=None)
+    a = ap.parse_args()
+    F, Wc = load_counters(a.fetch), load_counters(a.write)
+    fcal = next((avg(v["FETCH_SIZE"]) for k, v in F.items() if "sign_kernel" in k and v.get("FETCH_SIZE")), None)
+    wcal = next((avg(v["WRITE_SIZE"]) for k, v in Wc.items() if "sign_kernel" in k and v.get("WRITE_SIZE")), None)
     if not fcal or not wcal:
-        raise SystemExit("calibration copy not found in the PMC output")
+        raise SystemExit("calibration dispatch (torch.sign over 1 GiB) not found in the PMC output")
     fscale, wscale = float(1 << 30) / fcal, float(1 << 30) / wcal
+    SQ = load_counters(a.sq) if a.sq else {}
+    DUR = load_durations(a.sq_trace) if a.sq_trace else {}
     kernels = []
-    for name, (n, tot) in fagg.items():
-        wn, wtot = wagg.get(name, (0, 0.0))
-        rd = tot / n * fscale
-        wr = (wtot / wn * wscale) if wn else 0.0
-        kernels.append({"name": short(name), "launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-                        "hbm_bytes_per_launch": rd + wr})
+    for name, c in F.items():
+        if "elementwise" in name or "sign_kernel" in name or not c.get("FETCH_SIZE"):
+            continue
+        n = len(c["FETCH_SIZE"])
+        rd = avg(c["FETCH_SIZE"]) * fscale
+        wv = Wc.get(name, {}).get("WRITE_SIZE")
+        wr = avg(wv) * wscale if wv else 0.0
+        k = {"name": name, "launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+             "hbm_bytes_per_launch": rd + wr}
+        s = SQ.get(name)
+        if s and s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("GRBM_GUI_ACTIVE"):
+            busy, gui = avg(s["SQ_VALU_MFMA_BUSY_CYCLES"]), avg(s["GRBM_GUI_ACTIVE"])
+            dur = avg(DUR.get(name, []))
+            xcd = 1
+            if dur and gui / dur > 4.0:       # > 4 "GHz": the counter is summed over the 8 XCDs
+                xcd = 8
+            k["mfma_busy_cycles"] = busy
+            k["gui_active_cycles"] = gui / xcd
+            k["gui_active_summed_over_xcds"] = xcd == 8
+            k["mfma_util"] = busy / (1024.0 * gui / xcd) if gui else None
+            if dur:
+                k["avg_duration_ms_under_pmc"] = dur / 1e6
+                k["effective_clock_ghz"] = gui / xcd / dur
+            for extra in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
+                          "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F16"):
+                if s.get(extra):
+                    k[extra.lower()] = avg(s[extra])
+        kernels.append(k)
     kernels.sort(key=lambda k: -k["hbm_bytes_per_launch"] * k["launches"])
-    json.dump({"workload_key": key, "calibration": {"fetch_raw_per_GiB": fcal, "write_raw_per_GiB": wcal,
-                                                    "bytes_per_fetch_unit": fscale, "bytes_per_write_unit": wscale},
-               "kernels": [k for k in kernels if "elementwise" not in k["name"]][:40]}, sys.stdout, indent=1)
+    json.dump({"workload_key": a.key, "kernel_src_sha": kernel_src_sha(),
+               "provenance": "tools/gpu_round_artifacts.sh pmc: rocprofv3 --pmc passes over tools/probe_counters.py",
+               "calibration": {"fetch_raw_per_GiB": fcal, "write_raw_per_GiB": wcal, "bytes_per_fetch_unit": fscale,
+                               "bytes_per_write_unit": wscale},
+               "kernels": kernels[:40]}, __import__("sys").stdout, indent=1)
 
 
 if __name__ == "__main__":
