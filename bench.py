@@ -44,7 +44,7 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
 # Difficulty of the synthetic retrieval task (SURVEY 8d asks for an oracle Recall@1 of about 0.8, so that the vote
 # matters and near-duplicate sibling places are real distractors).  Calibrated on the device with --sweep-own.
-QUERY_OWN_DEFAULT = 0.7
+QUERY_OWN_DEFAULT = 0.12   # device sweep (r02): 0.0 -> 0.20, 0.1 -> 0.73, 0.2 -> 0.965, >= 0.3 -> 1.0 Recall@1
 
 
 FILTER_KIND = "f16"   # set from SegVLADEngine.search_stats() after the first search
