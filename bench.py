@@ -333,8 +333,8 @@ def main():
 
     # ---- per-stage device time (HIP events on the engine stream, summed over the timed steps) ----------------
     stages = {}
-    for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "knn_fallback",
-              "vote"):
+    for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "knn_redo",
+              "knn_fallback", "vote"):
         try:
             ms, n = eng.stage_ms(s)
             stages[s] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps}
@@ -351,7 +351,7 @@ def main():
     n_local_rows = index.n_local
     d_knn = P
     wl_key = f"q{nQ}x{S}_db{nR * S}_d{d_knn}_k{K}_w{world}"
-    main_stages = {k: v for k, v in stages.items() if k != "knn_fallback"}
+    main_stages = {k: v for k, v in stages.items() if k not in ("knn_fallback", "knn_redo")}
     dom = max(main_stages, key=lambda k: main_stages[k]["ms_per_step"]) if main_stages else None
     roof = None
     if dom in ("knn_gemm", "knn_select", "pca"):

@@ -179,17 +179,21 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *        "knn_filter"   auto | f16 | bf16x3 | fp32     arithmetic of the candidate filter GEMM
  *        "pca_arith"    auto | f16x3 | fp32            projection GEMM arithmetic
  *        "search_stats" 0 | 1                          record list occupancies (segvlad_search_stats)
+ *        "knn_heuristic" 1 | 0                         low-rank, a-posteriori verified level thresholds (5-10x fewer
+ *                                                      candidates per level) | rigorous k-th-rank thresholds only
  *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning   */
 int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
 
-/* ---- statistics of the last segvlad_search on this context (HOST array, up to 8 values):
+/* ---- statistics of the last segvlad_search on this context (HOST array, up to 9 values):
  *      [0] filter levels run after the sampled exact level (0 = distance-matrix path)
  *      [1] filter arithmetic used (0 none, 1 f16, 2 bf16x3, 3 fp32)
  *      [2] query rows whose candidate / refine list overflowed and that were redone, alone, on the
  *          exact distance-matrix path (the other rows keep their filtered result)
  *      [3] max and [4] sum of the last level's candidate-list lengths   (option search_stats = 1)
  *      [5] max and [6] sum of the exact-refinement list lengths         (option search_stats = 1)
- *      [7] number of query rows                                                                       */
+ *      [7] number of query rows
+ *      [8] query rows whose low-rank ("heuristic") level thresholds did not verify and that were redone
+ *          with the rigorous k-th-rank thresholds (option knn_heuristic = 0 disables the low-rank thresholds) */
 int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n);
 
 #ifdef __cplusplus

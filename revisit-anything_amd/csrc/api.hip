@@ -116,7 +116,8 @@ int segvlad_create(segvlad_ctx** out, int device_id) {
                                             {"SEGVLAD_F16_GM", "f16_gm"},           {"SEGVLAD_X3_TILE", "x3_tile"},
                                             {"SEGVLAD_X3_GM", "x3_gm"},             {"SEGVLAD_SEARCH_STATS", "search_stats"},
                                             {"SEGVLAD_ASSIGN_NARROW", "assign_narrow"}, {"SEGVLAD_DEBUG_SEARCH", "debug_search"},
-                                            {"SEGVLAD_AGG_KPB", "agg_kpb"}};
+                                            {"SEGVLAD_AGG_KPB", "agg_kpb"},
+                                            {"SEGVLAD_KNN_HEURISTIC", "knn_heuristic"}};
   for (auto& kv : env_keys)
     if (const char* v = getenv(kv[0])) (void)segvlad_set_option(c, kv[1], v);
   if (getenv("SEGVLAD_KNN_FP32")) (void)segvlad_set_option(c, "knn_filter", "fp32");
@@ -156,6 +157,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);
   if (!strcmp(key, "x3_gm")) return as_int(&o.x3_gm);
   if (!strcmp(key, "search_stats")) return as_int(&o.search_stats);
+  if (!strcmp(key, "knn_heuristic")) return as_int(&o.knn_heuristic);
   if (!strcmp(key, "assign_narrow")) return as_int(&o.assign_narrow);
   if (!strcmp(key, "agg_kpb")) return as_int(&o.agg_kpb);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
@@ -166,8 +168,8 @@ int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n) {
   if (!ctx) return SEGVLAD_ERR_ARG;
   if (!stats_out || n < 0) return ctx->fail(SEGVLAD_ERR_ARG, "search_stats: bad arguments");
   const SvSearchStats& t = ctx->sstats;
-  const int64_t v[8] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries};
-  for (int j = 0; j < n && j < 8; ++j) stats_out[j] = v[j];
+  const int64_t v[9] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo};
+  for (int j = 0; j < n && j < 9; ++j) stats_out[j] = v[j];
   return SEGVLAD_OK;
 }
 
@@ -183,7 +185,8 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo,    &ctx->db_f16,   &ctx->s_qf16,
                     &ctx->pca_w1,    &ctx->pca_w2,   &ctx->s_xh1,     &ctx->s_xh2,    &ctx->s_desc,   &ctx->s_tokorder,
                     &ctx->s_laboff,  &ctx->s_rnsorted, &ctx->s_ovf,   &ctx->s_fb_q,   &ctx->s_fb_d2,  &ctx->s_fb_idx,
-                    &ctx->s_fb_rows};
+                    &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
+                    &ctx->s_rd_p1,   &ctx->s_rd_p2};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -641,6 +644,7 @@ int segvlad_db_reset(segvlad_ctx* ctx) {
   ctx->db_maxabs = 0.f;
   ctx->db_rn_max = 0.f;
   ctx->db_rn_max_rows = 0;
+  ctx->db_heur_off = false;
   return SEGVLAD_OK;
 }
 
@@ -681,6 +685,7 @@ int segvlad_db_add(segvlad_ctx* ctx, const float* R, int n, int d, const int32_t
   SV_TRY(sv_launch_row_sumsq(ctx, dst, n, d, ctx->db_norms.as<float>() + ctx->db_n));
   ctx->db_n = n_new;
   ctx->db_d = d;
+  ctx->db_heur_off = false;
   return sv_finish(ctx);
 }
 
@@ -721,7 +726,7 @@ static int search_matrix(segvlad_ctx* ctx, const float* dq, int m, int64_t n, in
   return SEGVLAD_OK;
 }
 
-// rows of the overflow fallback: gather flagged query rows into a dense block, scatter their results back
+// rows of the redo / overflow passes: gather flagged query rows into a dense block, scatter their results back
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, const float* __restrict__ xn,
                                                           const int32_t* __restrict__ rows, int d, float* __restrict__ Y,
                                                           float* __restrict__ yn) {
@@ -739,6 +744,181 @@ __global__ __launch_bounds__(256) void scatter_topk_kernel(const float* __restri
     d2_out[dst * k + j] = d2[(int64_t)r * k + j];
     idx_out[dst * k + j] = idx[(int64_t)r * k + j];
   }
+}
+
+// ---- the level scheme ---------------------------------------------------------------------------------------------
+struct SearchPlan {
+  int levels = 0;          // filter levels after the sampled exact level
+  int64_t stride0 = 1;     // stride of the sampled exact level (16^levels)
+  int kind = 3;            // filter arithmetic: 1 f16, 2 bf16x3, 3 fp32
+  int d = 0, k = 0;
+  int64_t n = 0;
+  float c_eps = 0.f, inv_scale = 1.f, rn_max = 0.f;
+};
+constexpr int SV_RATIO = 16, SV_CAP = 8192, SV_RCAP = 512, SV_CHUNK = 4096;
+
+// Smallest rank r such that a threshold at the r-th smallest value of a 1/16 sample admits, 4 sigma below its
+// expectation 16 r, still `target` values of the full set (relative spread of the r-th order statistic ~ 1/sqrt(r)).
+static int heur_rank(int target) {
+  int r = 16;
+  while (16.0 * r - 64.0 * std::sqrt((double)r) < (double)target) ++r;
+  return r;
+}
+
+// One pass of the level scheme over m <= SV_CHUNK query rows: exact distances to the coarsest sample, then `levels`
+// filter GEMMs over samples 16x larger each, the last one covering every row, then the exact refinement.
+//   rigorous : every threshold is the k-th smallest distance of the previous (coarser) sample -- an UPPER bound of
+//              the k-th smallest of the finer one, so no true neighbour is ever dropped; ~16 k candidates per level.
+//   heuristic: thresholds at much lower ranks r_j (heur_rank) that admit ~16 r_j candidates -- 5-10x fewer -- and are
+//              verified afterwards: a level whose list holds fewer than r_{j+1} entries, or a final list whose k-th
+//              smallest approximate distance A_k exceeds the threshold T it was collected under (then {d2~ <= A_k + 2 eps}
+//              might not be contained in the collected {d2~ <= T + 2 eps}), flags the query; flagged queries are redone
+//              with the rigorous thresholds.  Exactness never depends on the ranks; they only decide how often the redo runs.
+// q16a / q16b: this chunk's 16-bit query planes (f16: plane, unused; bf16x3: hi, lo).  fail_rows [m] / fail_count: flags.
+static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, const float* qp, const uint16_t* q16a,
+                        const uint16_t* q16b, const float* qn, int m, float* out_d2, int64_t* out_idx, uint32_t* fail_rows,
+                        uint32_t* fail_count) {
+  const int d = pl.d, k = pl.k, levels = pl.levels;
+  const int64_t n = pl.n;
+  const float* R = ctx->db_rows.as<float>();
+  const float* rn = ctx->db_norms.as<float>();
+  // rank of the threshold handed to level j+1 (rank[levels] = k: the final top-k)
+  int rank[8];
+  rank[levels] = k;
+  for (int j = levels - 1; j >= 0; --j) rank[j] = heuristic ? std::min(rank[j + 1], heur_rank(rank[j + 1])) : k;
+  const int64_t n0 = (n + pl.stride0 - 1) / pl.stride0;
+  const int64_t ld0 = (n0 + 3) & ~3ll;
+  float* thr = ctx->s_thr_d2.as<float>();
+  const int r0 = rank[0];
+  {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
+    {
+      StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
+      SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0));
+      sc.count();
+    }
+    StageScope sc(ctx, "knn_select");
+    SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, r0, thr, ctx->s_thr_idx.as<int64_t>(), r0, 0));
+    sc.count();
+  }
+  const float* thr_ptr = thr + (r0 - 1);
+  int64_t thr_ld = r0;
+  // rigorous: level-0 thresholds are exact distances, one margin covers the filter's error.  heuristic: the final
+  // check needs the collected set to reach 2 eps beyond the threshold at every level.
+  float eps_mult = heuristic ? 2.f : 1.f;
+  int64_t stride = pl.stride0;
+  std::vector<uint32_t> hcnt;
+  for (int lv = 1; lv <= levels; ++lv) {
+    stride /= SV_RATIO;
+    const int64_t ns = (n + stride - 1) / stride;
+    const bool last = (lv == levels);
+    SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
+    if (pl.kind != 3) {
+      {
+        StageScope sc(ctx, "knn_gemm");
+        if (pl.kind == 1)
+          SV_TRY(sv_launch_f16_filter(ctx, q16a, ctx->db_f16.as<uint16_t>(), m, (int)ns, d, (int)stride, pl.inv_scale, qn, rn, thr_ptr,
+                                      thr_ld, eps_mult, pl.c_eps, pl.rn_max, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
+                                      ctx->s_cand_id.as<uint32_t>(), SV_CAP));
+        else
+          SV_TRY(sv_launch_bf16_filter(ctx, q16a, q16b, ctx->db_hi.as<uint16_t>(), ctx->db_lo.as<uint16_t>(), m, (int)ns, d, (int)stride,
+                                       qn, rn, thr_ptr, thr_ld, eps_mult, pl.c_eps, pl.rn_max, ctx->s_cand_cnt.as<uint32_t>(),
+                                       ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP));
+        sc.count();
+      }
+      if (ctx->opt.debug_search || (ctx->opt.search_stats && last)) {  // candidate-list statistics (synchronises)
+        hcnt.resize(m);
+        SV_HIP(hipStreamSynchronize(ctx->stream));
+        SV_HIP(hipMemcpy(hcnt.data(), ctx->s_cand_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+        uint64_t tot = 0;
+        uint32_t mx = 0, over = 0;
+        for (uint32_t c : hcnt) {
+          tot += c;
+          if (c > mx) mx = c;
+          if (c > (uint32_t)SV_CAP) ++over;
+        }
+        if (last) {
+          ctx->sstats.cand_sum += (int64_t)tot;
+          if ((int64_t)mx > ctx->sstats.cand_max) ctx->sstats.cand_max = mx;
+        }
+        if (ctx->opt.debug_search)
+          fprintf(stderr, "[search] %s m=%d level %d/%d ns=%lld rank %d: candidates mean %.1f max %u, %u lists over cap %d\n",
+                  heuristic ? "heuristic" : "rigorous", m, lv, levels, (long long)ns, rank[lv], (double)tot / m, mx, over, SV_CAP);
+      }
+      StageScope sc(ctx, "knn_select");
+      SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
+                                     SV_CAP, rank[lv], last ? 1 : 0, heuristic ? 1 : 0, thr_ptr, thr_ld, qn, pl.c_eps, pl.rn_max, thr,
+                                     ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count));
+      sc.count();
+      if (last) {
+        SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, k,
+                                      out_d2, out_idx));
+        sc.count();
+        if (ctx->opt.search_stats) {
+          hcnt.resize(m);
+          SV_HIP(hipStreamSynchronize(ctx->stream));
+          SV_HIP(hipMemcpy(hcnt.data(), ctx->s_ref_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+          for (uint32_t c : hcnt) {
+            ctx->sstats.refine_sum += c;
+            if ((int64_t)c > ctx->sstats.refine_max) ctx->sstats.refine_max = c;
+          }
+        }
+      }
+      // thresholds now hold approximate rank-th distances A_r: the exact one is <= A_r + eps, and any row at least that
+      // close has d2~ <= A_r + 2 eps
+      thr_ptr = thr;
+      thr_ld = 1;
+      eps_mult = 2.f;
+    } else {
+      {
+        StageScope sc(ctx, "knn_gemm");
+        SV_TRY(sv_launch_l2_filter(ctx, qp, R, m, (int)ns, d, qn, rn, (int)stride, thr_ptr, thr_ld, ctx->s_cand_cnt.as<uint32_t>(),
+                                   ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP));
+        sc.count();
+      }
+      StageScope sc(ctx, "knn_select");
+      // the filter pass has consumed thr; the select may overwrite it with the tighter thresholds
+      SV_TRY(sv_launch_select_cand(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
+                                   SV_CAP, k, last ? out_d2 : thr, last ? out_idx : nullptr, fail_rows, fail_count));
+      sc.count();
+      thr_ptr = thr + (k - 1);
+      thr_ld = k;
+    }
+  }
+  return SEGVLAD_OK;
+}
+
+// rows flagged in flags[0..nrows) are redone on the exact distance-matrix path; their results replace rows of (d2, idx)
+static int fallback_rows(segvlad_ctx* ctx, const SearchPlan& pl, const float* q, const float* qn, const uint32_t* flags, int nrows,
+                         float* d2, int64_t* idx, int* n_done) {
+  std::vector<uint32_t> hf(nrows);
+  SV_HIP(hipMemcpyAsync(hf.data(), flags, (size_t)nrows * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> rows;
+  for (int r = 0; r < nrows; ++r)
+    if (hf[r]) rows.push_back(r);
+  const int nf = (int)rows.size();
+  *n_done = nf;
+  if (nf == 0) return SEGVLAD_OK;
+  const int d = pl.d, k = pl.k;
+  SV_HIP(ctx->s_fb_rows.reserve((size_t)nf * 4));
+  SV_HIP(ctx->s_fb_q.reserve((size_t)nf * ((size_t)d + 1) * 4));
+  SV_HIP(ctx->s_fb_d2.reserve((size_t)nf * k * 4));
+  SV_HIP(ctx->s_fb_idx.reserve((size_t)nf * k * 8));
+  SV_HIP(hipMemcpyAsync(ctx->s_fb_rows.p, rows.data(), (size_t)nf * 4, hipMemcpyHostToDevice, ctx->stream));
+  float* fq = ctx->s_fb_q.as<float>();
+  float* fqn = fq + (size_t)nf * d;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, ctx->stream, q, qn, ctx->s_fb_rows.as<int32_t>(), d, fq, fqn);
+  SV_HIP(hipGetLastError());
+  {
+    StageScope sc(ctx, "knn_fallback");
+    SV_TRY(search_matrix(ctx, fq, nf, pl.n, d, k, fqn, ctx->s_fb_d2.as<float>(), ctx->s_fb_idx.as<int64_t>()));
+    sc.count(nf);
+  }
+  hipLaunchKernelGGL(scatter_topk_kernel, dim3(nf), dim3(256), 0, ctx->stream, ctx->s_fb_d2.as<float>(), ctx->s_fb_idx.as<int64_t>(),
+                     ctx->s_fb_rows.as<int32_t>(), k, d2, idx);
+  SV_HIP(hipGetLastError());
+  SV_HIP(hipStreamSynchronize(ctx->stream));  // rows[] lives on this frame
+  return SEGVLAD_OK;
 }
 
 int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_out, int64_t* idx_out) {
@@ -766,36 +946,35 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // block) -> s >= 4.8 k.  Databases of <= 32768 rows keep the plain matrix path; the sample never exceeds 32768 rows.
   // (Row shards of 250 k - 500 k rows -- the 1 M-row database on 2 or 4 GPUs -- get two levels instead of a 15 k - 31 k
   // row exact level.)
-  constexpr int RATIO = 16, CAP = 8192;
-  int levels = 0;
-  int64_t stride0 = 1;
+  SearchPlan pl;
+  pl.d = d;
+  pl.k = k;
+  pl.n = n;
   if (n > 32768) {
     const int64_t want = std::max<int64_t>((24 * (int64_t)k + 4) / 5, 512);
-    while (n / (stride0 * RATIO) >= want) {
-      stride0 *= RATIO;
-      ++levels;
+    while (n / (pl.stride0 * SV_RATIO) >= want) {
+      pl.stride0 *= SV_RATIO;
+      ++pl.levels;
     }
-    while (n / stride0 > 32768) {
-      stride0 *= RATIO;
-      ++levels;
+    while (n / pl.stride0 > 32768) {
+      pl.stride0 *= SV_RATIO;
+      ++pl.levels;
     }
   }
-  if (levels == 0 || n / stride0 < 4 * (int64_t)k) {
+  if (pl.levels == 0 || n / pl.stride0 < 4 * (int64_t)k) {
     SV_TRY(search_matrix(ctx, (const float*)dq, nq, n, d, k, qn, (float*)dd2, (int64_t*)didx));
     return sv_finish(ctx);
   }
   const float* R = ctx->db_rows.as<float>();
   const float* rn = ctx->db_norms.as<float>();
-  const int chunk = 4096;
   // filter arithmetic (ctx->opt.knn_filter, see SvOptions): "f16" = one fp16 product (d % 64 == 0), "bf16x3" = three
   // bf16 products (d % 32 == 0), else plain fp32
   const int want_f = ctx->opt.knn_filter;
   const bool f16_path = (want_f == 0 || want_f == 1) && (d % 64 == 0);
   const bool bf16_path = !f16_path && want_f != 3 && (d % 32 == 0);
-  ctx->sstats.levels = levels;
-  ctx->sstats.filter = f16_path ? 1 : bf16_path ? 2 : 3;
-  constexpr int RCAP = 512;
-  float rn_max = 0.f, c_eps = 0.f, inv_scale = 1.f;
+  pl.kind = f16_path ? 1 : bf16_path ? 2 : 3;
+  ctx->sstats.levels = pl.levels;
+  ctx->sstats.filter = pl.kind;
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
     if (new_bytes <= b.cap) return hipSuccess;
     DevBuf nb;
@@ -810,6 +989,14 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     b = nb;
     return hipSuccess;
   };
+  // power-of-two scales that put the largest magnitude in [8192, 16384): no overflow, negligible underflow
+  auto pow2_scale = [](float maxabs) -> float {
+    if (!(maxabs > 0.f) || !std::isfinite(maxabs)) return 1.f;
+    int e;
+    frexpf(maxabs, &e);  // maxabs = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.f, 14 - e);
+  };
+  float qscale = 1.f;
   if (f16_path || bf16_path) {
     if (ctx->db_rn_max_rows < n) {
       float m = 0.f;
@@ -817,18 +1004,11 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       if (m > ctx->db_rn_max) ctx->db_rn_max = m;
       ctx->db_rn_max_rows = n;
     }
-    rn_max = ctx->db_rn_max;
-    SV_HIP(ctx->s_ref_cnt.reserve((size_t)chunk * 4));
-    SV_HIP(ctx->s_ref_id.reserve((size_t)chunk * RCAP * 4));
+    pl.rn_max = ctx->db_rn_max;
+    SV_HIP(ctx->s_ref_cnt.reserve((size_t)SV_CHUNK * 4));
+    SV_HIP(ctx->s_ref_id.reserve((size_t)SV_CHUNK * SV_RCAP * 4));
   }
   if (f16_path) {
-    // power-of-two scales that put the largest magnitude in [8192, 16384): no overflow, negligible underflow
-    auto pow2_scale = [](float maxabs) -> float {
-      if (!(maxabs > 0.f) || !std::isfinite(maxabs)) return 1.f;
-      int e;
-      frexpf(maxabs, &e);  // maxabs = m * 2^e, m in [0.5, 1)
-      return ldexpf(1.f, 14 - e);
-    };
     if (ctx->db_f16_rows < n) {
       float m_new = 0.f;
       SV_TRY(sv_maxabs(ctx, R + (size_t)ctx->db_f16_rows * d, (n - ctx->db_f16_rows) * d, &m_new));
@@ -845,12 +1025,12 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     }
     float qmax = 0.f;
     SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
-    const float qscale = pow2_scale(qmax);
+    qscale = pow2_scale(qmax);
     SV_HIP(ctx->s_qf16.reserve((size_t)nq * d * 2));
     SV_TRY(sv_launch_to_f16(ctx, (const float*)dq, (int64_t)nq * d, qscale, ctx->s_qf16.as<uint16_t>()));
-    inv_scale = 1.f / (qscale * ctx->db_f16_scale);
+    pl.inv_scale = 1.f / (qscale * ctx->db_f16_scale);
     // |d2~ - d2| <= 2 * (2^-10 + 2^-22 + 2*d*2^-24) * ||q|| * ||r||   (+25 % slack)
-    c_eps = 2.5f * (1.f / 1024.f + 1.f / 4194304.f + 2.f * (float)d / 16777216.f);
+    pl.c_eps = 2.5f * (1.f / 1024.f + 1.f / 4194304.f + 2.f * (float)d / 16777216.f);
   } else if (bf16_path) {
     // lazily extend the bf16 planes to the rows added since the last search
     if (ctx->db_split_rows < n) {
@@ -862,156 +1042,90 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       ctx->db_split_rows = n;
     }
     // |d2~ - d2| <= 2 * (3*2^-16 + 4*d*2^-24) * ||q|| * ||r||   (+25 % slack)
-    c_eps = 2.5f * (3.f / 65536.f + 4.f * (float)d / 16777216.f);
+    pl.c_eps = 2.5f * (3.f / 65536.f + 4.f * (float)d / 16777216.f);
     SV_HIP(ctx->s_qh.reserve((size_t)nq * d * 2));
     SV_HIP(ctx->s_ql.reserve((size_t)nq * d * 2));
     SV_TRY(sv_launch_split_bf16(ctx, (const float*)dq, (int64_t)nq * d, ctx->s_qh.as<uint16_t>(), ctx->s_ql.as<uint16_t>()));
   }
-  SV_HIP(ctx->s_cand_cnt.reserve((size_t)chunk * 4));
-  SV_HIP(ctx->s_cand_d2.reserve((size_t)chunk * CAP * 4));
-  SV_HIP(ctx->s_cand_id.reserve((size_t)chunk * CAP * 4));
-  SV_HIP(ctx->s_thr_d2.reserve((size_t)chunk * k * 4));
-  SV_HIP(ctx->s_thr_idx.reserve((size_t)chunk * k * 8));
-  // overflow bookkeeping: one flag per query row + their count (word nq).  A query whose candidate or refine list
-  // overflowed is redone ALONE on the exact matrix path after the levels; the others keep their filtered result.
+  SV_HIP(ctx->s_cand_cnt.reserve((size_t)SV_CHUNK * 4));
+  SV_HIP(ctx->s_cand_d2.reserve((size_t)SV_CHUNK * SV_CAP * 4));
+  SV_HIP(ctx->s_cand_id.reserve((size_t)SV_CHUNK * SV_CAP * 4));
+  SV_HIP(ctx->s_thr_d2.reserve((size_t)SV_CHUNK * k * 4));
+  SV_HIP(ctx->s_thr_idx.reserve((size_t)SV_CHUNK * k * 8));
+  const int64_t n0 = (n + pl.stride0 - 1) / pl.stride0;
+  SV_HIP(ctx->s_dist.reserve((size_t)SV_CHUNK * ((n0 + 3) & ~3ll) * 4));
+  // Flags: [nq] rows + 1 count.  A heuristic pass flags the queries whose low-rank thresholds did not verify (-> redo
+  // with the rigorous thresholds, below); a rigorous pass flags list overflows (-> exact distance-matrix path, alone).
+  const bool heuristic = pl.kind != 3 && ctx->opt.knn_heuristic && !ctx->db_heur_off && heur_rank(k) < k;
   SV_HIP(ctx->s_ovf.reserve(((size_t)nq + 1) * 4));
   SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ((size_t)nq + 1) * 4, ctx->stream));
-  uint32_t* ovf_rows = ctx->s_ovf.as<uint32_t>();
-  uint32_t* ovf_count = ovf_rows + nq;
-  const int64_t n0 = (n + stride0 - 1) / stride0;
-  const int64_t ld0 = (n0 + 3) & ~3ll;
-  SV_HIP(ctx->s_dist.reserve((size_t)chunk * ld0 * 4));
-  std::vector<uint32_t> hcnt;
-  for (int q0 = 0; q0 < nq; q0 += chunk) {
-    const int m = (nq - q0 < chunk) ? (nq - q0) : chunk;
-    const float* qp = (const float*)dq + (size_t)q0 * d;
-    float* thr = ctx->s_thr_d2.as<float>();
-    {  // level 0: exact (fp32) top-k of the coarsest sample -> thr[q][k-1]
-      {
-        StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
-        SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn + q0, rn, (int)stride0));
-        sc.count();
-      }
-      StageScope sc(ctx, "knn_select");
-      SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, k, thr, ctx->s_thr_idx.as<int64_t>(), k, 0));
-      sc.count();
-    }
-    const float* thr_ptr = thr + (k - 1);
-    int64_t thr_ld = k;
-    float eps_mult = 1.f;  // level-0 thresholds are exact distances: one margin covers the filter's error
-    int64_t stride = stride0;
-    for (int lv = 1; lv <= levels; ++lv) {
-      stride /= RATIO;
-      const int64_t ns = (n + stride - 1) / stride;
-      const bool last = (lv == levels);
-      SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
-      if (f16_path || bf16_path) {
-        {
-          StageScope sc(ctx, "knn_gemm");
-          if (f16_path)
-            SV_TRY(sv_launch_f16_filter(ctx, ctx->s_qf16.as<uint16_t>() + (size_t)q0 * d, ctx->db_f16.as<uint16_t>(), m, (int)ns, d,
-                                        (int)stride, inv_scale, qn + q0, rn, thr_ptr, thr_ld, eps_mult, c_eps, rn_max,
-                                        ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
-          else
-            SV_TRY(sv_launch_bf16_filter(ctx, ctx->s_qh.as<uint16_t>() + (size_t)q0 * d, ctx->s_ql.as<uint16_t>() + (size_t)q0 * d,
-                                         ctx->db_hi.as<uint16_t>(), ctx->db_lo.as<uint16_t>(), m, (int)ns, d, (int)stride, qn + q0, rn,
-                                         thr_ptr, thr_ld, eps_mult, c_eps, rn_max, ctx->s_cand_cnt.as<uint32_t>(),
-                                         ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
-          sc.count();
-        }
-        if (ctx->opt.debug_search || (ctx->opt.search_stats && last)) {  // candidate-list statistics (synchronises)
-          hcnt.resize(m);
-          SV_HIP(hipStreamSynchronize(ctx->stream));
-          SV_HIP(hipMemcpy(hcnt.data(), ctx->s_cand_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-          uint64_t tot = 0;
-          uint32_t mx = 0, over = 0;
-          for (uint32_t c : hcnt) {
-            tot += c;
-            if (c > mx) mx = c;
-            if (c > (uint32_t)CAP) ++over;
-          }
-          if (last) {
-            ctx->sstats.cand_sum += (int64_t)tot;
-            if ((int64_t)mx > ctx->sstats.cand_max) ctx->sstats.cand_max = mx;
-          }
-          if (ctx->opt.debug_search)
-            fprintf(stderr, "[search] q0=%d m=%d level %d/%d ns=%lld: candidates mean %.1f max %u, %u lists over cap %d\n", q0, m, lv,
-                    levels, (long long)ns, (double)tot / m, mx, over, CAP);
-        }
-        StageScope sc(ctx, "knn_select");
-        SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
-                                       ctx->s_cand_id.as<uint32_t>(), m, CAP, k, last ? 1 : 0, qn + q0, c_eps, rn_max, thr,
-                                       ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), RCAP, ovf_rows + q0,
-                                       ovf_count));
-        sc.count();
-        if (last) {
-          SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn + q0, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(),
-                                        RCAP, k, (float*)dd2 + (size_t)q0 * k, (int64_t*)didx + (size_t)q0 * k));
-          sc.count();
-          if (ctx->opt.search_stats) {
-            hcnt.resize(m);
-            SV_HIP(hipStreamSynchronize(ctx->stream));
-            SV_HIP(hipMemcpy(hcnt.data(), ctx->s_ref_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-            for (uint32_t c : hcnt) {
-              ctx->sstats.refine_sum += c;
-              if ((int64_t)c > ctx->sstats.refine_max) ctx->sstats.refine_max = c;
-            }
-          }
-        }
-        // thresholds now hold approximate k-th distances A_k: the exact k-th is <= A_k + eps, and any true
-        // neighbour has d2~ <= A_k + 2 eps
-        thr_ptr = thr;
-        thr_ld = 1;
-        eps_mult = 2.f;
-      } else {
-        {
-          StageScope sc(ctx, "knn_gemm");
-          SV_TRY(sv_launch_l2_filter(ctx, qp, R, m, (int)ns, d, qn + q0, rn, (int)stride, thr_ptr, thr_ld,
-                                     ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), CAP));
-          sc.count();
-        }
-        StageScope sc(ctx, "knn_select");
-        // the filter pass has consumed thr; the select may overwrite it with the tighter thresholds
-        SV_TRY(sv_launch_select_cand(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(),
-                                     m, CAP, k, last ? (float*)dd2 + (size_t)q0 * k : thr,
-                                     last ? (int64_t*)didx + (size_t)q0 * k : nullptr, ovf_rows + q0, ovf_count));
-        sc.count();
-        thr_ptr = thr + (k - 1);
-        thr_ld = k;
-      }
-    }
+  uint32_t* flag_rows = ctx->s_ovf.as<uint32_t>();
+  uint32_t* flag_count = flag_rows + nq;
+  auto plane_a = [&](const DevBuf& f16, const DevBuf& hi, int64_t q0) -> const uint16_t* {
+    return (pl.kind == 1 ? reinterpret_cast<const uint16_t*>(f16.p) : reinterpret_cast<const uint16_t*>(hi.p)) + (size_t)q0 * d;
+  };
+  for (int q0 = 0; q0 < nq; q0 += SV_CHUNK) {
+    const int m = (nq - q0 < SV_CHUNK) ? (nq - q0) : SV_CHUNK;
+    SV_TRY(levels_chunk(ctx, pl, heuristic, (const float*)dq + (size_t)q0 * d, pl.kind == 3 ? nullptr : plane_a(ctx->s_qf16, ctx->s_qh, q0),
+                        pl.kind == 2 ? ctx->s_ql.as<uint16_t>() + (size_t)q0 * d : nullptr, qn + q0, m, (float*)dd2 + (size_t)q0 * k,
+                        (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count));
   }
-  uint32_t n_ovf = 0;
-  SV_HIP(hipMemcpyAsync(&n_ovf, ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t n_flag = 0;
+  SV_HIP(hipMemcpyAsync(&n_flag, flag_count, 4, hipMemcpyDeviceToHost, ctx->stream));
   SV_HIP(hipStreamSynchronize(ctx->stream));
-  if (n_ovf) {
-    // redo ONLY the flagged query rows on the exact matrix path
+  if (n_flag && !heuristic) {
+    int nf = 0;
+    SV_TRY(fallback_rows(ctx, pl, (const float*)dq, qn, flag_rows, nq, (float*)dd2, (int64_t*)didx, &nf));
+    ctx->sstats.n_fallback = nf;
+  } else if (n_flag) {
+    // ---- redo of the flagged queries with the rigorous thresholds, as one dense batch ---------------------------------
     std::vector<uint32_t> hf(nq);
-    SV_HIP(hipMemcpy(hf.data(), ovf_rows, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    SV_HIP(hipMemcpy(hf.data(), flag_rows, (size_t)nq * 4, hipMemcpyDeviceToHost));
     std::vector<int32_t> rows;
     for (int q = 0; q < nq; ++q)
       if (hf[q]) rows.push_back(q);
-    const int nf = (int)rows.size();
-    ctx->sstats.n_fallback = nf;
-    SV_HIP(ctx->s_fb_rows.reserve((size_t)nf * 4));
-    SV_HIP(ctx->s_fb_q.reserve((size_t)nf * ((size_t)d + 1) * 4));
-    SV_HIP(ctx->s_fb_d2.reserve((size_t)nf * k * 4));
-    SV_HIP(ctx->s_fb_idx.reserve((size_t)nf * k * 8));
-    SV_HIP(hipMemcpyAsync(ctx->s_fb_rows.p, rows.data(), (size_t)nf * 4, hipMemcpyHostToDevice, ctx->stream));
-    float* fq = ctx->s_fb_q.as<float>();
-    float* fqn = fq + (size_t)nf * d;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, ctx->stream, (const float*)dq, qn, ctx->s_fb_rows.as<int32_t>(), d,
-                       fq, fqn);
+    const int nr = (int)rows.size();
+    ctx->sstats.n_redo = nr;
+    if ((int64_t)nr * 4 > nq && nq >= 64) ctx->db_heur_off = true;   // the sample misleads on this database: stop guessing
+    SV_HIP(ctx->s_rd_rows.reserve((size_t)nr * 4));
+    SV_HIP(ctx->s_rd_q.reserve((size_t)nr * ((size_t)d + 1) * 4));
+    SV_HIP(ctx->s_rd_d2.reserve((size_t)nr * k * 4));
+    SV_HIP(ctx->s_rd_idx.reserve((size_t)nr * k * 8));
+    SV_HIP(ctx->s_rd_flags.reserve(((size_t)nr + 1) * 4));
+    SV_HIP(hipMemsetAsync(ctx->s_rd_flags.p, 0, ((size_t)nr + 1) * 4, ctx->stream));
+    SV_HIP(hipMemcpyAsync(ctx->s_rd_rows.p, rows.data(), (size_t)nr * 4, hipMemcpyHostToDevice, ctx->stream));
+    float* rq = ctx->s_rd_q.as<float>();
+    float* rqn = rq + (size_t)nr * d;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nr), dim3(256), 0, ctx->stream, (const float*)dq, qn, ctx->s_rd_rows.as<int32_t>(), d, rq,
+                       rqn);
     SV_HIP(hipGetLastError());
-    {
-      StageScope sc(ctx, "knn_fallback");
-      SV_TRY(search_matrix(ctx, fq, nf, n, d, k, fqn, ctx->s_fb_d2.as<float>(), ctx->s_fb_idx.as<int64_t>()));
-      sc.count(nf);
+    SV_HIP(ctx->s_rd_p1.reserve((size_t)nr * d * 2));
+    if (pl.kind == 1) {
+      SV_TRY(sv_launch_to_f16(ctx, rq, (int64_t)nr * d, qscale, ctx->s_rd_p1.as<uint16_t>()));   // same scale as the main pass
+    } else {
+      SV_HIP(ctx->s_rd_p2.reserve((size_t)nr * d * 2));
+      SV_TRY(sv_launch_split_bf16(ctx, rq, (int64_t)nr * d, ctx->s_rd_p1.as<uint16_t>(), ctx->s_rd_p2.as<uint16_t>()));
     }
-    hipLaunchKernelGGL(scatter_topk_kernel, dim3(nf), dim3(256), 0, ctx->stream, ctx->s_fb_d2.as<float>(),
-                       ctx->s_fb_idx.as<int64_t>(), ctx->s_fb_rows.as<int32_t>(), k, (float*)dd2, (int64_t*)didx);
+    uint32_t* rflags = ctx->s_rd_flags.as<uint32_t>();
+    for (int q0 = 0; q0 < nr; q0 += SV_CHUNK) {
+      const int m = (nr - q0 < SV_CHUNK) ? (nr - q0) : SV_CHUNK;
+      StageScope sc(ctx, "knn_redo");
+      SV_TRY(levels_chunk(ctx, pl, false, rq + (size_t)q0 * d, ctx->s_rd_p1.as<uint16_t>() + (size_t)q0 * d,
+                          pl.kind == 2 ? ctx->s_rd_p2.as<uint16_t>() + (size_t)q0 * d : nullptr, rqn + q0, m,
+                          ctx->s_rd_d2.as<float>() + (size_t)q0 * k, ctx->s_rd_idx.as<int64_t>() + (size_t)q0 * k, rflags + q0, rflags + nr));
+      sc.count(m);
+    }
+    uint32_t n_ovf = 0;
+    SV_HIP(hipMemcpyAsync(&n_ovf, rflags + nr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SV_HIP(hipStreamSynchronize(ctx->stream));   // also: rows[] lives on this frame
+    if (n_ovf) {
+      int nf = 0;
+      SV_TRY(fallback_rows(ctx, pl, rq, rqn, rflags, nr, ctx->s_rd_d2.as<float>(), ctx->s_rd_idx.as<int64_t>(), &nf));
+      ctx->sstats.n_fallback = nf;
+    }
+    hipLaunchKernelGGL(scatter_topk_kernel, dim3(nr), dim3(256), 0, ctx->stream, ctx->s_rd_d2.as<float>(), ctx->s_rd_idx.as<int64_t>(),
+                       ctx->s_rd_rows.as<int32_t>(), k, (float*)dd2, (int64_t*)didx);
     SV_HIP(hipGetLastError());
-    SV_HIP(hipStreamSynchronize(ctx->stream));  // rows[] lives on this frame
   }
   return sv_finish(ctx);
 }

@@ -78,6 +78,7 @@ struct SvOptions {
   int x3_tile = 0;        // PCA split GEMM tile (0 = from the shape, 128, 256)
   int x3_gm = -1;         // PCA split GEMM XCD-aware block height (-1 = default of the kernel, 0 = plain order)
   int search_stats = 0;   // 1: segvlad_search records list occupancies (synchronises once per chunk)
+  int knn_heuristic = 1;  // 1: low-rank (verified) thresholds in the level scheme; 0: rigorous k-th-rank thresholds only
   int assign_narrow = 0;  // 1: force the narrow assignment kernel
   int agg_kpb = 4;        // clusters per aggregation workgroup
   int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises)
@@ -93,6 +94,7 @@ struct SvSearchStats {
   int64_t refine_max = 0;       // largest refine list (search_stats only)
   int64_t refine_sum = 0;       // sum of refine-list lengths (search_stats only)
   int64_t n_queries = 0;
+  int64_t n_redo = 0;           // query rows whose heuristic thresholds did not verify and that were redone rigorously
 };
 
 struct segvlad_ctx {
@@ -129,12 +131,13 @@ struct segvlad_ctx {
   float db_f16_scale = 0.f, db_maxabs = 0.f;
   float db_rn_max = 0.f;
   int64_t db_rn_max_rows = 0;
+  bool db_heur_off = false;   // set when > 25 % of a search's queries needed the rigorous redo (until the index changes)
 
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
       s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
-      s_fb_idx, s_fb_rows;
+      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -207,9 +210,13 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
                           int M, int n_sample, int d, int b_stride, const float* qn, const float* rn, const float* thr,
                           int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2,
                           uint32_t* cand_id, int cap);
+// rank: which order statistic of the list is A (mode 0: the next level's threshold; mode 1: k).  check != 0 (heuristic
+// thresholds): mode 0 flags a list shorter than rank, mode 1 flags A > thr_in[row * thr_in_ld] (the threshold the list was
+// collected under).  Flagged rows (also: list overflow) are marked in fail_rows and counted once in *fail_count.
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
-                            int cap, int k, int mode, const float* qn, float c_eps, float rn_max, float* thr_out,
-                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* ovf_rows, uint32_t* ovf_count);
+                            int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
+                            float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
+                            uint32_t* fail_rows, uint32_t* fail_count);
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);

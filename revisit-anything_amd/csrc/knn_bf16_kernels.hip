@@ -885,7 +885,8 @@ __device__ __forceinline__ void hist_add_(uint32_t* hist, bool active, uint32_t 
 //   mode 0: thr_out[q] = A_k
 //   mode 1: refine list = ids with d2~ <= A_k + 2 eps(q) (unordered; at most rcap, more -> the row is flagged in ovf_rows)
 __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
-                                                            const uint32_t* __restrict__ cid, int cap, int k, int mode,
+                                                            const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
+                                                            const float* __restrict__ thr_in, int64_t thr_in_ld,
                                                             const float* __restrict__ qn, float c_eps, float rn_max,
                                                             float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
                                                             uint32_t* __restrict__ ref_id, int rcap,
@@ -898,14 +899,19 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   const uint32_t c = cnt[row];
-  if (c > (uint32_t)cap || ovf_rows[row]) {
-    // overflow (now or at a coarser level): the query is redone ALONE on the matrix path; a threshold of -inf
-    // keeps its candidate list empty at the finer levels, an empty refine list makes the refinement a no-op
+  // the threshold this list was collected under (read before thr_out -- possibly the same word -- is overwritten)
+  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  auto flag_row = [&]() {
+    // this query is redone later (rigorous thresholds / exact matrix path): a threshold of -inf keeps its candidate
+    // list empty at the finer levels, an empty refine list makes the refinement a no-op
     if (tid == 0) {
       if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
       if (mode == 1) ref_cnt[row] = 0;
       else thr_out[row] = -INFINITY;
     }
+  };
+  if (c > (uint32_t)cap || ovf_rows[row] || (check && (int)c < k)) {   // overflow / flagged at a coarser level / too few
+    flag_row();
     return;
   }
   for (int j = tid; j < (int)c; j += 256) keys[j] = f2key_(cd2[row * cap + j]);
@@ -949,6 +955,12 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
     if (tid == 0) thr_out[row] = ak;
     return;
   }
+  // heuristic thresholds: the list holds every row with d2~ <= t_in + 2 eps; the refine set {d2~ <= A_k + 2 eps} is
+  // contained in it iff A_k <= t_in
+  if (check && !(ak <= t_in)) {
+    flag_row();
+    return;
+  }
   const uint32_t klim = f2key_(ak + 2.f * c_eps * sqrtf(qn[row] * rn_max));
   if (tid == 0) s_n = 0;
   __syncthreads();
@@ -970,12 +982,13 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
 }
 
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
-                            int cap, int k, int mode, const float* qn, float c_eps, float rn_max, float* thr_out,
-                            uint32_t* ref_cnt, uint32_t* ref_id, int rcap, uint32_t* ovf_rows, uint32_t* ovf_count) {
+                            int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
+                            float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
+                            uint32_t* fail_rows, uint32_t* fail_count) {
   if (nq <= 0) return SEGVLAD_OK;
   const size_t lds = (size_t)cap * 4;
-  hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, k, mode, qn,
-                     c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows, ovf_count);
+  hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, rank, mode, check,
+                     thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

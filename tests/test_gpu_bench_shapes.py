@@ -295,3 +295,62 @@ def test_vpair_geometry_and_pca512_golden(eng):
     d2, idx = eng.search(yn, 5)
     rd2, ridx = O().knn_l2(yn, yn, 5)
     assert np.array_equal(idx.cpu().numpy()[:, 0], ridx[:, 0]) and np.abs(d2.cpu().numpy() - rd2).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# low-rank ("heuristic") level thresholds: a-posteriori verified, rigorous redo of the queries that fail
+# ------------------------------------------------------------------------------------------------
+def test_knn_heuristic_thresholds_equal_rigorous_and_redo_is_exact(eng, planted_1m):
+    """The level scheme's low-rank thresholds (5-10x fewer candidates) must give bit-identical results to the rigorous
+    k-th-rank thresholds; queries they fail on (here forced: a database whose strided sample is unrepresentative for a
+    group of queries) are redone rigorously and counted."""
+    import torch
+
+    R, Q = planted_1m["R"], planted_1m["Q"]
+    k = 200
+    eng.db_reset()
+    eng.db_add(R[:500000])
+    try:
+        eng.set_option("search_stats", 1)
+        d2h, idxh = eng.search(Q, k)
+        sth = eng.search_stats()
+        eng.set_option("knn_heuristic", 0)
+        d2r, idxr = eng.search(Q, k)
+        strg = eng.search_stats()
+    finally:
+        eng.set_option("knn_heuristic", 1)
+        eng.set_option("search_stats", 0)
+    assert torch.equal(idxh, idxr) and torch.equal(d2h, d2r)
+    assert strg["n_redo"] == 0 and sth["n_redo"] <= 0.02 * sth["n_queries"], (sth, strg)
+    print(f"heuristic: candidates/query {sth['cand_sum'] / sth['n_queries']:.0f} (max {sth['cand_max']}), redo {sth['n_redo']}; "
+          f"rigorous: {strg['cand_sum'] / strg['n_queries']:.0f} (max {strg['cand_max']})")
+    assert sth["cand_sum"] < 0.5 * strg["cand_sum"]
+    # an unrepresentative sample: rows NOT on the stride-16 grid are near-copies of a few query vectors, so the sampled
+    # ranks badly under-estimate how many rows fall under the threshold... the other direction (too FEW rows) is what makes
+    # the check fail: put the near-copies ONLY on the sampled grid
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n, d, nq = 300000, 256, 256
+    Rb = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
+    Qb = torch.nn.functional.normalize(torch.randn(nq, d, device=dev, generator=g), dim=1)
+    grid = torch.arange(0, 60, device=dev) * 256 * 16                      # rows of the coarsest (stride 256) sample
+    grid = grid[grid < n]
+    for q in range(8):                                                      # 8 queries own ~37 planted near-copies each
+        rows = grid[q::8]
+        Rb[rows] = torch.nn.functional.normalize(Qb[q][None] + 0.05 * torch.randn(len(rows), d, device=dev, generator=g), dim=1)
+    eng.db_reset()
+    eng.db_add(Rb)
+    d2h, idxh = eng.search(Qb, 50)
+    sth = eng.search_stats()
+    try:
+        eng.set_option("knn_heuristic", 0)
+        d2r, idxr = eng.search(Qb, 50)
+    finally:
+        eng.set_option("knn_heuristic", 1)
+    assert torch.equal(idxh, idxr) and torch.equal(d2h, d2r)
+    assert sth["n_redo"] >= 1, sth                                          # the planted queries could not be verified
+    rd2, ridx = O().topk_from_d2(O().l2_matrix(Rb.cpu().numpy(), Qb[:16].cpu().numpy()), 50)
+    assert np.abs(d2h[:16].cpu().numpy() - rd2).max() < 1e-5
+    clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
+    assert np.array_equal(idxh[:16].cpu().numpy()[clear], ridx[clear])
