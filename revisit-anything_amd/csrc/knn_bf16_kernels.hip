@@ -361,13 +361,18 @@ __device__ __forceinline__ void wait_vm_lgkm0() {  // s_waitcnt needs a literal 
 // ABL == 9: phase timing (s_memtime of wave 0 at the phase boundaries, summed over workgroups; SEGVLAD_F16_CFG=90 prints it)
 __device__ unsigned long long sv_f16_phase_cycles[8];
 #define SV_PHASE(k)                                                                          \
-  if (ABL >= 9) {                                                                            \
+  if (ABL == 9 || ABL == 12) {                                                                            \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
     if (threadIdx.x == 0) atomicAdd(&sv_f16_phase_cycles[k], now_ - phase_t0);               \
     phase_t0 = now_;                                                                         \
   }
 
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false>
+// POL: cache policy of the operand DMA (never changes a result): bit 0 = database rows (B) non-temporal, bit 1 = queries (A)
+// PP : 0 = every wave runs the k-tile as one segment (one barrier per k-tile); PP > 0 = "ping-pong": the k-tile is cut
+//      into PP phases of [load segment: LDS fragment reads + DMA issue][barrier][MFMA segment][barrier], and the second
+//      half of the waves (the SIMD partners of the first half: waves w and w + NW/2 share a SIMD) runs one barrier
+//      behind, so that on every SIMD one wave feeds the matrix pipe while its partner reads LDS and issues DMA.
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total,
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* __restrict__ cand_cnt,
     float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap) {
   constexpr int NW = WM * WN;
+  constexpr int AUXA = (POL & 2) ? 2 : 0, AUXB = (POL & 1) ? 2 : 0;   // aux = 2: "nt" (streaming) hint
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int RB = HBK * 2;            // row bytes per k-tile
   constexpr int CH = RB / 16;            // 16-B chunks per row (4 or 8)
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and operand
   static_assert(JA * RP * NW == BM && JB * RP * NW == BN && (JA + JB) % KS == 0, "tile/wave geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned long long phase_t0 = (ABL >= 9) ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long phase_t0 = (ABL == 9 || ABL == 12) ? __builtin_amdgcn_s_memtime() : 0ull;
   // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2); the 32
   // workgroups an XCD runs side by side form one gm x (32/gm) block of tiles, so that they share their query and
   // database rows in that L2 while they march over k (tm-fastest order made every XCD fetch every database row).
@@ -431,14 +437,14 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       const int row = (w * JA + j) * RP + lrow_p;
       const int64_t qa = (m0_ + row < M) ? (m0_ + row) : (int64_t)(M - 1);
       __builtin_amdgcn_global_load_lds((gptr_t)(Qh + qa * d + 8 * swz(row, lch)), (lptr_t)(lds + a_off(0) + (w * JA + j) * 1024), 16,
-                                       0, 0);
+                                       0, AUXA);
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
       const int row = (w * JB + j) * RP + lrow_p;
       const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
       __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch)), (lptr_t)(lds + b_off(0) + (w * JB + j) * 1024), 16,
-                                       0, 0);
+                                       0, AUXB);
     }
     if (NB == 3 && ntiles > 1) {
 #pragma unroll
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         const int row = (w * JB + j) * RP + lrow_p;
         const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
         __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch) + HBK),
-                                         (lptr_t)(lds + b_off(1) + (w * JB + j) * 1024), 16, 0, 0);
+                                         (lptr_t)(lds + b_off(1) + (w * JB + j) * 1024), 16, 0, AUXB);
       }
     }
   };
@@ -508,71 +514,139 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // DMA piece p of iteration kt: pieces 0..JA-1 belong to A(kt+1), JA..JA+JB-1 to B(kt+BAHEAD)
   auto dma_piece = [&](int piece, int kt, int ia_next, int ib_next) {
     if (ABL == 3) return;  // ablation: no DMA in the loop
+    if (ABL == 13 && piece < JA) return;    // ablation: B only
+    if (ABL == 14 && piece >= JA) return;   // ablation: A only
     if (piece < JA) {
       if (kt + 1 < ntiles)
         __builtin_amdgcn_global_load_lds((gptr_t)(srcA[piece] + (kt + 1) * HBK),
-                                         (lptr_t)(lds + a_off(ia_next) + (w * JA + piece) * 1024), 16, 0, 0);
+                                         (lptr_t)(lds + a_off(ia_next) + (w * JA + piece) * 1024), 16, 0, AUXA);
     } else {
       const int j = piece - JA;
       if (kt + BAHEAD < ntiles)
         __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (kt + BAHEAD) * HBK),
-                                         (lptr_t)(lds + b_off(ib_next) + (w * JB + j) * 1024), 16, 0, 0);
+                                         (lptr_t)(lds + b_off(ib_next) + (w * JB + j) * 1024), 16, 0, AUXB);
     }
   };
   SV_PHASE(0)  // prologue: first tiles landed
 
   int ia = 0, ib = 0;
   const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
-    const unsigned char* SA = lds + a_off(ia);
-    const unsigned char* SB = lds + b_off(ib);
+  if (PP > 0) {
+    constexpr int PPn = PP > 0 ? PP : 1;
+    constexpr int PH = KS / PPn;            // MFMA k-steps per phase
+    constexpr int DPP = (JA + JB) / PPn;    // DMA pieces per phase and wave
+    static_assert(PP == 0 || (KS % PPn == 0 && (JA + JB) % PPn == 0 && PH >= 1), "phase geometry");
+    const bool lag = w >= NW / 2;           // wave-uniform (w comes from readfirstlane)
+    if (lag) __builtin_amdgcn_s_barrier(); // the second half of the waves runs one barrier (= one segment) behind
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
+      const unsigned char* SA = lds + a_off(ia);
+      const unsigned char* SB = lds + b_off(ib);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int cl = 2 * ks + kk;  // logical 16-B chunk (8 consecutive k) of this lane
-      f16x8 a[TM], b[TN];
+      for (int ph = 0; ph < PPn; ++ph) {
+        // ---- load segment: fragments of this phase's k-steps, this phase's share of the DMA pieces ----
+        f16x8 a[PH][TM], b[PH][TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        const int ra = fa0 + 32 * t;
-        a[t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
-      }
+        for (int k2 = 0; k2 < PH; ++k2) {
+          const int cl = 2 * (ph * PH + k2) + kk;
 #pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const int rb = fb0 + 32 * t;
-        b[t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
-      }
+          for (int t = 0; t < TM; ++t) {
+            const int ra = fa0 + 32 * t;
+            a[k2][t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
+          }
 #pragma unroll
-      for (int pz = 0; pz < (JA + JB) / KS; ++pz) dma_piece(ks * ((JA + JB) / KS) + pz, kt, ia ^ 1, ibn);
-#pragma unroll
-      for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-          if (ABL == 2) {  // ablation: no MFMA (operands stay live)
-            acc[mt][nt][0] += (float)a[mt][0] + (float)b[nt][0];
-          } else {
-            acc[mt][nt] = MFMA_F16(a[mt], b[nt], acc[mt][nt]);
+          for (int t = 0; t < TN; ++t) {
+            const int rb = fb0 + 32 * t;
+            b[k2][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
           }
         }
+#pragma unroll
+        for (int pz = 0; pz < DPP; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
+        if (ph == PPn - 1) {
+          // last load segment of the k-tile: this wave's pieces of A(kt+1) and B(kt+1) have landed (B(kt+2), the
+          // youngest JB DMA instructions, may still fly).  The barriers between here and the first read of tile kt+1
+          // (one for the leading half, two for the lagging half) make that true for every wave's pieces.
+          if (NB == 3 && kt + 2 < ntiles)
+            wait_vm_lgkm0<JB>();
+          else
+            wait_vm_lgkm0<0>();
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA segment ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < PH; ++k2)
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a[k2][mt], b[k2][nt], acc[mt][nt]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ia ^= 1;
+      ib = (ib + 1 >= NB) ? 0 : ib + 1;
     }
-    // this wave's pieces of A(kt+1) and B(kt+1) have landed (with NB = 3, B(kt+2) -- the youngest JB DMA
-    // instructions -- may still fly: vmcnt retires in order) and its LDS reads are done; after the barrier that
-    // holds for every wave, so the stages of tile kt may be overwritten
-    if (NB == 3 && kt + 2 < ntiles)
-      wait_vm_lgkm0<JB>();
-    else
-      wait_vm_lgkm0<0>();
-    __builtin_amdgcn_s_barrier();
-    ia ^= 1;
-    ib = (ib + 1 >= NB) ? 0 : ib + 1;
+    if (!lag) __builtin_amdgcn_s_barrier();  // the leading half waits for the lagging half's last MFMA segment
+  } else {
+  for (int kt = 0; kt < ntiles; ++kt) {
+      const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
+      const unsigned char* SA = lds + a_off(ia);
+      const unsigned char* SB = lds + b_off(ib);
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int cl = 2 * ks + kk;  // logical 16-B chunk (8 consecutive k) of this lane
+        f16x8 a[TM], b[TN];
+  #pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          const int ra = fa0 + 32 * t;
+          a[t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
+        }
+  #pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          const int rb = fb0 + 32 * t;
+          b[t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
+        }
+  #pragma unroll
+        for (int pz = 0; pz < (JA + JB) / KS; ++pz) dma_piece(ks * ((JA + JB) / KS) + pz, kt, ia ^ 1, ibn);
+  #pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+  #pragma unroll
+          for (int nt = 0; nt < TN; ++nt) {
+            if (ABL == 2) {  // ablation: no MFMA (operands stay live)
+              acc[mt][nt][0] += (float)a[mt][0] + (float)b[nt][0];
+            } else {
+              acc[mt][nt] = MFMA_F16(a[mt], b[nt], acc[mt][nt]);
+            }
+          }
+      }
+      // this wave's pieces of A(kt+1) and B(kt+1) have landed (with NB = 3, B(kt+2) -- the youngest JB DMA
+      // instructions -- may still fly: vmcnt retires in order) and its LDS reads are done; after the barrier that
+      // holds for every wave, so the stages of tile kt may be overwritten
+      if (NB == 3 && kt + 2 < ntiles)
+        wait_vm_lgkm0<JB>();
+      else
+        wait_vm_lgkm0<0>();
+      __builtin_amdgcn_s_barrier();
+      ia ^= 1;
+      ib = (ib + 1 >= NB) ? 0 : ib + 1;
+    }
   }
 
   SV_PHASE(1)  // main loop
-  if (ABL >= 1 && ABL <= 3) {  // ablation: no epilogue (accumulators stay live)
+  if ((ABL >= 1 && ABL <= 3) || ABL == 16) {  // ablation: no epilogue (accumulators stay live; 16: DMA skeleton only)
     float t = 0.f;
+    if (ABL != 16) {
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt)
+      for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < TN; ++nt) t += acc[mt][nt][0] + acc[mt][nt][15];
+        for (int nt = 0; nt < TN; ++nt) t += acc[mt][nt][0] + acc[mt][nt][15];
+    }
     if (t == 12345.678f) cand_cnt[0] = 1;
     return;
   }
@@ -603,11 +677,12 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // consumer ranks or sorts it.
   // records per wave: a quarter of its elements at most; PERSIST keeps the whole scratch inside LDS slots 0 and 1
   constexpr int LCAP = PERSIST ? 896 : ((TM * TN * 256 < 2048) ? TM * TN * 256 : 2048);
-  static_assert(!PERSIST || (size_t)BM * 20 + (size_t)BN * 4 + (size_t)NW * (LCAP + 1) * 8 <= 2 * (size_t)PA, "epilogue scratch");
+  static_assert(!PERSIST || (size_t)BM * 24 + (size_t)BN * 4 + (size_t)NW * (LCAP + 1) * 8 <= 2 * (size_t)PA, "epilogue scratch");
   float4* rrec = reinterpret_cast<float4*>(lds);                         // [BM] {||q||^2, exact limit, screening bound, -}
   uint32_t* rowcnt = reinterpret_cast<uint32_t*>(rrec + BM);             // [BM] survivors per row -> next free global slot
   float* cnl = reinterpret_cast<float*>(rowcnt + BM);                    // [BN] column norms
-  uint2* wlist = reinterpret_cast<uint2*>(cnl + BN) + (size_t)w * (LCAP + 1);  // this wave's hit list (+1 dump slot)
+  float* taul = cnl + BN;                                                // [BM] screening bounds, contiguous (16-B reads)
+  uint2* wlist = reinterpret_cast<uint2*>(taul + BM) + (size_t)w * (LCAP + 1);  // this wave's hit list (+1 dump slot)
   const float half_scale = 0.5f / inv_scale;
   const float rmax_hs = rn_max * half_scale;
   if (tid < BM) {
@@ -623,6 +698,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     }
     rrec[j] = make_float4(q2, lim, tau, 0.f);
     rowcnt[j] = 0u;
+    taul[j] = tau;
   }
   float cnh[TN];
 #pragma unroll
@@ -634,20 +710,30 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   SV_PHASE(2)  // row records staged
   uint32_t wave_cnt = 0;  // wave-uniform: only updated under wave-uniform control flow
   uint32_t dbg_bodies = 0;
+  // this lane's 16 * TM screening bounds, fetched up front with 16-B reads (accumulator element r of tile mt belongs to
+  // row mt*32 + 8*(r>>2) + 4*kk + (r&3): four consecutive rows per (mt, r>>2)) -- a per-iteration LDS read put ~100
+  // cycles of latency into each of the 32 screening steps (two waves per SIMD cannot hide it)
+  float4 tq[TM][4];
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      tq[mt][g] = *reinterpret_cast<const float4*>(taul + wm * (32 * TM) + mt * 32 + 8 * g + 4 * kk);
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const uint32_t lrow16 = (uint32_t)(wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) << 16;
-      const float tau = rrec[lrow16 >> 16].z;
+      const float4 tq4 = tq[mt][r >> 2];
+      const float tau = (r & 3) == 0 ? tq4.x : (r & 3) == 1 ? tq4.y : (r & 3) == 2 ? tq4.z : tq4.w;
       float dd[TN];
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) dd[nt] = acc[mt][nt][r] - cnh[nt];
       float best = dd[0];
 #pragma unroll
       for (int nt = 1; nt < TN; ++nt) best = fmaxf(best, dd[nt]);
-      if (ABL != 12 && __builtin_amdgcn_ballot_w64(best >= tau) != 0ull) {   // ABL 12: timing ablation (wrong results)
-        if (ABL >= 9) ++dbg_bodies;
+      if (ABL < 12 && __builtin_amdgcn_ballot_w64(best >= tau) != 0ull) {   // ABL >= 12: timing ablations (wrong results)
+        if (ABL == 9 || ABL == 12) ++dbg_bodies;
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
           const bool hit = dd[nt] >= tau;
@@ -662,7 +748,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         }
       }
     }
-  if (ABL >= 9 && tid == 0) atomicAdd(&sv_f16_phase_cycles[6], (unsigned long long)dbg_bodies);
+  if ((ABL == 9 || ABL == 12) && tid == 0) atomicAdd(&sv_f16_phase_cycles[6], (unsigned long long)dbg_bodies);
   SV_PHASE(3)  // pass 1
   // pass 2a: exact test of this wave's hits, dense (the list is wave-private: no barrier needed before reading it)
   const uint32_t n_w = wave_cnt <= (uint32_t)LCAP ? wave_cnt : 0u;   // a dense block abandons its (truncated) list
@@ -755,7 +841,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   }   // tile loop
 }
 
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false>
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -780,10 +866,10 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   if (!PERSIST) {  // epilogue: row records + per-row counters + one survivor list per wave
     constexpr int TMl = BM / (32 * WM), TNl = BN / (32 * WN);
     constexpr int LCAPl = (TMl * TNl * 256 < 2048) ? TMl * TNl * 256 : 2048;
-    const size_t elds = (size_t)BM * 20 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
+    const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP>;
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -798,12 +884,12 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
 #define SV_F16_ARGS ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap
   // tile configuration: option "f16_cfg" (default chosen from measurements)
-  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 0 : 3);
+  // r02 measurements (10 000 x 1 M x 1024, random unit vectors, filter launches only): 0 -> 22.5 ms, 50 (ping-pong) -> 21.7,
+  // 200 (persistent) -> 21.7, 250 (persistent + ping-pong) -> 21.5; HBK = 32 variants (4, 1) 24.1 / 25.3
+  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : 3);
   switch (c) {
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
-    case 200:   // persistent workgroups that request the next tile's head before their epilogue: -4 % on unstructured
-                // data (probe_knn.py), +2 % on the bench's place-structured database (the smaller per-wave hit lists
-                // send more blocks down the dense path) -> not the default
+    case 200:   // persistent workgroups that request the next tile's head before their epilogue
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true>(SV_F16_ARGS);
       return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);
@@ -811,6 +897,10 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 10: return launch_f16_filter<256, 256, 4, 2, 64, 3, 1>(SV_F16_ARGS);  // ablations of config 0 (WRONG results)
     case 20: return launch_f16_filter<256, 256, 4, 2, 64, 3, 2>(SV_F16_ARGS);
     case 30: return launch_f16_filter<256, 256, 4, 2, 64, 3, 3>(SV_F16_ARGS);
+    case 130: return launch_f16_filter<256, 256, 4, 2, 64, 3, 13>(SV_F16_ARGS);   // DMA only, B pieces only
+    case 140: return launch_f16_filter<256, 256, 4, 2, 64, 3, 14>(SV_F16_ARGS);   // DMA only, A pieces only
+    case 121: return launch_f16_filter<256, 256, 4, 2, 64, 3, 15>(SV_F16_ARGS);   // DMA only (no phase timing)
+    case 160: return launch_f16_filter<256, 256, 4, 2, 64, 3, 16>(SV_F16_ARGS);   // DMA only, no epilogue
     case 90:
     case 120: {  // phase timing of config 0 (debug: synchronises and prints; 110 / 120 also ablate pass 1)
       unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c8[8];
@@ -829,6 +919,16 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
       return rc;
     }
 #endif
+    case 50: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2>(SV_F16_ARGS);  // ping-pong, 2 phases per k-tile
+    case 51: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 4>(SV_F16_ARGS);  // ping-pong, 4 phases per k-tile
+    case 52: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 1>(SV_F16_ARGS);  // ping-pong, 1 phase per k-tile
+    case 250:
+      if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2>(SV_F16_ARGS);        // persistent + ping-pong
+      return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2>(SV_F16_ARGS);
+    case 40: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 1>(SV_F16_ARGS);  // database rows non-temporal
+    case 41: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 2>(SV_F16_ARGS);  // queries non-temporal
+    case 42: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 3>(SV_F16_ARGS);  // both
     case 1: return launch_f16_filter<256, 256, 4, 2, 32, 2>(SV_F16_ARGS);  //  64 KiB LDS, 2 workgroups / CU
     case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
     case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB

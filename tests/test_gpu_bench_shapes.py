@@ -325,20 +325,19 @@ def test_knn_heuristic_thresholds_equal_rigorous_and_redo_is_exact(eng, planted_
     print(f"heuristic: candidates/query {sth['cand_sum'] / sth['n_queries']:.0f} (max {sth['cand_max']}), redo {sth['n_redo']}; "
           f"rigorous: {strg['cand_sum'] / strg['n_queries']:.0f} (max {strg['cand_max']})")
     assert sth["cand_sum"] < 0.5 * strg["cand_sum"]
-    # an unrepresentative sample: rows NOT on the stride-16 grid are near-copies of a few query vectors, so the sampled
-    # ranks badly under-estimate how many rows fall under the threshold... the other direction (too FEW rows) is what makes
-    # the check fail: put the near-copies ONLY on the sampled grid
+    # An unrepresentative sample: 8 queries own 30 near-copies each, ALL on the stride-16 grid (the middle level's
+    # sample) and none on the stride-256 grid.  The middle level then sees 30 near-copies among its ~300 candidates, puts
+    # its rank-22 threshold on a near-copy distance, and the last level finds only those 30 rows under it: fewer than
+    # k = 50 -> the a-posteriori check must fail and the query must be redone with the rigorous thresholds.
     dev = eng.device
     g = torch.Generator(device=dev)
     g.manual_seed(5)
     n, d, nq = 300000, 256, 256
     Rb = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
     Qb = torch.nn.functional.normalize(torch.randn(nq, d, device=dev, generator=g), dim=1)
-    grid = torch.arange(0, 60, device=dev) * 256 * 16                      # rows of the coarsest (stride 256) sample
-    grid = grid[grid < n]
-    for q in range(8):                                                      # 8 queries own ~37 planted near-copies each
-        rows = grid[q::8]
-        Rb[rows] = torch.nn.functional.normalize(Qb[q][None] + 0.05 * torch.randn(len(rows), d, device=dev, generator=g), dim=1)
+    for q in range(8):
+        rows = 16 * (2 * (q * 30 + torch.arange(0, 30, device=dev)) + 1)   # odd multiples of 16: on the stride-16 grid only
+        Rb[rows] = torch.nn.functional.normalize(Qb[q][None] + 0.05 * torch.randn(30, d, device=dev, generator=g), dim=1)
     eng.db_reset()
     eng.db_add(Rb)
     d2h, idxh = eng.search(Qb, 50)
@@ -349,7 +348,7 @@ def test_knn_heuristic_thresholds_equal_rigorous_and_redo_is_exact(eng, planted_
     finally:
         eng.set_option("knn_heuristic", 1)
     assert torch.equal(idxh, idxr) and torch.equal(d2h, d2r)
-    assert sth["n_redo"] >= 1, sth                                          # the planted queries could not be verified
+    assert 8 <= sth["n_redo"] <= 16, sth                                    # the 8 planted queries could not be verified
     rd2, ridx = O().topk_from_d2(O().l2_matrix(Rb.cpu().numpy(), Qb[:16].cpu().numpy()), 50)
     assert np.abs(d2h[:16].cpu().numpy() - rd2).max() < 1e-5
     clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
