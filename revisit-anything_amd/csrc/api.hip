@@ -384,8 +384,8 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
     int e;
     frexpf(1.f + ctx->pca_mean_maxabs, &e);
     xscale = ldexpf(1.f, 14 - e);
-    SV_HIP(ctx->s_xh1.reserve((size_t)S_tot * ctx->KD * 2));
-    SV_HIP(ctx->s_xh2.reserve((size_t)S_tot * ctx->KD * 2));
+    SV_HIP(ctx->s_xh1.reserve((size_t)sv_x3_rows(S_tot) * ctx->KD * 2));   // blocked planes, rows padded to whole tiles
+    SV_HIP(ctx->s_xh2.reserve((size_t)sv_x3_rows(S_tot) * ctx->KD * 2));
     SV_TRY(sv_out(ctx, pca_y, (size_t)S_tot * ctx->P * sizeof(float), &d_y));
   }
 
@@ -563,8 +563,8 @@ int segvlad_pca_set(segvlad_ctx* ctx, const float* mean, const float* comps, con
       frexpf(wmax, &e);
       ctx->pca_w_scale = ldexpf(1.f, 14 - e);
       ctx->pca_mean_maxabs = mmax;
-      SV_HIP(ctx->pca_w1.reserve((size_t)P * KD * 2));
-      SV_HIP(ctx->pca_w2.reserve((size_t)P * KD * 2));
+      SV_HIP(ctx->pca_w1.reserve((size_t)sv_x3_rows(P) * KD * 2));   // blocked planes, rows padded to whole tiles
+      SV_HIP(ctx->pca_w2.reserve((size_t)sv_x3_rows(P) * KD * 2));
       SV_TRY(sv_launch_split_f16x2(ctx, ctx->pca_comps.as<float>(), P, KD, nullptr, ctx->pca_w_scale, ctx->pca_w1.as<uint16_t>(),
                                    ctx->pca_w2.as<uint16_t>()));
     }
@@ -594,8 +594,8 @@ int segvlad_pca_apply(segvlad_ctx* ctx, const float* X, int n, float* Y, int l2n
       frexpf(bound, &e);
       xscale = ldexpf(1.f, 14 - e);
     }
-    SV_HIP(ctx->s_xh1.reserve((size_t)n * ctx->KD * 2));
-    SV_HIP(ctx->s_xh2.reserve((size_t)n * ctx->KD * 2));
+    SV_HIP(ctx->s_xh1.reserve((size_t)sv_x3_rows(n) * ctx->KD * 2));
+    SV_HIP(ctx->s_xh2.reserve((size_t)sv_x3_rows(n) * ctx->KD * 2));
   }
   {
     StageScope sc(ctx, "pca");

@@ -32,6 +32,22 @@
 __device__ __forceinline__ float sv_d2(float q2, float r2, float dot) { return __fmaf_rn(-2.f, dot, q2 + r2); }
 #endif
 
+// Layout of the fp16 operand planes of the split projection GEMM (gemm_f16x3_kernel): [row / 128][k / 32][128 rows][32 k],
+// the four 16-byte chunks of a row stored at chunk ^ ((row >> 2) & 3).  One (128-row, 32-k) block is 8 KiB of CONTIGUOUS
+// memory that is, byte for byte, the bank-conflict-free LDS image the MFMA fragment reads expect: the global->LDS DMA
+// of a k-tile is a linear copy of whole 128-byte lines.  (Row-major planes made every DMA piece touch 16 half-lines
+// 196 KiB apart; each line was fetched twice, one k-tile apart, and the XCD's L2 -- 4 MiB against 4 MiB of such
+// half-used lines in flight -- kept nothing for the workgroups sharing a tile: 26 GB fetched for 4.4 GB of operands.)
+// Rows are padded to a multiple of 256 (the pad rows hold garbage: they only feed output rows / columns that are never stored).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t sv_x3_off(int64_t row, int64_t k, int64_t Kd) {
+  return ((size_t)(row >> 7) * (size_t)(Kd >> 5) + (size_t)(k >> 5)) * 4096 + (size_t)(row & 127) * 32 +
+         (size_t)((((k & 31) >> 3) ^ ((row >> 2) & 3)) << 3) + (size_t)(k & 7);
+}
+inline int64_t sv_x3_rows(int64_t n) { return (n + 255) & ~255ll; }
+
 // grow-only device buffer
 struct DevBuf {
   void* p = nullptr;

@@ -8,7 +8,8 @@
 // replaces, at 3/16 of the matrix-pipe time.  (The kNN filter can afford a single product because it only needs
 // a rigorous bound; here the value itself is the output, hence the two-term split.)
 //
-//   split_f16x2_kernel   (X - sub) * scale -> h1, h2 planes (sub = PCA mean on the A side, none on the W side)
+//   split_f16x2_kernel   (X - sub) * scale -> h1, h2 planes in the blocked layout of ctx.h (sv_x3_off); sub = PCA mean on
+//                        the A side, none on the W side
 //   gemm_f16x3_kernel    C = (A1+A2).(B1+B2)^T * col_scale: BM x BN x 32 tiles, global->LDS DMA with source-side
 //                        swizzle (see knn_bf16_kernels.hip), two stages per operand, optional split-K
 #include <stdlib.h>
@@ -43,8 +44,9 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
       a[e] = (_Float16)f[e];
       b[e] = (_Float16)(f[e] - (float)a[e]);
     }
-    reinterpret_cast<h4*>(h1)[j] = a;
-    reinterpret_cast<h4*>(h2)[j] = b;
+    const size_t o = sv_x3_off(j / d4, (j % d4) * 4, d);   // blocked plane layout (ctx.h)
+    *reinterpret_cast<h4*>(h1 + o) = a;
+    *reinterpret_cast<h4*>(h2 + o) = b;
   }
 }
 
@@ -116,25 +118,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int lrow_p = l >> 2, lch = l & 3;
-  int64_t offA[JA], offB[JB];  // element offsets of this lane's 16-B chunk inside a plane (without k)
+  // Element offsets of this lane's 16-B chunk in the blocked planes (ctx.h: sv_x3_off): piece p of a tile = rows
+  // 16 p .. 16 p + 15, which are 1 KiB of contiguous memory inside their (128-row, 32-k) block, already in the swizzled
+  // order of the LDS image -> the DMA is a linear copy (lane l fetches bytes 16 l .. 16 l + 15 of the piece).  The
+  // planes are padded to whole 256-row tiles, so edge tiles need no clamping.
+  const size_t nkb = (size_t)(Kd >> 5);
+  size_t offA[JA], offB[JB];
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
-    const int row = (w * JA + j) * RP + lrow_p;
-    const int64_t ra = (m0 + row < M) ? (m0 + row) : (int64_t)(M - 1);
-    offA[j] = ra * Kd + kbeg + 8 * swz(row, lch);
+    const int64_t r0 = m0 + (w * JA + j) * RP;
+    offA[j] = ((size_t)(r0 >> 7) * nkb + (size_t)(kbeg >> 5)) * 4096 + (size_t)(r0 & 127) * 32 + (size_t)l * 8;
   }
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
-    const int row = (w * JB + j) * RP + lrow_p;
-    const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
-    offB[j] = rb * Kd + kbeg + 8 * swz(row, lch);
+    const int64_t r0 = n0 + (w * JB + j) * RP;
+    offB[j] = ((size_t)(r0 >> 7) * nkb + (size_t)(kbeg >> 5)) * 4096 + (size_t)(r0 & 127) * 32 + (size_t)l * 8;
   }
   // LDS: stage s = [A1 | A2 | B1 | B2], two stages
   constexpr int STAGE = 2 * PA + 2 * PB;
   auto dma_tile = [&](int kt, int buf) {
     unsigned char* S = lds + buf * STAGE;
-    const int k0 = kt * HBK;
+    const size_t k0 = (size_t)kt * 4096;   // one 32-deep k-block further: 4096 elements inside the 128-row block
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       __builtin_amdgcn_global_load_lds((gptr_t)(A1 + offA[j] + k0), (lptr_t)(S + (w * JA + j) * 1024), 16, 0, 0);

@@ -886,7 +886,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   // tile configuration: option "f16_cfg" (default chosen from measurements)
   // r02 measurements (10 000 x 1 M x 1024, random unit vectors, filter launches only): 0 -> 22.5 ms, 50 (ping-pong) -> 21.7,
   // 200 (persistent) -> 21.7, 250 (persistent + ping-pong) -> 21.5; HBK = 32 variants (4, 1) 24.1 / 25.3
-  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : 3);
+  // streaming regime (M <= 128, e.g. one 50-segment query image per pass over 1 M rows): 2 -> 0.41 ms, 3 -> 0.51 ms
+  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : 2);
   switch (c) {
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
     case 200:   // persistent workgroups that request the next tile's head before their epilogue

@@ -993,8 +993,9 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
                 p1[e] = (_Float16)f[e];
                 p2[e] = (_Float16)(f[e] - (float)p1[e]);
               }
-              *reinterpret_cast<h4*>(h1 + o) = p1;
-              *reinterpret_cast<h4*>(h2 + o) = p2;
+              const size_t ob = sv_x3_off(s0 + 64 * sc + row, (int64_t)k * D + dcol, KD);   // blocked plane layout (ctx.h)
+              *reinterpret_cast<h4*>(h1 + ob) = p1;
+              *reinterpret_cast<h4*>(h2 + ob) = p2;
             }
           }
         }

@@ -27,11 +27,11 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   # dispatches of the synthetic-image factory) is what stalled in round 1.
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/prof_$c
-    timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -- \
+    REPS=1 timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -- \
        python $REPO/tools/probe_counters.py > /tmp/prof_$c.log 2> /tmp/prof_$c.err || echo "PMC pass $c: timeout or failure"
   done
   rm -rf /tmp/prof_SQ
-  timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+  REPS=1 timeout 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
        --kernel-trace --output-format csv -d /tmp/prof_SQ -- python $REPO/tools/probe_counters.py > /tmp/prof_SQ.log 2> /tmp/prof_SQ.err \
        || echo "PMC pass SQ: timeout or failure"
   ff=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' 2>/dev/null | head -1)
