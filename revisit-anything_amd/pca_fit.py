@@ -62,8 +62,8 @@ class NumpyBackend:
 class EnginePcaBackend:
     """The same two products on the device through the C-ABI's projection GEMM: ``X V = pca_apply(X)`` with the model
     ``comps = V^T``; ``X^T U = pca_apply(U^T)^T`` with ``comps = X^T`` (rows = descriptor columns).  X stays resident
-    in HBM ([n, KD] fp32; 50 000 x 98 304 = 19.7 GB).  Not exercised on a GPU yet (written after the round's GPU
-    budget was spent): the CPU tests cover the algorithm through NumpyBackend."""
+    in HBM ([n, KD] fp32; 50 000 x 98 304 = 19.7 GB).  GPU-tested against sklearn's exact solver
+    (tests/test_gpu_frows.py); the CPU tests cover the algorithm through NumpyBackend."""
 
     def __init__(self, engine, X):
         import torch
