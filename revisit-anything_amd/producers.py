@@ -13,7 +13,9 @@ linears, so the value facet is simply the output of ``encoder.layer[L].attention
 last third of a fused qkv projection (tests/test_producers.py shows the identity).  With weights on disk
 (``from_pretrained(local_dir)``) this reproduces the reference's tokens up to backbone numerics -- unpinned here: the
 image has neither the weights nor the hub code; with ``from_config`` (random initialisation) it serves
-throughput-only end-to-end runs (BASELINE configs[2])."""
+throughput-only end-to-end runs (BASELINE configs[2]).
+
+The second half of the row, the SAM automatic mask generator at half resolution, is ``SamAutoMasks`` further down."""
 from __future__ import annotations
 
 from typing import Optional, Union
@@ -111,3 +113,202 @@ def image_to_tokens(img_rgb: np.ndarray, extractor, cfg: Optional[dict] = None, 
     feat = extractor(x)                                                             # [1, hr*wr, D]
     feat = feat.reshape(1, hr, wr, -1).permute(0, 3, 1, 2).contiguous().float()     # [1, D, hr, wr]
     return torch.nn.functional.normalize(feat, dim=1) if normalize else feat
+
+
+# =====================================================================================================================
+# SAM automatic masks (second half)
+# =====================================================================================================================
+# The reference produces ``/{image}/masks/{j}/segmentation`` with ``SamAutomaticMaskGenerator(sam_vit_h)`` at its
+# defaults (func_vpr.py:510-516) on the image resized to HALF the DINO resolution (place_rec_SAM_DINO.py:51-63,
+# func_vpr.py:564-590).  ``segment_anything`` needs torchvision (absent here), so the generator below restates its
+# published algorithm (sam/segment_anything/automatic_mask_generator.py:137-330, utils/amg.py) on the ``transformers``
+# implementation of the same network (``SamModel``; the converted ``facebook/sam-vit-*`` checkpoints hold the same
+# weights):  point grid -> 3 masks per point -> predicted-IoU filter -> stability-score filter -> threshold -> boxes ->
+# box NMS (by predicted IoU) -> records.  crop_n_layers = 0 (the reference's default): one crop = the whole image.
+# With weights staged on disk it reproduces the reference's masks up to backbone numerics (unpinned here: no weights);
+# random-initialised it serves throughput-only end-to-end runs (BASELINE configs[2]).
+SAM_PIXEL_MEAN = (123.675, 116.28, 103.53)
+SAM_PIXEL_STD = (58.395, 57.12, 57.375)
+
+
+def build_point_grid(n_per_side: int) -> np.ndarray:
+    """utils/amg.py build_point_grid: an n x n grid of (x, y) in [0, 1], cell centres, x fastest."""
+    offset = 1.0 / (2 * n_per_side)
+    pts = np.linspace(offset, 1 - offset, n_per_side)
+    xs = np.tile(pts[None, :], (n_per_side, 1))
+    ys = np.tile(pts[:, None], (1, n_per_side))
+    return np.stack([xs, ys], axis=-1).reshape(-1, 2)
+
+
+def stability_score(mask_logits: torch.Tensor, mask_threshold: float, offset: float) -> torch.Tensor:
+    """utils/amg.py calculate_stability_score: IoU between the mask binarised at threshold + offset and at
+    threshold - offset (the first is contained in the second, so it is a ratio of areas)."""
+    inter = (mask_logits > (mask_threshold + offset)).flatten(-2).sum(-1, dtype=torch.int32)
+    union = (mask_logits > (mask_threshold - offset)).flatten(-2).sum(-1, dtype=torch.int32)
+    return inter / union
+
+
+def mask_boxes(masks: torch.Tensor) -> torch.Tensor:
+    """utils/amg.py batched_mask_to_box: XYXY boxes of bool masks [n, H, W]; an empty mask gives [0, 0, 0, 0]."""
+    if masks.numel() == 0:
+        return torch.zeros((*masks.shape[:-2], 4), dtype=torch.int64, device=masks.device)
+    h, w = masks.shape[-2:]
+    in_h = masks.any(dim=-1)
+    hc = in_h * torch.arange(h, device=masks.device)[None, :]
+    bottom = hc.max(dim=-1).values
+    top = (hc + h * (~in_h)).min(dim=-1).values
+    in_w = masks.any(dim=-2)
+    wc = in_w * torch.arange(w, device=masks.device)[None, :]
+    right = wc.max(dim=-1).values
+    left = (wc + w * (~in_w)).min(dim=-1).values
+    empty = (right < left) | (bottom < top)
+    out = torch.stack([left, top, right, bottom], dim=-1)
+    return out * (~empty).unsqueeze(-1)
+
+
+def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Greedy NMS with torchvision.ops.nms semantics: indices of the kept boxes in order of decreasing score; a box is
+    dropped when its IoU with an already kept, higher-scoring box exceeds ``iou_threshold``."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=boxes.device)
+    b = boxes.float()
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = b[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.maximum(b[:, None, :2], b[None, :, :2])
+    rb = torch.minimum(b[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    iou = inter / (area[:, None] + area[None, :] - inter)
+    over = (iou > iou_threshold).cpu().numpy()
+    keep = np.ones(n, dtype=bool)
+    for i in range(n):
+        if keep[i]:
+            sup = over[i].copy()
+            sup[:i + 1] = False
+            keep[sup] = False
+    return order[torch.from_numpy(np.nonzero(keep)[0]).to(order.device)]
+
+
+class SamAutoMasks:
+    """``generate(img_rgb uint8 [H, W, 3]) -> list of SAM records`` (keys as automatic_mask_generator.py:150-168:
+    segmentation bool [H, W], area, bbox XYWH, predicted_iou, point_coords, stability_score, crop_box), ordered by
+    decreasing predicted IoU (the order batched_nms returns)."""
+
+    def __init__(self, model, points_per_side: int = 32, points_per_batch: int = 64, pred_iou_thresh: float = 0.88,
+                 stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0, box_nms_thresh: float = 0.7,
+                 min_mask_region_area: int = 0, mask_threshold: float = 0.0, device: Union[str, torch.device] = "cpu"):
+        self.device = torch.device(device)
+        self.model = model.eval().to(self.device)
+        self.img_size = int(self.model.config.vision_config.image_size)
+        self.points_per_batch = int(points_per_batch)
+        self.pred_iou_thresh = float(pred_iou_thresh)
+        self.stability_score_thresh = float(stability_score_thresh)
+        self.stability_score_offset = float(stability_score_offset)
+        self.box_nms_thresh = float(box_nms_thresh)
+        self.min_mask_region_area = int(min_mask_region_area)
+        self.mask_threshold = float(mask_threshold)
+        self.point_grid = build_point_grid(points_per_side)
+
+    @classmethod
+    def from_config(cls, size: str = "huge", device="cpu", **kw) -> "SamAutoMasks":
+        """Random-initialised SAM of a published size (vit_b / vit_l / vit_h geometry)."""
+        from transformers import SamConfig, SamModel
+
+        arch = {"base": (768, 12, 12, (2, 5, 8, 11)), "large": (1024, 24, 16, (5, 11, 17, 23)),
+                "huge": (1280, 32, 16, (7, 15, 23, 31))}[size]
+        vis = dict(hidden_size=arch[0], num_hidden_layers=arch[1], num_attention_heads=arch[2], global_attn_indexes=list(arch[3]))
+        return cls(SamModel(SamConfig(vision_config=vis)), device=device, **kw)
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cpu", **kw) -> "SamAutoMasks":
+        from transformers import SamModel
+
+        return cls(SamModel.from_pretrained(path, local_files_only=True), device=device, **kw)
+
+    # ---- predictor.set_image: ResizeLongestSide + normalise + pad (predictor.py, utils/transforms.py, modeling/sam.py) ----
+    def preprocess(self, img_rgb: np.ndarray):
+        from PIL import Image
+
+        h, w = img_rgb.shape[:2]
+        scale = self.img_size * 1.0 / max(h, w)
+        nh, nw = int(h * scale + 0.5), int(w * scale + 0.5)
+        im = np.array(Image.fromarray(img_rgb).resize((nw, nh), Image.BILINEAR))        # torchvision's resize of a PIL image
+        x = torch.from_numpy(np.ascontiguousarray(im)).permute(2, 0, 1).float()
+        x = (x - torch.tensor(SAM_PIXEL_MEAN).view(3, 1, 1)) / torch.tensor(SAM_PIXEL_STD).view(3, 1, 1)
+        x = torch.nn.functional.pad(x, (0, self.img_size - nw, 0, self.img_size - nh))
+        return x[None].to(self.device), (nh, nw)
+
+    def _upscale(self, low_res: torch.Tensor, in_hw, out_hw) -> torch.Tensor:
+        """Sam.postprocess_masks: low-res logits -> padded model frame -> un-pad -> original size (bilinear both times)."""
+        m = torch.nn.functional.interpolate(low_res, (self.img_size, self.img_size), mode="bilinear", align_corners=False)
+        m = m[..., :in_hw[0], :in_hw[1]]
+        return torch.nn.functional.interpolate(m, out_hw, mode="bilinear", align_corners=False)
+
+    @torch.no_grad()
+    def generate(self, img_rgb: np.ndarray):
+        a = np.asarray(img_rgb)
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+            raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {a.dtype} {a.shape}")
+        H, W = a.shape[:2]
+        x, (nh, nw) = self.preprocess(a)
+        emb = self.model.get_image_embeddings(x)
+        pts_img = self.point_grid * np.array([[W, H]], dtype=np.float64)                 # (x, y) in the image
+        pts_model = pts_img * np.array([[nw / W, nh / H]])                                # ResizeLongestSide.apply_coords
+        masks_l, ious_l, stab_l, pts_l = [], [], [], []
+        for b0 in range(0, len(pts_img), self.points_per_batch):
+            pm = torch.as_tensor(pts_model[b0:b0 + self.points_per_batch], dtype=torch.float32, device=self.device)
+            nb = pm.shape[0]
+            out = self.model(image_embeddings=emb, input_points=pm.view(1, nb, 1, 2),
+                             input_labels=torch.ones((1, nb, 1), dtype=torch.int, device=self.device), multimask_output=True)
+            logits = self._upscale(out.pred_masks[0], (nh, nw), (H, W)).flatten(0, 1)      # [nb * 3, H, W]
+            iou = out.iou_scores[0].flatten(0, 1)
+            pts = torch.as_tensor(pts_img[b0:b0 + nb], dtype=torch.float64).repeat_interleave(logits.shape[0] // nb, dim=0)
+            keep = iou > self.pred_iou_thresh if self.pred_iou_thresh > 0.0 else torch.ones_like(iou, dtype=torch.bool)
+            logits, iou, pts = logits[keep], iou[keep], pts[keep.cpu()]
+            st = stability_score(logits, self.mask_threshold, self.stability_score_offset)
+            if self.stability_score_thresh > 0.0:
+                keep = st >= self.stability_score_thresh
+                logits, iou, pts, st = logits[keep], iou[keep], pts[keep.cpu()], st[keep]
+            masks_l.append(logits > self.mask_threshold)
+            ious_l.append(iou), stab_l.append(st), pts_l.append(pts)
+        masks = torch.cat(masks_l)
+        ious, stab, pts = torch.cat(ious_l), torch.cat(stab_l), torch.cat(pts_l)
+        boxes = mask_boxes(masks)
+        keep = box_nms(boxes, ious, self.box_nms_thresh)                                   # within-crop NMS, score = predicted IoU
+        kc = keep.cpu()
+        masks, ious, stab, pts, boxes = masks[keep].cpu().numpy(), ious[keep].cpu(), stab[keep].cpu(), pts[kc], boxes[keep].cpu()
+        recs = []
+        for j in range(masks.shape[0]):
+            area = int(masks[j].sum())
+            if area > self.min_mask_region_area:
+                x0, y0, x1, y1 = (int(v) for v in boxes[j])
+                recs.append({"segmentation": masks[j], "area": area, "bbox": [x0, y0, x1 - x0, y1 - y0],
+                             "predicted_iou": float(ious[j]), "point_coords": [[float(pts[j, 0]), float(pts[j, 1])]],
+                             "stability_score": float(stab[j]), "crop_box": [0, 0, W, H]})
+        return recs
+
+
+def resize_like_cv2(img: np.ndarray, width: int, height: int) -> np.ndarray:
+    """``cv2.resize(img, (width, height))`` (bilinear, pixel centres, no antialiasing), uint8 in and out."""
+    x = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float()[None]
+    y = torch.nn.functional.interpolate(x, size=(int(height), int(width)), mode="bilinear", align_corners=False, antialias=False)
+    return y[0].round().clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+
+
+def process_single_SAM(cfg: dict, img_bgr: np.ndarray, generator: SamAutoMasks):
+    """func_vpr.py:537-547: BGR -> RGB, resize to (desired_width, desired_height) when cfg['resize'], generate."""
+    img = np.ascontiguousarray(np.asarray(img_bgr)[:, :, ::-1])
+    img_p = resize_like_cv2(img, cfg["desired_width"], cfg["desired_height"]) if cfg.get("resize") else img
+    return img_p, generator.generate(img_p)
+
+
+def masks_given_image(generator: SamAutoMasks, img_bgr: np.ndarray, cfg: dict, mask_full_resolution: bool = False):
+    """func_vpr.py:564-590 with the image already decoded (cv2.imread is the caller's): crop rows ``rmin:``, run SAM at
+    HALF the configured resolution unless ``mask_full_resolution``; returns (list of bool masks, SAM records)."""
+    im = np.asarray(img_bgr)[int(cfg.get("rmin", 0)):, :, :]
+    f = 1.0 if mask_full_resolution else 0.5
+    cfg_sam = {"desired_width": int(f * cfg["desired_width"]), "desired_height": int(f * cfg["desired_height"]), "resize": True}
+    _, masks = process_single_SAM(cfg_sam, im, generator)
+    return [m["segmentation"] for m in masks], masks

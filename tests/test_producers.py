@@ -79,3 +79,92 @@ def test_tokens_feed_the_store_and_the_driver(tiny, tmp_path):
     t, m = driver.load_image_inputs(st.FeatureStore(str(tmp_path / "d"), "dino"), st.FeatureStore(str(tmp_path / "m"), "masks"), "a.jpg")
     assert t.shape == (48, 20) and m.shape == (3, 28, 35)
     assert np.allclose(t, tok.numpy().reshape(48, 20))
+
+
+# ---- SAM automatic masks (f3, second half) ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny_sam():
+    from transformers import SamConfig, SamModel
+
+    torch.manual_seed(7)
+    cfg = SamConfig(vision_config=dict(hidden_size=32, output_channels=16, num_hidden_layers=2, num_attention_heads=2, image_size=128,
+                                       patch_size=16, window_size=4, global_attn_indexes=[1], mlp_dim=64, num_pos_feats=8),
+                    prompt_encoder_config=dict(hidden_size=16, image_size=128, patch_size=16, mask_input_channels=4),
+                    mask_decoder_config=dict(hidden_size=16, mlp_dim=32, num_hidden_layers=2, num_attention_heads=2,
+                                             iou_head_hidden_dim=16, iou_head_depth=2))
+    m = SamModel(cfg)
+    with torch.no_grad():                      # the default initialiser (std 1e-10) gives constant outputs
+        for p in m.parameters():
+            p.normal_(0.0, 0.35)
+    return m
+
+
+def test_sam_helpers_match_their_definitions():
+    g = pr.build_point_grid(2)
+    assert np.allclose(g, [[0.25, 0.25], [0.75, 0.25], [0.25, 0.75], [0.75, 0.75]])           # (x, y), x fastest
+    assert pr.build_point_grid(32).shape == (1024, 2)
+    rng = np.random.Generator(np.random.PCG64(3))
+    lg = torch.from_numpy(rng.standard_normal((5, 12, 9)).astype(np.float32)) * 2
+    st = pr.stability_score(lg, 0.0, 1.0).numpy()
+    ref = [(lg[i] > 1).sum().item() / (lg[i] > -1).sum().item() for i in range(5)]
+    assert np.allclose(st, ref)
+    m = torch.zeros(3, 8, 10, dtype=torch.bool)
+    m[0, 2:5, 3:9] = True
+    m[1, 7, 0] = True
+    assert pr.mask_boxes(m).tolist() == [[3, 2, 8, 4], [0, 7, 0, 7], [0, 0, 0, 0]]           # XYXY inclusive; empty -> zeros
+    # NMS against the textbook loop
+    b = torch.from_numpy(rng.uniform(0, 50, (60, 2)).astype(np.float32))
+    boxes = torch.cat([b, b + torch.from_numpy(rng.uniform(5, 30, (60, 2)).astype(np.float32))], dim=1)
+    scores = torch.from_numpy(rng.random(60).astype(np.float32))
+    keep = pr.box_nms(boxes, scores, 0.3).tolist()
+
+    def iou(p, q):
+        iw = max(0.0, min(p[2], q[2]) - max(p[0], q[0]))
+        ih = max(0.0, min(p[3], q[3]) - max(p[1], q[1]))
+        inter = iw * ih
+        return inter / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - inter)
+
+    want = []
+    for i in np.argsort(-scores.numpy(), kind="stable"):
+        if all(iou(boxes[i].tolist(), boxes[j].tolist()) <= 0.3 for j in want):
+            want.append(int(i))
+    assert keep == want
+
+
+def test_sam_auto_masks_records_and_half_resolution(tiny_sam, tmp_path):
+    from revisit_anything_amd import store as st
+
+    gen = pr.SamAutoMasks(tiny_sam, points_per_side=6, points_per_batch=16, pred_iou_thresh=-1.0, stability_score_thresh=0.0,
+                          box_nms_thresh=0.7)
+    rng = np.random.Generator(np.random.PCG64(11))
+    img = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    x, (nh, nw) = gen.preprocess(img)
+    assert tuple(x.shape) == (1, 3, 128, 128) and (nh, nw) == (96, 128)                      # longest side -> 128, padded
+    recs = gen.generate(img)
+    assert len(recs) >= 1
+    ious = [r["predicted_iou"] for r in recs]
+    assert ious == sorted(ious, reverse=True)                                                 # batched_nms order
+    for r in recs:
+        seg = r["segmentation"]
+        assert seg.dtype == bool and seg.shape == (96, 128) and r["area"] == int(seg.sum()) > 0
+        ys, xs = np.nonzero(seg)
+        assert r["bbox"] == [int(xs.min()), int(ys.min()), int(xs.max() - xs.min()), int(ys.max() - ys.min())]
+        assert r["crop_box"] == [0, 0, 128, 96] and len(r["point_coords"]) == 1 and 0 <= r["stability_score"] <= 1
+    # surviving boxes do not overlap by more than the NMS threshold
+    bx = torch.tensor([[r["bbox"][0], r["bbox"][1], r["bbox"][0] + r["bbox"][2], r["bbox"][1] + r["bbox"][3]] for r in recs])
+    assert len(pr.box_nms(bx, torch.tensor(ious), 0.7)) == len(recs)
+    # thresholds act: the default 0.88 predicted-IoU cut removes everything a random network proposes
+    strict = pr.SamAutoMasks(tiny_sam, points_per_side=4, pred_iou_thresh=1e9)
+    assert strict.generate(img) == []
+    # the reference runs SAM at HALF the configured resolution (place_rec_SAM_DINO.py:61) on the BGR frame
+    cfg = {"rmin": 0, "desired_width": 128, "desired_height": 96}
+    segs, recs2 = pr.masks_given_image(gen, img[:, :, ::-1], cfg)
+    assert len(segs) == len(recs2) >= 1 and all(s.shape == (48, 64) for s in segs)
+    full, _ = pr.masks_given_image(gen, img[:, :, ::-1], cfg, mask_full_resolution=True)
+    assert all(s.shape == (96, 128) for s in full)
+    # records go into the mask store with the reference's nesting and come back through preload_masks
+    st.write_masks(str(tmp_path / "m"), "a.jpg", recs2)
+    from revisit_anything_amd.func_vpr import preload_masks
+    back = preload_masks(st.FeatureStore(str(tmp_path / "m"), "masks"), "a.jpg")
+    assert len(back) == len(recs2) and all(np.array_equal(b, r["segmentation"]) for b, r in zip(back, recs2))
+    assert np.array_equal(pr.resize_like_cv2(img, 128, 96), img)                              # identity size: untouched
