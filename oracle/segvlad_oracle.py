@@ -395,3 +395,29 @@ def recall_segloc(segFtVLAD1, segFtVLAD2, gt, segRange2, imInds1, pca=True, k_se
 def gt_17places(n_query: int, loc_rad: int = 15):
     """gt.py:60-64."""
     return [list(np.arange(i - loc_rad, i + loc_rad + 1)) for i in range(n_query)]
+
+
+# --------------------------------------------------------------------------------------------
+# f5  AnyLoc global VLAD                                   func_vpr.py:886-946 (vlad, segment=False), utilities.py:819-890
+# --------------------------------------------------------------------------------------------
+def global_vlad(tokens_dn, c_centers):
+    """VLAD.generate over ALL tokens of an image: the segment-VLAD of one all-token segment (float64; the reference
+    returns float32)."""
+    N = np.asarray(tokens_dn).shape[1]
+    return seg_vlad(tokens_dn, np.ones((1, N), dtype=bool), c_centers, None)[0]
+
+
+def get_recall_anyloc(db, q, gt, k=5):
+    """func_vpr.py:834-884: exact top-k (fp64 brute force instead of the KDTree: same neighbours), recall@1..k in percent."""
+    d2, ids = knn_l2(db, q, k)
+    recall = np.zeros(k)
+    n_eval = 0
+    for i in range(len(q)):
+        if len(gt[i]) == 0:
+            continue
+        n_eval += 1
+        for j in range(k):
+            if ids[i, j] in gt[i]:
+                recall[j] += 1
+                break
+    return np.cumsum(recall) / float(n_eval) * 100, ids

@@ -355,3 +355,90 @@ def calculate_map(queries_results):
     """func_vpr.py:363-392 surface (off by default: place_rec_main.py:107)."""
     ap = [calculate_ap(q) for q in queries_results]
     return sum(ap) / len(ap) if ap else 0
+
+
+# --------------------------------------------------------------------------------------------------
+# f5  AnyLoc global-VLAD baseline (place_rec_main.py:379-389)
+# --------------------------------------------------------------------------------------------------
+def _centres_of(vlad):
+    c = getattr(vlad, "c_centers", vlad)
+    return c if isinstance(c, torch.Tensor) else torch.as_tensor(np.asarray(c))
+
+
+def aggFt(desc_path, masks, segRange, cfg, aggType, vlad=None, upsample=False, segment_global=False, segment=False):
+    """func_vpr.py:886-946, the branch the AnyLoc baseline runs (``aggType='vlad'``, ``segment=False``,
+    place_rec_main.py:383-384): one global VLAD per image over ALL patch tokens -- L2-normalised tokens, hard cosine
+    assignment, residuals against the raw centres, intra-normalisation, L2 (``VLAD.generate``, utilities.py:819-890).
+    ``upsample`` is accepted and ignored exactly as in that branch (its interpolation is commented out, :936-937).
+    ``desc_path``: an open h5py-like mapping ``{key: {'ift_dino': [1, D, h, w]}}``, a store directory, or an .h5 path.
+    ``vlad``: the reference's VLAD object (its ``c_centers`` are used) or the centres themselves.
+    Returns a list of float32 ``[K*D]`` arrays in natural key order.  On the device this is the segment-VLAD kernel with
+    one all-token segment per image (a whole batch of images per call)."""
+    if aggType != "vlad" or segment or segment_global:
+        raise NotImplementedError("aggFt: only the AnyLoc global-VLAD branch (aggType='vlad', segment=False) is on the device path")
+    if vlad is None:
+        raise ValueError("aggFt(aggType='vlad') needs the vocabulary (a VLAD object or its c_centers)")
+    f = desc_path
+    if isinstance(desc_path, (str, os.PathLike)):
+        if os.path.isdir(desc_path):
+            from .store import FeatureStore
+
+            f = FeatureStore(str(desc_path), "dino")
+        else:
+            import h5py  # noqa: F401  (only where the reference's own files are used)
+
+            f = h5py.File(desc_path, "r")
+    keys = sorted(f.keys(), key=_natural_key)
+    eng = engine()
+    _set_vocab(_centres_of(vlad))
+    out: List[np.ndarray] = []
+    batch = 64
+    for b0 in range(0, len(keys), batch):
+        blocks = [np.asarray(f[k]["ift_dino"][()], dtype=np.float32) for k in keys[b0:b0 + batch]]
+        shapes = {b.shape for b in blocks}
+        groups = [blocks] if len(shapes) == 1 else [[b] for b in blocks]      # mixed geometries: one image per call
+        for grp in groups:
+            B = len(grp)
+            D = grp[0].shape[1]
+            N = grp[0].shape[2] * grp[0].shape[3]
+            tok = torch.from_numpy(np.stack([g.reshape(D, N) for g in grp])).to(eng.device)
+            nw = (N + 63) // 64
+            row = np.zeros(nw, np.uint64)
+            row[:N // 64] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            if N % 64:
+                row[N // 64] = np.uint64((1 << (N % 64)) - 1)
+            bits = torch.from_numpy(np.tile(row.view(np.int64), (B, 1))).to(eng.device)
+            v = eng.seg_vlad(tok, bits, np.arange(B + 1, dtype=np.int32), None)["out"].cpu().numpy()
+            out.extend(v[j] for j in range(B))
+    return out
+
+
+def get_recall(database_vectors, query_vectors, gt, analysis=False, k=5):
+    """func_vpr.py:834-884: exact top-k reference images per query (the reference's KDTree is an exact search; here the
+    device index), Recall@1..k in PERCENT over the queries with a non-empty ground truth, plus the per-query match
+    records ``{'seg_id_q': -1, 'img_id_r': ids[k], 'seg_id_r': -1, 'img_id_to_seg_id': -1}``; prints the same line."""
+    from .place_rec import IndexFlatL2
+
+    db = np.ascontiguousarray(database_vectors, dtype=np.float32)
+    q = np.ascontiguousarray(query_vectors, dtype=np.float32)
+    index = IndexFlatL2(db.shape[1])
+    index.add(db)
+    _, ids = index.search(q, int(k))
+    recall = [0] * k
+    recall_per_query = [0] * len(q)
+    matches = []
+    num_evaluated = 0
+    for i in range(len(q)):
+        matches.append({"seg_id_q": -1, "img_id_r": ids[i], "seg_id_r": -1, "img_id_to_seg_id": -1})
+        if len(gt[i]) == 0:
+            continue
+        num_evaluated += 1
+        hit = np.nonzero(np.isin(ids[i], np.asarray(gt[i])))[0]
+        if len(hit):
+            recall[int(hit[0])] += 1
+            recall_per_query[i] = 1
+    print("POSITIVES/TOTAL AnyLoc for this dataset: ", np.cumsum(recall), "/", num_evaluated)
+    rec = (np.cumsum(recall) / float(num_evaluated)) * 100
+    if analysis:
+        return rec, recall_per_query, matches
+    return rec, matches

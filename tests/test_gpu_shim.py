@@ -337,3 +337,41 @@ def test_host_helpers_preload_getIdx_calc_recall(fv, capsys):
     rec = fv.calc_recall([list(p) for p in z["preds"]], gts, 5)
     assert np.allclose(rec, z["recalls"])
     assert "POSITIVES/TOTAL segVLAD for this dataset" in capsys.readouterr().out
+
+
+# ------------------------------------------------------------------------------------------------
+# f5  AnyLoc global-VLAD baseline: aggFt(..., 'vlad', vlad) + get_recall (place_rec_main.py:379-389)
+# ------------------------------------------------------------------------------------------------
+def test_anyloc_aggFt_and_get_recall_golden(fv, tmp_path, capsys):
+    import types
+
+    import torch
+
+    from revisit_anything_amd import store as st
+
+    z = np.load(os.path.join(G, "anyloc_cases.npz"))
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    toks = [synth().make_tokens(voc, 34 * 45, seed=s, noise=0.2) for s in (2010, 2011)]
+    h5 = {f"img_{j}.jpg": {"ift_dino": t.reshape(1, 1536, 34, 45)} for j, t in enumerate(toks)}
+    vlad = types.SimpleNamespace(c_centers=torch.from_numpy(voc), num_clusters=32, desc_dim=1536)      # the reference's VLAD object
+    out = fv.aggFt(h5, None, None, {"desired_height": 480, "desired_width": 640}, "vlad", vlad, upsample=True)
+    assert isinstance(out, list) and len(out) == 2 and out[0].shape == (32 * 1536,) and out[0].dtype == np.float32
+    Gm = np.random.Generator(np.random.PCG64(780)).standard_normal((32 * 1536, 8))
+    for j in range(2):
+        assert np.abs(out[j][::37] - z[f"vlad{j}_sub"]).max() < 1e-6
+        assert np.abs(out[j].astype(np.float64) @ Gm - z[f"vlad{j}_proj"]).max() < 2e-4
+        assert np.abs(out[j] - O().global_vlad(toks[j], voc)).max() < 1e-6
+    # a store directory works like the h5 file, keys in natural order
+    for j, t in enumerate(toks):
+        st.write_dino(str(tmp_path / "d"), f"img_{j}.jpg", t.reshape(1, 1536, 34, 45))
+    out2 = fv.aggFt(str(tmp_path / "d"), None, None, {}, "vlad", torch.from_numpy(voc))
+    assert all(np.array_equal(a, b) for a, b in zip(out, out2))
+    with pytest.raises(NotImplementedError):
+        fv.aggFt(h5, None, None, {}, "avg", vlad)
+    gt = [[int(g)] if g >= 0 else [] for g in z["gt"]]
+    rec, matches = fv.get_recall(fv.normalizeFeat(z["db"]), fv.normalizeFeat(z["q"]), gt, k=5)
+    assert np.allclose(rec, z["recall"])
+    assert np.array_equal(np.stack([m["img_id_r"] for m in matches]), z["ids"])
+    assert "POSITIVES/TOTAL AnyLoc for this dataset" in capsys.readouterr().out
+    rec2, per_q, _ = fv.get_recall(z["db"], z["q"], gt, analysis=True, k=5)
+    assert np.allclose(rec2, z["recall"]) and sum(per_q) == round(z["recall"][-1] / 100 * sum(1 for g in gt if g))

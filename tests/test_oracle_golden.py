@@ -254,3 +254,20 @@ def test_knn_matrix_and_partition_topk_equal_the_argsort_form():
         assert np.array_equal(d2, d2b) and np.array_equal(idx, idxb)
     d2s, idxs = O.topk_from_d2(O.l2_matrix(R[:3], Q), 5)      # fewer rows than k
     assert np.all(idxs[:, 3:] == -1) and np.all(np.isinf(d2s[:, 3:]))
+
+
+def test_anyloc_global_vlad_and_recall():
+    """f5: the oracle's all-token VLAD == the reference's VLAD.generate (utilities.py:819-890, with the published cosine
+    `predict` of its third-party k-means), and get_recall (func_vpr.py:834-884)."""
+    z = L("anyloc_cases.npz")
+    voc = np.load(os.path.join(G, "vocab_indoor_k32_d1536.npy"))
+    for j, seed in enumerate((2010, 2011)):
+        tok = synth.make_tokens(voc, 34 * 45, seed=seed, noise=0.2)
+        v = O.global_vlad(tok, voc)
+        assert v.shape == (32 * 1536,)
+        assert np.abs(v[::37] - z[f"vlad{j}_sub"]).max() < 2e-7          # the reference computes this one in fp32
+        Gm = np.random.Generator(np.random.PCG64(780)).standard_normal((32 * 1536, 8))
+        assert np.abs(v @ Gm - z[f"vlad{j}_proj"]).max() < 1e-4
+    gt = [[int(g)] if g >= 0 else [] for g in z["gt"]]
+    rec, ids = O.get_recall_anyloc(z["db"], z["q"], gt, k=5)
+    assert np.allclose(rec, z["recall"]) and np.array_equal(ids, z["ids"])

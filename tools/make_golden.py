@@ -232,6 +232,50 @@ def main():
                         pca512=yv)
     print("VPAir-shape descriptor", gdv.shape, "pca512", yv.shape)
 
+    # ---- AnyLoc global VLAD (f5): the reference's VLAD.generate + get_recall bodies -------------------------------
+    # VLAD.generate / generate_res_vec are extracted from utilities.py (class methods); its kmeans member is
+    # fast_pytorch_kmeans (third party, absent): a stand-in with the published cosine `predict` (arg-max of the
+    # similarity between normalised points and normalised centroids).
+    import einops as ein
+    ucls = [n for n in ast.parse(open(f"{REF}/utilities.py").read()).body if isinstance(n, ast.ClassDef) and n.name == "VLAD"][0]
+    meths = [m for m in ucls.body if isinstance(m, ast.FunctionDef) and m.name in ("generate", "generate_res_vec", "can_use_cache_vlad")]
+    uns = dict(np=np, torch=torch, F=F, ein=ein, os=os, Union=__import__("typing").Union, List=__import__("typing").List)
+    exec(compile(ast.Module(body=meths, type_ignores=[]), f"{REF}/utilities.py", "exec"), uns)
+
+    class _KM:
+        def __init__(self, c):
+            self.c = F.normalize(c, dim=1)
+
+        def predict(self, x):
+            return torch.argmax(F.normalize(x, dim=1) @ self.c.T, dim=1)
+
+    vobj = types.SimpleNamespace(num_clusters=32, desc_dim=1536, intra_norm=True, norm_descs=True, vlad_mode="hard", cache_dir=None,
+                                 c_centers=torch.from_numpy(voc), kmeans=_KM(torch.from_numpy(voc)))
+    vobj.can_use_cache_vlad = lambda: False
+    vobj.generate_res_vec = lambda q, cid=None: uns["generate_res_vec"](vobj, q, cid)
+    av = {}
+    for j, seed in enumerate((2010, 2011)):
+        tk = synth.make_tokens(voc, 34 * 45, seed=seed, noise=0.2)
+        xq = F.normalize(torch.from_numpy(tk.reshape(1, 1536, -1)), dim=1).permute(0, 2, 1).squeeze()     # aggFt :941-943
+        gdv = uns["generate"](vobj, xq).numpy()
+        av[f"vlad{j}_sub"] = gdv[::37].astype(np.float64)
+        av[f"vlad{j}_proj"] = gdv.astype(np.float64) @ np.random.Generator(np.random.PCG64(780)).standard_normal((32 * 1536, 8))
+    from sklearn.neighbors import KDTree
+    fv.__dict__["KDTree"] = KDTree
+    extract(f"{REF}/func_vpr.py", {"get_recall"}, fv.__dict__)
+    rr = np.random.Generator(np.random.PCG64(781))
+    dbv = rr.standard_normal((40, 64)); dbv /= np.linalg.norm(dbv, axis=1, keepdims=True)
+    qv = dbv[rr.integers(0, 40, 15)] + 0.4 * rr.standard_normal((15, 64)); qv /= np.linalg.norm(qv, axis=1, keepdims=True)
+    gta = [[int(i)] for i in rr.integers(0, 40, 15)]
+    gta[3] = []
+    for i in (0, 1, 2, 5, 8):
+        gta[i] = [int(np.argmin(((dbv - qv[i]) ** 2).sum(1)))]
+    rec_a, match_a = fv.get_recall(dbv.astype(np.float32), qv.astype(np.float32), gta, k=5)
+    av.update(db=dbv.astype(np.float32), q=qv.astype(np.float32), gt=np.array([g[0] if g else -1 for g in gta]), recall=np.asarray(rec_a),
+              ids=np.stack([m["img_id_r"] for m in match_a]))
+    np.savez_compressed(f"{OUT}/anyloc_cases.npz", **av)
+    print("anyloc recall", rec_a)
+
     # ---- incidence cases (captured mask_idx) --------------------------------------------------------
     ic = {}
     cases = [("same", 112, 140, 112, 140), ("x2", 60, 80, 120, 160), ("x2clip", 63, 77, 126, 154),

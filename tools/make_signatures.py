@@ -13,7 +13,8 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 WANT = {
     "func_vpr.py": ["preload_masks", "getIdxSingleFast", "nbrMasksAGGFastSingle", "seg_vlad_gpu_single",
                     "seg_vlad_gpu_single_img", "vlad_single", "vlad_matmuls_per_cluster", "apply_pca_transform_from_pkl",
-                    "apply_pca_transform_from_pkl_numpy", "normalizeFeat", "get_matches", "calc_recall", "weighted_borda_count"],
+                    "apply_pca_transform_from_pkl_numpy", "normalizeFeat", "get_matches", "calc_recall", "weighted_borda_count",
+                    "aggFt", "get_recall"],
     "place_rec_main.py": ["recall_segloc"],
 }
 
