@@ -113,17 +113,24 @@ class ShardedSegmentIndex:
             idx = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
         if self.world == 1:
             return d2, idx
-        # ONE collective: (d2, global id) travel as a packed 12-byte record {fp32 bits, id low, id high}
+        d2c, idc = self.exchange_topk(d2, idx)
+        md, mi = self.be.merge_topk(d2c, idc, self.world, k)
+        return torch.as_tensor(md), torch.as_tensor(mi)
+
+    def exchange_topk(self, d2: torch.Tensor, idx: torch.Tensor):
+        """ONE collective for the per-shard lists: (d2 fp32, global id int64) travel as a packed 12-byte record
+        {fp32 bits, id low, id high}; returns ([nq, world*k] d2, [nq, world*k] ids), shard-major within a row.
+        (Also valid at world size 1, which is how the RCCL path is smoke-tested on a 1-GPU box.)"""
+        nq, k = int(d2.shape[0]), int(d2.shape[1])
         rec = torch.empty((nq, k, 3), dtype=torch.int32, device=self.device)
         rec[:, :, 0] = d2.contiguous().view(torch.int32)
         rec[:, :, 1:] = idx.contiguous().view(torch.int32).view(nq, k, 2)
         allrec = torch.empty((self.world * nq, k, 3), dtype=torch.int32, device=self.device)   # rank-major concatenation
         dist.all_gather_into_tensor(allrec, rec, group=self.group)
-        allrec = allrec.view(self.world, nq, k, 3).permute(1, 0, 2, 3)                                 # [nq, world, k, 3]: shard-major within a row
+        allrec = allrec.view(self.world, nq, k, 3).permute(1, 0, 2, 3)                        # [nq, world, k, 3]
         d2c = allrec[..., 0].contiguous().view(torch.float32).view(nq, self.world * k)
         idc = allrec[..., 1:].contiguous().view(torch.int64).view(nq, self.world * k)
-        md, mi = self.be.merge_topk(d2c, idc, self.world, k)
-        return torch.as_tensor(md), torch.as_tensor(mi)
+        return d2c, idc
 
     def retrieve(self, Q, qseg_offsets: Sequence[int], k_search: int = 200, k_vote: int = 50, n_top: int = 5, mode: int = 0,
                  want_scores: bool = False):

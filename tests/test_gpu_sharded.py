@@ -71,3 +71,47 @@ def test_two_ranks_one_gpu_equal_single_index(tmp_path):
         assert np.array_equal(z["pred"], pred.cpu().numpy())
         assert np.array_equal(z["sc"], sc.cpu().numpy())
     assert (pred.cpu().numpy()[:, 0] // 4 == tau // 4).mean() >= 0.9   # right sibling group (4 near-duplicate places)
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)       # "nccl" IS RCCL on ROCm
+    from revisit_anything_amd.engine import SegVLADEngine
+    from revisit_anything_amd.sharded import ShardedSegmentIndex
+
+    eng = SegVLADEngine(0)
+    idx = ShardedSegmentIndex(eng, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    d2 = torch.rand(37, 50, device=dev, generator=g)
+    ids = torch.randint(0, 2 ** 40, (37, 50), device=dev, generator=g)                 # ids beyond 32 bits survive the packing
+    a, b = idx.exchange_topk(d2, ids)                                                  # packed all_gather_into_tensor on RCCL
+    rows = idx.gather_rows(torch.rand(11, 64, device=dev, generator=g), [11]) if world == 1 else None
+    t = torch.ones(3, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(a, d2) and torch.equal(b, ids) and float(t[0]) == world and (rows is None or rows.shape == (11, 64)))
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(ok))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_smoke_world_size_1(tmp_path):
+    """The `nccl` (= RCCL) code path of the sharded index on the one GPU this box has: process-group creation on the
+    device, the packed (d2, id) all_gather_into_tensor and an all_reduce.  (World size 2 needs two devices: RCCL refuses
+    two ranks on one GPU; the driver's multi-GPU run is the first with world > 1.)"""
+    import torch
+    import torch.multiprocessing as mp
+
+    assert torch.cuda.is_available()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "ok0").read() == "True"
