@@ -973,8 +973,19 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   const bool f16_path = (want_f == 0 || want_f == 1) && (d % 64 == 0);
   const bool bf16_path = !f16_path && want_f != 3 && (d % 32 == 0);
   pl.kind = f16_path ? 1 : bf16_path ? 2 : 3;
-  ctx->sstats.levels = pl.levels;
   ctx->sstats.filter = pl.kind;
+  // The low-rank ("heuristic") thresholds need only a few dozen sample rows per rank, so their plan goes deeper: the
+  // exact fp32 level (an order of magnitude dearer per row than a filter level) shrinks to >= 192 rows -- 1 M rows:
+  // strides 4096, 256, 16, 1 instead of 256, 16, 1 (0.9 ms of exact GEMM per 10 000 queries -> 0.06 ms); a 125 k-row
+  // shard: 256, 16, 1 instead of 16, 1 (1.35 -> 0.1 ms).  The rigorous redo keeps the plan above.
+  const bool heuristic = pl.kind != 3 && ctx->opt.knn_heuristic && !ctx->db_heur_off && heur_rank(k) < k;
+  SearchPlan plh = pl;
+  if (heuristic)
+    while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
+      plh.stride0 *= SV_RATIO;
+      ++plh.levels;
+    }
+  ctx->sstats.levels = plh.levels;
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
     if (new_bytes <= b.cap) return hipSuccess;
     DevBuf nb;
@@ -1056,7 +1067,9 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_HIP(ctx->s_dist.reserve((size_t)SV_CHUNK * ((n0 + 3) & ~3ll) * 4));
   // Flags: [nq] rows + 1 count.  A heuristic pass flags the queries whose low-rank thresholds did not verify (-> redo
   // with the rigorous thresholds, below); a rigorous pass flags list overflows (-> exact distance-matrix path, alone).
-  const bool heuristic = pl.kind != 3 && ctx->opt.knn_heuristic && !ctx->db_heur_off && heur_rank(k) < k;
+  plh.c_eps = pl.c_eps;
+  plh.inv_scale = pl.inv_scale;
+  plh.rn_max = pl.rn_max;
   SV_HIP(ctx->s_ovf.reserve(((size_t)nq + 1) * 4));
   SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ((size_t)nq + 1) * 4, ctx->stream));
   uint32_t* flag_rows = ctx->s_ovf.as<uint32_t>();
@@ -1066,7 +1079,8 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   };
   for (int q0 = 0; q0 < nq; q0 += SV_CHUNK) {
     const int m = (nq - q0 < SV_CHUNK) ? (nq - q0) : SV_CHUNK;
-    SV_TRY(levels_chunk(ctx, pl, heuristic, (const float*)dq + (size_t)q0 * d, pl.kind == 3 ? nullptr : plane_a(ctx->s_qf16, ctx->s_qh, q0),
+    SV_TRY(levels_chunk(ctx, heuristic ? plh : pl, heuristic, (const float*)dq + (size_t)q0 * d,
+                        pl.kind == 3 ? nullptr : plane_a(ctx->s_qf16, ctx->s_qh, q0),
                         pl.kind == 2 ? ctx->s_ql.as<uint16_t>() + (size_t)q0 * d : nullptr, qn + q0, m, (float*)dd2 + (size_t)q0 * k,
                         (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count));
   }

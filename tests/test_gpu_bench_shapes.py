@@ -91,8 +91,8 @@ def test_knn_f16_filter_d1024_bench_and_shard_sizes(eng, planted_1m, n_rows):
         eng.set_option("search_stats", 1)
         d2, idx = eng.search(Q, k)
         st = eng.search_stats()
-        # level plan (api.hip): strides 256, 16, 1 down to 250 k rows; 125 k rows (the 8-GPU shard) get strides 16, 1
-        assert st["filter"] == "f16" and st["levels"] == (1 if n_rows == 125000 else 2) and st["n_fallback"] == 0, st
+        # level plan (api.hip, low-rank thresholds): 1 M rows -> strides 4096, 256, 16, 1; 500 k / 250 k / 125 k -> 256, 16, 1
+        assert st["filter"] == "f16" and st["levels"] == (3 if n_rows == 1000000 else 2) and st["n_fallback"] == 0, st
         # refine-list occupancy on planted + un-planted + clustered queries (cap 512 per query)
         print(f"[{n_rows} rows] last-level candidates mean {st['cand_sum'] / st['n_queries']:.0f} max {st['cand_max']}; "
               f"refine list mean {st['refine_sum'] / st['n_queries']:.0f} max {st['refine_max']} (cap 512)")

@@ -35,7 +35,7 @@ def test_bench_step_predictions_equal_oracle_on_20_images():
     # the workload is hard enough for the vote to matter (oracle Recall@1 ~ 0.8), on all 200 images
     assert 0.55 <= j["recall_at_1"] <= 0.95, j["recall_at_1"]
     assert j["filter_dtype"] == "f16" and j["dtype"] == "f32"
-    assert j["search_stats"]["n_fallback"] == 0 and j["search_stats"]["levels"] == 2
+    assert j["search_stats"]["n_fallback"] == 0 and j["search_stats"]["levels"] == 3
     assert j["roofline"]["bound"] == "mfma" and j["cpu_baseline"]["kind"] == "port"
 
 

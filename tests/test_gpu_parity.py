@@ -457,8 +457,11 @@ def test_knn_dense_block_of_neighbours_in_consecutive_rows(eng):
     d2, idx = (t.cpu().numpy() for t in eng.search(Q, k))
     launches = eng.stage_ms("knn_gemm")[1] + eng.stage_ms("knn_level0")[1]
     eng.set_profiling(False)
+    st = eng.search_stats()
     rd2, ridx = O().knn_l2(R, Q, k)
-    assert launches == 2, launches            # level-0 matrix GEMM + one filter level: no exact-path fall-back
+    # level-0 matrix GEMM + the filter levels (+ the rigorous redo's, if the low-rank thresholds did not verify on this
+    # place-coherent layout): never the exact distance-matrix fall-back
+    assert st["n_fallback"] == 0 and launches == 1 + st["levels"] + (2 if st["n_redo"] else 0), (launches, st)
     assert np.all((idx >= 5000) & (idx < 5260))
     # ||q||^2 ~ 600 and d2 ~ 0.3: the fp32 form q2 + r2 - 2 q.r cancels ~11 bits (as faiss' does)
     tol = 4e-6 * float((Q * Q).sum(1).max() + (R * R).sum(1).max())
