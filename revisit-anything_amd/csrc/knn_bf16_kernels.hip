@@ -992,13 +992,15 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
                                                             float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
                                                             uint32_t* __restrict__ ref_id, int rcap,
                                                             uint32_t* __restrict__ ovf_rows,
-                                                            uint32_t* __restrict__ ovf_count) {
+                                                            uint32_t* __restrict__ ovf_count,
+                                                            const uint32_t* __restrict__ todo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);  // [cap]
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_digit, s_krem, s_n;
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
+  if (todo && !todo[row]) return;   // already ranked by select_small_kernel
   const uint32_t c = cnt[row];
   // the threshold this list was collected under (read before thr_out -- possibly the same word -- is overwritten)
   const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
@@ -1082,14 +1084,106 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
   }
 }
 
+// The same ranking for SHORT lists (<= 1024 candidates: every list of the low-rank level scheme), one WAVE per query
+// instead of one 256-thread workgroup: the keys live in registers (16 per lane), the rank-th smallest is found by a
+// binary MSB-first radix select whose per-bit counts are wave reductions, the refine list is compacted by ballots.
+// No LDS, no barriers: 0.19 ms -> ~0.03 ms per 4096 queries and level.  Longer lists are left to select_approx_kernel
+// (todo[row] = 1).
+__global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+                                                           const uint32_t* __restrict__ cid, int nq, int cap, int k, int mode, int check,
+                                                           const float* __restrict__ thr_in, int64_t thr_in_ld,
+                                                           const float* __restrict__ qn, float c_eps, float rn_max,
+                                                           float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
+                                                           uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
+                                                           uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ todo) {
+  constexpr int PER = 16;
+  const int l = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nq) return;
+  const uint32_t c = cnt[row];
+  if (c > (uint32_t)(64 * PER) && c <= (uint32_t)cap && !ovf_rows[row]) {   // long list: the workgroup kernel ranks it
+    if (l == 0) todo[row] = 1u;
+    return;
+  }
+  if (l == 0) todo[row] = 0u;
+  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  auto flag_row = [&]() {
+    if (l == 0) {
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      if (mode == 1) ref_cnt[row] = 0;
+      else thr_out[row] = -INFINITY;
+    }
+  };
+  if (c > (uint32_t)cap || ovf_rows[row] || (check && (int)c < k)) {
+    flag_row();
+    return;
+  }
+  uint32_t key[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int j = l + 64 * i;
+    key[i] = (j < (int)c) ? f2key_(cd2[row * cap + j]) : 0xffffffffu;   // padding sorts last (a real key is never all ones: NaN-free)
+  }
+  float ak = INFINITY;
+  if ((int)c >= k) {
+    uint32_t prefix = 0, mask = 0, rem = (uint32_t)k;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t b = 1u << bit;
+      uint32_t zeros = 0;   // keys that match the prefix so far and have this bit clear
+#pragma unroll
+      for (int i = 0; i < PER; ++i) zeros += ((key[i] & (mask | b)) == prefix) ? 1u : 0u;
+      for (int o = 32; o > 0; o >>= 1) zeros += (uint32_t)__shfl_xor((int)zeros, o);
+      if (rem > zeros) {
+        rem -= zeros;
+        prefix |= b;
+      }
+      mask |= b;
+    }
+    ak = key2f_(prefix);
+  }
+  if (mode == 0) {
+    if (l == 0) thr_out[row] = ak;
+    return;
+  }
+  if (check && !(ak <= t_in)) {
+    flag_row();
+    return;
+  }
+  const uint32_t klim = f2key_(ak + 2.f * c_eps * sqrtf(qn[row] * rn_max));
+  uint32_t total = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int j = l + 64 * i;
+    const bool hit = (j < (int)c) && key[i] <= klim;
+    const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+    if (mk != 0ull) {
+      const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+      if (hit && pos < (uint32_t)rcap) ref_id[row * rcap + pos] = cid[row * cap + j];
+      total += (uint32_t)__popcll(mk);
+    }
+  }
+  if (l == 0) {
+    if (total > (uint32_t)rcap) {
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      ref_cnt[row] = 0;
+    } else {
+      ref_cnt[row] = total;
+    }
+  }
+}
+
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
                             float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
                             uint32_t* fail_rows, uint32_t* fail_count) {
   if (nq <= 0) return SEGVLAD_OK;
+  SV_HIP(ctx->s_sel_todo.reserve((size_t)nq * 4));
+  uint32_t* todo = ctx->s_sel_todo.as<uint32_t>();
+  hipLaunchKernelGGL(select_small_kernel, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cand_cnt, cand_d2, cand_id, nq, cap, rank, mode,
+                     check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo);
   const size_t lds = (size_t)cap * 4;
   hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, rank, mode, check,
-                     thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count);
+                     thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
