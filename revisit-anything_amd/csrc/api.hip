@@ -186,7 +186,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->pca_w1,    &ctx->pca_w2,   &ctx->s_xh1,     &ctx->s_xh2,    &ctx->s_desc,   &ctx->s_tokorder,
                     &ctx->s_laboff,  &ctx->s_rnsorted, &ctx->s_ovf,   &ctx->s_fb_q,   &ctx->s_fb_d2,  &ctx->s_fb_idx,
                     &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
-                    &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo};
+                    &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)

@@ -41,22 +41,30 @@ __device__ __forceinline__ bool better(double sa, uint32_t ta, double sb, uint32
 
 constexpr int VOTE_THREADS = 1024;
 
+// GLOBAL = false: the (image id, visiting order) keys of one query image are sorted in LDS (<= 16384 entries, i.e. 327
+// segments at k = 50); images with more entries are skipped.  GLOBAL = true: the workgroup handles query image
+// img_list[blockIdx.x] with its keys in a global scratch row (any size: SAM's automatic generator can return many hundreds
+// of segments on cluttered images) -- same algorithm, same bits, slower.
+template <bool GLOBAL>
 __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(const int64_t* __restrict__ idx, const float* __restrict__ sims,
                                                    const int32_t* __restrict__ img_of_seg, int64_t n_ref_seg,
                                                    const int32_t* __restrict__ qoff, int k,
                                                    const float* __restrict__ minmax, int n_top, int mode,
                                                    Run* __restrict__ runs_scratch, int64_t runs_stride,
-                                                   int32_t* __restrict__ pred, double* __restrict__ score, int use_wl) {
+                                                   int32_t* __restrict__ pred, double* __restrict__ score, int use_wl,
+                                                   int e_lds_cap, const int32_t* __restrict__ img_list,
+                                                   uint64_t* __restrict__ gkeys, int64_t gkeys_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* keys = GLOBAL ? gkeys + (int64_t)blockIdx.x * gkeys_stride : reinterpret_cast<uint64_t*>(smem);
   __shared__ uint32_t s_nruns;
   __shared__ double r_score[VOTE_THREADS];
   __shared__ uint32_t r_tie[VOTE_THREADS];
   __shared__ int r_pos[VOTE_THREADS];
   const int tid = threadIdx.x;
-  const int qi = blockIdx.x;
+  const int qi = GLOBAL ? img_list[blockIdx.x] : (int)blockIdx.x;
   const int q0 = qoff[qi], Sq = qoff[qi + 1] - q0;
   const int E = Sq * k;
+  if (!GLOBAL && E > e_lds_cap) return;   // oversized image: the GLOBAL launch handles it
   int Epad = 2;
   while (Epad < E) Epad <<= 1;
   const float smin = minmax[0], smax = minmax[1];
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(const int64_t* __res
 
   // the weights of the sorted entries, in parallel (the fp64 run sums below must stay sequential to reproduce the
   // reference's order of additions; fetching sims[] inside that serial walk was one exposed global load per entry)
-  float* wl = reinterpret_cast<float*>(keys + Epad);   // [E]
+  float* wl = reinterpret_cast<float*>(keys + Epad);   // [E]  (LDS mode only; use_wl = 0 in GLOBAL mode)
   if (mode == SEGVLAD_VOTE_WT_BORDA_IM && use_wl) {
     for (int p = tid; p < E; p += VOTE_THREADS) {
       const uint64_t key = keys[p];
@@ -173,26 +181,48 @@ int sv_launch_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, cons
                    int64_t n_ref_seg, const int32_t* qoff_dev, const int32_t* qoff_host, int n_img, int k,
                    const float* minmax_dev, int n_top, int mode, int32_t* pred, double* score) {
   if (n_img <= 0) return SEGVLAD_OK;
-  int maxS = 0;
+  constexpr int E_LDS = 16384;   // entries the in-LDS sort holds (8 B keys, 128 KiB)
+  int maxS_small = 0, maxS = 0;
+  std::vector<int32_t> big;
   for (int i = 0; i < n_img; ++i) {
     const int s = qoff_host[i + 1] - qoff_host[i];
     if (s < 0) return ctx->fail(SEGVLAD_ERR_ARG, "vote: qseg_offsets must be non-decreasing");
     if (s > maxS) maxS = s;
+    if ((int64_t)s * k > E_LDS) big.push_back(i);
+    else if (s > maxS_small) maxS_small = s;
   }
-  const int64_t E = (int64_t)maxS * k;
-  int Epad = 2;
-  while (Epad < E) Epad <<= 1;
-  size_t lds = (size_t)Epad * 12;   // sort keys + the entries' weights
-  const int use_wl = lds <= 128 * 1024;
-  if (!use_wl) lds = (size_t)Epad * 8;
-  if (lds > 128 * 1024)
-    return ctx->fail(SEGVLAD_ERR_LIMIT, "vote: %d segments x k=%d entries per query image exceed the 16384-entry LDS sort", maxS, k);
-  if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int64_t stride = E > 0 ? E : 1;
+  const int64_t Emax = (int64_t)maxS * k;
+  const int64_t stride = Emax > 0 ? Emax : 1;
   SV_HIP(ctx->s_misc.reserve((size_t)n_img * stride * sizeof(Run)));
-  hipLaunchKernelGGL(vote_kernel, dim3(n_img), dim3(VOTE_THREADS), lds, ctx->stream, idx, sims, img_of_seg, n_ref_seg, qoff_dev, k,
-                     minmax_dev, n_top, mode, ctx->s_misc.as<Run>(), stride, pred, score, use_wl);
-  SV_HIP(hipGetLastError());
+  if ((int)big.size() < n_img) {
+    const int64_t E = (int64_t)maxS_small * k;
+    int Epad = 2;
+    while (Epad < E) Epad <<= 1;
+    size_t lds = (size_t)Epad * 12;   // sort keys + the entries' weights
+    const int use_wl = lds <= 128 * 1024;
+    if (!use_wl) lds = (size_t)Epad * 8;
+    if (lds > 64 * 1024)
+      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vote_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    hipLaunchKernelGGL(vote_kernel<false>, dim3(n_img), dim3(VOTE_THREADS), lds, ctx->stream, idx, sims, img_of_seg, n_ref_seg, qoff_dev,
+                       k, minmax_dev, n_top, mode, ctx->s_misc.as<Run>(), stride, pred, score, use_wl, E_LDS,
+                       (const int32_t*)nullptr, (uint64_t*)nullptr, (int64_t)0);
+    SV_HIP(hipGetLastError());
+  }
+  if (!big.empty()) {   // oversized query images: keys sorted in a global scratch row each
+    if (Emax > (1ll << 24)) return ctx->fail(SEGVLAD_ERR_LIMIT, "vote: %d segments x k=%d entries per query image", maxS, k);
+    int64_t Epad = 2;
+    while (Epad < Emax) Epad <<= 1;
+    const size_t nb = big.size();
+    SV_HIP(ctx->s_vote_keys.reserve(nb * (size_t)Epad * 8 + nb * 4 + 64));
+    uint64_t* gk = ctx->s_vote_keys.as<uint64_t>();
+    int32_t* list = reinterpret_cast<int32_t*>(gk + nb * (size_t)Epad);
+    SV_HIP(hipMemcpyAsync(list, big.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(vote_kernel<true>, dim3((unsigned)nb), dim3(VOTE_THREADS), 0, ctx->stream, idx, sims, img_of_seg, n_ref_seg,
+                       qoff_dev, k, minmax_dev, n_top, mode, ctx->s_misc.as<Run>(), stride, pred, score, 0, E_LDS,
+                       (const int32_t*)list, gk, Epad);
+    SV_HIP(hipGetLastError());
+    SV_HIP(hipStreamSynchronize(ctx->stream));   // big[] lives on this frame
+  }
   return SEGVLAD_OK;
 }

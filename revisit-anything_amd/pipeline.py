@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._lib import SegVLADError
 from .engine import SegVLADEngine
 from .func_vpr import adjacency_from_centroids
 
@@ -67,7 +68,13 @@ class SegVLADPipeline:
             if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)
                 adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
             else:                     # device kernel: no host round trip
-                adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
+                try:
+                    adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
+                except SegVLADError as e:
+                    if "LDS budget" not in str(e):
+                        raise
+                    # an image with more segments (~620) than the in-LDS Delaunay holds: the reference's own Qhull path
+                    adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
         else:
             bits = eng.incidence(masks, self.H, self.W, self.patch)
             if not self.order:

@@ -353,3 +353,38 @@ def test_knn_heuristic_thresholds_equal_rigorous_and_redo_is_exact(eng, planted_
     assert np.abs(d2h[:16].cpu().numpy() - rd2).max() < 1e-5
     clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
     assert np.array_equal(idxh[:16].cpu().numpy()[clear], ridx[clear])
+
+
+def test_vote_handles_oversized_query_images(eng):
+    """a query image with more than 327 segments (k = 50) no longer raises ERR_LIMIT: its keys are sorted in
+    a global scratch row (vote_kernel<true>) while the other images of the batch keep the in-LDS sort.  Ids and fp64 scores
+    must stay bit-identical to the reference's accumulation order."""
+    from revisit_anything_amd._lib import VOTE_COUNT
+
+    rng = np.random.Generator(np.random.PCG64(77))
+    n_ref_img, segs = 400, 25
+    im = np.repeat(np.arange(n_ref_img), segs).astype(np.int32)
+    seg_per_q = np.array([30, 400, 5, 700, 64])                       # 400 * 50 and 700 * 50 entries exceed the LDS sort
+    off = np.concatenate([[0], np.cumsum(seg_per_q)]).astype(np.int32)
+    nq = int(off[-1])
+    matches = rng.integers(0, n_ref_img * segs, size=(nq, 50)).astype(np.int64)
+    for i in range(len(seg_per_q)):                                    # concentrate half of each image's votes on 4 images
+        pool = rng.integers(0, n_ref_img, size=4)
+        rows = slice(off[i], off[i + 1])
+        sel = rng.random((seg_per_q[i], 50)) < 0.5
+        repl = pool[rng.integers(0, 4, size=sel.shape)] * segs + rng.integers(0, segs, size=sel.shape)
+        matches[rows] = np.where(sel, repl, matches[rows])
+    sims = np.sort(rng.uniform(0.2, 1.9, size=(nq, 50)).astype(np.float32), axis=1)[:, ::-1].copy()
+    segRange = [np.arange(off[i], off[i + 1]) for i in range(len(seg_per_q))]
+    pred, sc = eng.vote(matches, sims, off, n_top=5, img_of_seg=im)
+    opred, oscore = O().get_matches_wt_borda_im(matches, len(seg_per_q), sims, segRange, im.astype(np.int64), n=5, return_scores=True)
+    pred, sc = pred.cpu().numpy(), sc.cpu().numpy()
+    for i in range(len(seg_per_q)):
+        assert pred[i].tolist() == [int(x) for x in opred[i]]
+        assert np.array_equal(sc[i], np.array(oscore[i]))             # fp64 sums bit-identical
+    predc, scc = eng.vote(matches, None, off, n_top=5, mode=VOTE_COUNT, img_of_seg=im)
+    _, counts = O().get_matches_max_seg_topk(matches, len(seg_per_q), segRange, im.astype(np.int64), n=5)
+    for i, bc in enumerate(counts):
+        order = np.lexsort((np.arange(len(bc)), -bc))[:5]
+        assert predc.cpu().numpy()[i].tolist() == order.tolist()
+        assert scc.cpu().numpy()[i].tolist() == bc[order].astype(np.float64).tolist()
