@@ -98,6 +98,7 @@ struct SvOptions {
   int assign_narrow = 0;  // 1: force the narrow assignment kernel
   int agg_kpb = 4;        // clusters per aggregation workgroup
   int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises)
+  int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
 };
 
 // statistics of the last segvlad_search (segvlad_search_stats)
@@ -132,6 +133,8 @@ struct segvlad_ctx {
   DevBuf pca_mean, pca_comps, pca_scale;  // scale = 1/sqrt(var) or 1
   DevBuf pca_w1, pca_w2;                  // fp16 two-term split of comps * pca_w_scale (16-bit MFMA path)
   float pca_w_scale = 0.f, pca_mean_maxabs = 0.f;
+  DevBuf pca_cproj;                       // [K+1][P]: W_k C_k and W mean ("project then aggregate"); rebuilt when stale
+  bool pca_cproj_valid = false;           // cleared by segvlad_set_vocab / segvlad_pca_set
 
   // database (exact kNN)
   int db_d = 0;
@@ -153,7 +156,7 @@ struct segvlad_ctx {
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
       s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
-      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys;
+      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -199,7 +202,8 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
 int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
                         const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
                         const float* gscale, int B, int N, int SC, float* out, float* block_norms,
-                        const float* mean = nullptr, float xscale = 0.f, uint16_t* h1 = nullptr, uint16_t* h2 = nullptr);
+                        const float* mean = nullptr, float xscale = 0.f, uint16_t* h1 = nullptr, uint16_t* h2 = nullptr,
+                        const int32_t* rowbase = nullptr);
 
 // gemm_kernels.hip
 int sv_launch_row_sumsq(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* out);
@@ -242,6 +246,15 @@ int sv_launch_split_f16x2(segvlad_ctx* ctx, const float* X, int64_t n_rows, int 
                           uint16_t* h2);
 int sv_launch_gemm_f16x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, const uint16_t* B1, const uint16_t* B2, int M,
                          int N, int Kd, float out_scale, const float* col_scale, float* C);
+int sv_launch_gemm_f16x3_grouped(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, const uint16_t* B1, const uint16_t* B2,
+                                 int M_pad, int N, int Kd, int n_groups, const int32_t* tile_group, float out_scale, float* C);
+// project_kernels.hip ("project then aggregate" form of segvlad_images_pca)
+int sv_launch_group_plan(segvlad_ctx* ctx, const int32_t* lab_off, int B, int K, int32_t* rowbase, int32_t* tile_group, int max_tiles);
+int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* mean, const float* centres, int P, int K, int D,
+                             float* cproj /*[K+1][P]: rows 0..K-1 = W_k C_k, row K = W mean*/);
+int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* cproj, const float* block_norms, const float* gscale,
+                                const uint64_t* colmask, const int32_t* lab_off, const int32_t* rowbase, const int32_t* seg_off_dev,
+                                int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y);
 int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out);
 int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
                                                                   const uint16_t* __restrict__ B2, int M, int N, int Kd,
                                                                   int tiles_m, int gm, int n_splits, int k_per_split, float out_scale,
                                                                   const float* __restrict__ col_scale,
-                                                                  float* __restrict__ C, int64_t ldc) {
+                                                                  float* __restrict__ C, int64_t ldc,
+                                                                  const int32_t* __restrict__ tile_group, int nkb_b) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int HBK = 32, RB = 64, RP = 16;           // 64-B rows per plane and k-tile, 16 rows per 1-KiB DMA piece
@@ -96,10 +97,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
     tm = (r % sm_cnt) * gm + within % gm;
     tn = (r / sm_cnt) * gn + within / gm;
     if (tm >= tiles_m || tn >= tiles_n) return;
+  } else if (tile_group) {   // grouped: tn fastest -- the column tiles of a row tile start together and share its A rows in L2
+    const int tiles_n = (N + BN - 1) / BN;
+    tn = blockIdx.x % tiles_n;
+    tm = blockIdx.x / tiles_n;
+    split = 0;
   } else {
     tm = blockIdx.x % tiles_m;
     tn = blockIdx.x / tiles_m;
     split = blockIdx.y;
+  }
+  // GROUPED mode (tile_group != null; the token projection of segvlad_images_pca): the rows of A are grouped, every
+  // BM-row tile belongs to ONE group g = tile_group[tm] (-1: unused tile) and is multiplied with k-blocks
+  // [g * Kd/32, (g+1) * Kd/32) of B, whose row blocks hold nkb_b k-blocks: C[rows of g] = A_g . B[:, g-th column slice]^T
+  int group = 0;
+  if (tile_group) {
+    group = tile_group[tm];
+    if (group < 0) return;
   }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -132,7 +146,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
     const int64_t r0 = n0 + (w * JB + j) * RP;
-    offB[j] = ((size_t)(r0 >> 7) * nkb + (size_t)(kbeg >> 5)) * 4096 + (size_t)(r0 & 127) * 32 + (size_t)l * 8;
+    offB[j] = ((size_t)(r0 >> 7) * (tile_group ? (size_t)nkb_b : nkb) + (size_t)(kbeg >> 5) + (size_t)group * nkb) * 4096 +
+              (size_t)(r0 & 127) * 32 + (size_t)l * 8;
   }
   // LDS: stage s = [A1 | A2 | B1 | B2], two stages
   constexpr int STAGE = 2 * PA + 2 * PB;
@@ -267,7 +282,7 @@ static int launch_x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, c
     grid = dim3((unsigned)((units + 7) / 8 * 8 * 32), 1);
   }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, ctx->stream, A1, A2, B1, B2, M, N, Kd, tiles_m, gm, splits, k_per_split,
-                     out_scale, col_scale, dst, (int64_t)N);
+                     out_scale, col_scale, dst, (int64_t)N, (const int32_t*)nullptr, 0);
   SV_HIP(hipGetLastError());
   if (splits > 1) {
     const int64_t mn = (int64_t)M * N;
@@ -285,4 +300,22 @@ int sv_launch_gemm_f16x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A
   const bool big = ctx->opt.x3_tile ? (ctx->opt.x3_tile == 256) : (M >= 1024);  // 256x256 tiles: 8.1 vs 12.6 ms at 10000 x 98304 x 1024
   if (big) return launch_x3<256, 256, 4, 2>(ctx, A1, A2, B1, B2, M, N, Kd, out_scale, col_scale, C);
   return launch_x3<128, 128, 2, 2>(ctx, A1, A2, B1, B2, M, N, Kd, out_scale, col_scale, C);
+}
+
+// Grouped projection (segvlad_images_pca, "project then aggregate"): Z[rows of group g][N] = A_g . B[:, g*Kd .. (g+1)*Kd)^T for
+// every group g, in ONE launch.  A planes: [M_pad][Kd] blocked, rows grouped, every 256-row tile inside one group
+// (tile_group[tile], -1 = unused); B planes: [N][groups * Kd] blocked (the PCA components: group g = cluster g's columns).
+int sv_launch_gemm_f16x3_grouped(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, const uint16_t* B1, const uint16_t* B2,
+                                 int M_pad, int N, int Kd, int n_groups, const int32_t* tile_group, float out_scale, float* C) {
+  if (M_pad <= 0 || N <= 0) return SEGVLAD_OK;
+  constexpr int BM = 256, BN = 256;
+  const int tiles_m = M_pad / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
+  auto kern = gemm_f16x3_kernel<BM, BN, 4, 2>;
+  SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // tn fastest: the four column tiles of a row tile start together and share its A rows in L2
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), 1), dim3(512), lds, ctx->stream, A1, A2, B1, B2, M_pad, N, Kd, tiles_m, 0,
+                     1, Kd, out_scale, (const float*)nullptr, C, (int64_t)N, tile_group, n_groups * (Kd >> 5));
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
 }

@@ -824,7 +824,13 @@ __device__ unsigned long long sv_agg_phase_cycles[8];   // ABL == 9: s_memtime p
     phase_t0 = now_;                                                              \
   }
 
-template <bool PLANES, int ABL = 0>   // ABL: timing ablations (SEGVLAD_AGG_ABL; wrong results)
+// MODE 0: the normalised fp32 descriptor blocks go to `out`.  MODE 1 ("planes"): additionally / instead the two fp16 planes
+// (v - mean) * xscale = h1 + h2 of the descriptor, in the blocked layout the projection GEMM reads.  MODE 2 ("project then
+// aggregate"): nothing of the descriptor is stored -- only its block norms -- and the kernel emits the fp16 planes of the
+// NORMALISED TOKENS x^ * xscale, rows grouped by cluster across the batch (rowbase[b][k] = first row of image b's cluster-k
+// tokens): the projection then runs per token with its cluster's slice of the components (half the flops of projecting the
+// K*D-wide descriptor) and the segments are aggregated in the projected space (project_kernels.hip).
+template <int MODE, int ABL = 0>   // ABL: timing ablations (SEGVLAD_AGG_ABL; wrong results)
 __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
                                                         const int32_t* __restrict__ tok_order,
                                                         const int32_t* __restrict__ lab_off,
@@ -834,7 +840,8 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
                                                         int Ncap, float* __restrict__ out,
                                                         float* __restrict__ block_norms, const float* __restrict__ mean,
                                                         float xscale, _Float16* __restrict__ h1, _Float16* __restrict__ h2,
-                                                        int kpb) {
+                                                        int kpb, const int32_t* __restrict__ rowbase) {
+  constexpr bool PLANES = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -921,6 +928,20 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is read before it is refilled
         if (ABL != 1 && p + QD < npairs) issue(p + QD);
         if (!dvalid || ABL == 1) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 2 && sc == 0 && dvalid && j < n) {   // the normalised token's fp16 planes, grouped row rowbase + j
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          const float s_ = rn * xscale;
+          const float f[4] = {x.x * s_, x.y * s_, x.z * s_, x.w * s_};
+          h4 p1, p2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p1[e] = (_Float16)f[e];
+            p2[e] = (_Float16)(f[e] - (float)p1[e]);
+          }
+          const size_t ob = sv_x3_off((int64_t)rowbase[(size_t)b * K + k] + j, dcol, D);
+          *reinterpret_cast<h4*>(h1 + ob) = p1;
+          *reinterpret_cast<h4*>(h2 + ob) = p2;
+        }
         const float b0 = fmaf(x.x, rn, -c4.x), b1 = fmaf(x.y, rn, -c4.y);
         const float b2 = fmaf(x.z, rn, -c4.z), b3 = fmaf(x.w, rn, -c4.w);
         const float a0 = ((m >> i) & 1ull) ? 1.f : 0.f;
@@ -972,7 +993,7 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
     SV_APHASE(7)  // row sums
     __syncthreads();
     SV_APHASE(2)  // barrier
-    if (dvalid) {
+    if (MODE != 2 && dvalid) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         if (mt == 1 && !two) break;
@@ -1012,7 +1033,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
                         const uint8_t* /*labels: grouped by prep*/,
                         const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
                         const float* gscale, int B, int N, int SC, float* out, float* block_norms, const float* mean,
-                        float xscale, uint16_t* h1, uint16_t* h2) {
+                        float xscale, uint16_t* h1, uint16_t* h2, const int32_t* rowbase) {
   const int nwaves = (D + 127) / 128;
   if (nwaves > 12)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: D=%d exceeds the 1536-wide workgroup of this build", D);
@@ -1022,14 +1043,15 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
   lds = (lds + 15) & ~(size_t)15;
   lds += (size_t)nwaves * 6 * 1024;   // DMA queue
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: N=%d tokens need %zu B of LDS (limit 160 KiB)", N, lds);
-  auto kern = (h1 != nullptr) ? aggregate_kernel<true> : aggregate_kernel<false>;
+  // rowbase != null: "project then aggregate" (token planes + block norms); else h1 != null: descriptor planes
+  auto kern = (rowbase != nullptr) ? aggregate_kernel<2> : (h1 != nullptr) ? aggregate_kernel<1> : aggregate_kernel<0>;
   bool phases = false;
 #ifdef SEGVLAD_ABLATIONS   // timing ablations / phase timing: development builds only
   if (const char* ab = getenv("SEGVLAD_AGG_ABL")) {
-    if (atoi(ab) == 1) kern = aggregate_kernel<false, 1>;
-    if (atoi(ab) == 2) kern = aggregate_kernel<false, 2>;
+    if (atoi(ab) == 1) kern = aggregate_kernel<0, 1>;
+    if (atoi(ab) == 2) kern = aggregate_kernel<0, 2>;
     if (atoi(ab) == 9) {
-      kern = aggregate_kernel<false, 9>;
+      kern = aggregate_kernel<0, 9>;
       phases = true;
       unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       SV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sv_agg_phase_cycles), z, sizeof(z)));
@@ -1044,7 +1066,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
                      ctx->s_tokorder.as<int32_t>(),
                      ctx->s_laboff.as<int32_t>(), colmask, centres, seg_off_dev,
                      gscale, N, D, K, SC, Ncap, out, block_norms, mean, xscale, reinterpret_cast<_Float16*>(h1),
-                     reinterpret_cast<_Float16*>(h2), kpb);
+                     reinterpret_cast<_Float16*>(h2), kpb, rowbase);
   SV_HIP(hipGetLastError());
 #ifdef SEGVLAD_ABLATIONS
   if (phases) {
