@@ -268,7 +268,6 @@ int segvlad_set_vocab(segvlad_ctx* ctx, const float* C, int K, int D) {
   ctx->K = K;
   ctx->D = D;
   ctx->Kpad = Kpad;
-  ctx->pca_cproj_valid = false;
   SV_TRY(sv_launch_vocab_prepare(ctx));
   return sv_finish(ctx);
 }
@@ -396,19 +395,19 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
                        (ctx->opt.pca_path == 2 || (double)S_tot * K >= 1.25 * (double)B * N);
   int64_t rows_pad = 0;   // grouped token rows: every cluster's rows padded to whole 256-row GEMM tiles
   if (fused && project) {
-    xscale = ldexpf(1.f, 14);   // |x^| <= 1
+    xscale = ldexpf(1.f, 13);   // residuals of unit tokens against the centres (means of unit tokens): |r| <= 2
     rows_pad = (((int64_t)B * N + 255) & ~255ll) + 256ll * K;
-    SV_HIP(ctx->s_xh1.reserve((size_t)rows_pad * D * 2));
-    SV_HIP(ctx->s_xh2.reserve((size_t)rows_pad * D * 2));
+    SV_HIP(ctx->s_xh1.reserve((size_t)(rows_pad + 256) * D * 2));   // + one tile: the dummy row of sv_launch_token_norms
+    SV_HIP(ctx->s_xh2.reserve((size_t)(rows_pad + 256) * D * 2));
     SV_HIP(ctx->s_pz.reserve((size_t)rows_pad * ctx->P * sizeof(float)));
     SV_HIP(ctx->s_rowbase.reserve((size_t)B * K * sizeof(int32_t)));
     SV_HIP(ctx->s_tilegrp.reserve((size_t)(rows_pad >> 8) * sizeof(int32_t)));
     SV_HIP(ctx->s_bn.reserve((size_t)S_tot * K * sizeof(float)));
     SV_TRY(sv_out(ctx, pca_y, (size_t)S_tot * ctx->P * sizeof(float), &d_y));
     if (!ctx->pca_cproj_valid) {
-      SV_HIP(ctx->pca_cproj.reserve((size_t)(K + 1) * ctx->P * sizeof(float)));
-      SV_TRY(sv_launch_project_consts(ctx, ctx->pca_comps.as<float>(), ctx->pca_mean.as<float>(), ctx->vocab.as<float>(), ctx->P,
-                                      K, D, ctx->pca_cproj.as<float>()));
+      SV_HIP(ctx->pca_cproj.reserve((size_t)ctx->P * sizeof(float)));
+      SV_TRY(sv_launch_project_consts(ctx, ctx->pca_comps.as<float>(), ctx->pca_mean.as<float>(), ctx->P, ctx->KD,
+                                      ctx->pca_cproj.as<float>()));
       ctx->pca_cproj_valid = true;
     }
   } else if (fused) {
@@ -465,10 +464,9 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
         StageScope sc(ctx, "aggregate");   // block norms + the normalised tokens' fp16 planes, grouped by cluster
         SV_TRY(sv_launch_group_plan(ctx, ctx->s_laboff.as<int32_t>(), B, K, ctx->s_rowbase.as<int32_t>(),
                                     ctx->s_tilegrp.as<int32_t>(), (int)(rows_pad >> 8)));
-        SV_TRY(sv_launch_aggregate(ctx, ctx->s_xt.as<float>(), ctx->s_rnorm.as<float>(), (const uint8_t*)d_lab,
-                                   ctx->s_colmask.as<uint64_t>(), ctx->vocab.as<float>(), K, D, ctx->s_segoff.as<int32_t>(),
-                                   ctx->s_gscale.as<float>(), B, N, SC, nullptr, bn, nullptr, xscale, ctx->s_xh1.as<uint16_t>(),
-                                   ctx->s_xh2.as<uint16_t>(), ctx->s_rowbase.as<int32_t>()));
+        SV_TRY(sv_launch_token_norms(ctx, ctx->s_xt.as<float>(), ctx->s_colmask.as<uint64_t>(), ctx->vocab.as<float>(), K, D,
+                                     ctx->s_segoff.as<int32_t>(), B, N, SC, bn, xscale, ctx->s_xh1.as<uint16_t>(),
+                                     ctx->s_xh2.as<uint16_t>(), ctx->s_rowbase.as<int32_t>(), ctx->opt.debug_search == 7 ? -rows_pad : rows_pad));
         sc.count(2);
       }
       StageScope sc(ctx, "pca");

@@ -133,8 +133,8 @@ struct segvlad_ctx {
   DevBuf pca_mean, pca_comps, pca_scale;  // scale = 1/sqrt(var) or 1
   DevBuf pca_w1, pca_w2;                  // fp16 two-term split of comps * pca_w_scale (16-bit MFMA path)
   float pca_w_scale = 0.f, pca_mean_maxabs = 0.f;
-  DevBuf pca_cproj;                       // [K+1][P]: W_k C_k and W mean ("project then aggregate"); rebuilt when stale
-  bool pca_cproj_valid = false;           // cleared by segvlad_set_vocab / segvlad_pca_set
+  DevBuf pca_cproj;                       // [P]: W mean ("project then aggregate"); rebuilt when stale
+  bool pca_cproj_valid = false;           // cleared by segvlad_pca_set
 
   // database (exact kNN)
   int db_d = 0;
@@ -202,8 +202,12 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
 int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels,
                         const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
                         const float* gscale, int B, int N, int SC, float* out, float* block_norms,
-                        const float* mean = nullptr, float xscale = 0.f, uint16_t* h1 = nullptr, uint16_t* h2 = nullptr,
-                        const int32_t* rowbase = nullptr);
+                        const float* mean = nullptr, float xscale = 0.f, uint16_t* h1 = nullptr, uint16_t* h2 = nullptr);
+
+// block norms + the fp16 planes of the token residuals x^ - C_k, grouped by cluster (rowbase from sv_launch_group_plan); after sv_launch_prep
+int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* colmask, const float* centres, int K, int D,
+                          const int32_t* seg_off_dev, int B, int N, int SC, float* block_norms, float xscale, uint16_t* h1,
+                          uint16_t* h2, const int32_t* rowbase, int64_t dummy_row /* a plane row nobody reads */);
 
 // gemm_kernels.hip
 int sv_launch_row_sumsq(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* out);
@@ -250,9 +254,8 @@ int sv_launch_gemm_f16x3_grouped(segvlad_ctx* ctx, const uint16_t* A1, const uin
                                  int M_pad, int N, int Kd, int n_groups, const int32_t* tile_group, float out_scale, float* C);
 // project_kernels.hip ("project then aggregate" form of segvlad_images_pca)
 int sv_launch_group_plan(segvlad_ctx* ctx, const int32_t* lab_off, int B, int K, int32_t* rowbase, int32_t* tile_group, int max_tiles);
-int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* mean, const float* centres, int P, int K, int D,
-                             float* cproj /*[K+1][P]: rows 0..K-1 = W_k C_k, row K = W mean*/);
-int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* cproj, const float* block_norms, const float* gscale,
+int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* mean, int P, int64_t KD, float* wmu /*[P] = W mean*/);
+int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* wmu, const float* block_norms, const float* gscale,
                                 const uint64_t* colmask, const int32_t* lab_off, const int32_t* rowbase, const int32_t* seg_off_dev,
                                 int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y);
 int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out);

@@ -1,21 +1,23 @@
 // "Project then aggregate": the fused segment-VLAD -> PCA call (segvlad_images_pca without the descriptor output)
 // reformulated so that the K*D-wide descriptor is never formed (gfx950).
 //
-// The reference computes, per segment s, the blocks V_sk = sum_{t in cluster k, t covered by s} (x^_t - C_k), normalises
-// each block and the whole vector, and projects: y_s = (g_s * concat_k(V_sk / ||V_sk||) - mu) W^T / sqrt(lambda)
-// (func_vpr.py:1181-1210, 1419-1443).  The projection is linear, so with W_k = W[:, kD:(k+1)D], z_t = W_k(t) x^_t,
-// c_k = W_k C_k and a_sk = g_s / ||V_sk||:
+// The reference computes, per segment s, the blocks V_sk = sum_{t in cluster k, t covered by s} r_t with r_t = x^_t - C_k(t),
+// normalises each block and the whole vector, and projects: y_s = (g_s * concat_k(V_sk / ||V_sk||) - mu) W^T / sqrt(lambda)
+// (func_vpr.py:1181-1210, 1419-1443).  The projection is linear, so with W_k = W[:, kD:(k+1)D], z_t = W_k(t) r_t and
+// a_sk = g_s / ||V_sk||:
 //
-//     y_s = ( sum_t [t covered by s] a_{s,k(t)} z_t  -  sum_k a_sk n_sk c_k  -  W mu ) / sqrt(lambda)
+//     y_s = ( sum_t [t covered by s] a_{s,k(t)} z_t  -  W mu ) / sqrt(lambda)
 //
-// i.e. every TOKEN is projected once with its cluster's slice of the components -- 2 N D P flops per image instead of
-// 2 S K D P for the descriptor (1530 x 1536 instead of 50 x 98 304 rows x columns: 2.1 x fewer) -- and the segments are
-// aggregated in the P-dimensional space.  Only the block norms ||V_sk|| still come from the D-space aggregation kernel
-// (aggregate_kernel MODE 2, which also emits the fp16 planes of the normalised tokens, grouped by cluster).
+// i.e. every TOKEN's residual is projected once with its cluster's slice of the components -- 2 N D P flops per image
+// instead of 2 S K D P for the descriptor (1530 x 1536 instead of 50 x 98 304 rows x columns: 2.1 x fewer) -- and the
+// segments are aggregated in the P-dimensional space.  Only the block norms ||V_sk|| still come from the D-space
+// (token_norms_kernel, vlad_kernels.hip, which also emits the fp16 planes of the residuals, grouped by cluster).
+// Projecting the RESIDUAL (not the token, with the centre term subtracted afterwards) keeps the sums free of cancellation:
+// the result is as accurate as projecting the finished descriptor.
 //
 //   group_plan_kernel          lab_off [B][K+1] -> rowbase [B][K] (grouped row of (image, cluster)), tile_group [tiles]
-//   project_consts_kernel      c_k = W_k C_k  ([K][P]) and W mu ([P])            (once per (vocabulary, PCA model))
-//   project_aggregate_kernel   the weighted sums above on fp32 MFMA (exact fp32 chains), whitening scale fused
+//   project_consts_kernel      W mu ([P])                                         (once per PCA model)
+//   project_aggregate_kernel   the weighted sums above on fp32 MFMA (exact fp32 chains), mean term and whitening scale fused
 #include "ctx.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,60 +25,67 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int pj_frag_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
 
 // ---- grouping plan ---------------------------------------------------------------------------------------------------
-// One workgroup, one thread per cluster.  Cluster k's tokens of all images occupy rows [base_k, base_k + M_k) of the
-// grouped planes, base_k a multiple of 256 (a GEMM row tile never straddles two clusters); inside, image b's tokens of
-// that cluster start at rowbase[b][k], in the label-grouped order of prep_kernel.
-__global__ __launch_bounds__(256) void group_plan_kernel(const int32_t* __restrict__ lab_off, int B, int K,
-                                                         int32_t* __restrict__ rowbase, int32_t* __restrict__ tile_group,
-                                                         int max_tiles) {
-  __shared__ int32_t tot[256], base[257];
-  const int k = threadIdx.x;
+// One workgroup.  Cluster k's tokens of all images occupy rows [base_k, base_k + M_k) of the grouped planes, base_k a
+// multiple of 256 (a GEMM row tile never straddles two clusters); inside, image b's tokens of that cluster start at
+// rowbase[b][k], in the label-grouped order of prep_kernel.  Thread (k, c) owns cluster k for the c-th slice of the images:
+// slice sums -> exclusive scan over the slices (per cluster) and over the padded cluster totals -> slice walk.
+__global__ __launch_bounds__(1024) void group_plan_kernel(const int32_t* __restrict__ lab_off, int B, int K,
+                                                          int32_t* __restrict__ rowbase, int32_t* __restrict__ tile_group,
+                                                          int max_tiles) {
+  __shared__ int32_t part[1024], base[257];
+  const int nsl = 1024 / K;                       // image slices (K <= 256 -> >= 4)
+  const int k = threadIdx.x % K, c = threadIdx.x / K;
+  const int per = (B + nsl - 1) / nsl, b0 = c * per, b1 = min(B, b0 + per);
+  const bool act = c < nsl;
   for (int t = threadIdx.x; t < max_tiles; t += blockDim.x) tile_group[t] = -1;
-  int run = 0;
-  if (k < K) {
-    for (int b = 0; b < B; ++b) {
-      rowbase[(size_t)b * K + k] = run;   // relative to the cluster's base for now
-      run += lab_off[(size_t)b * (K + 1) + k + 1] - lab_off[(size_t)b * (K + 1) + k];
+  int sum = 0;
+  if (act)
+    for (int b = b0; b < b1; ++b) sum += lab_off[(size_t)b * (K + 1) + k + 1] - lab_off[(size_t)b * (K + 1) + k];
+  part[threadIdx.x] = act ? sum : 0;
+  __syncthreads();
+  if ((int)threadIdx.x < K) {                     // exclusive scan over this cluster's slices; total M_k
+    int run = 0;
+    for (int q = 0; q < nsl; ++q) {
+      const int v = part[q * K + threadIdx.x];
+      part[q * K + threadIdx.x] = run;
+      run += v;
     }
-    tot[k] = run;
+    base[threadIdx.x + 1] = (run + 255) & ~255;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int q = 0; q < K; ++q) {
-      base[q] = acc;
-      acc += (tot[q] + 255) & ~255;
-    }
-    base[K] = acc;
+    base[0] = 0;
+    for (int q = 0; q < K; ++q) base[q + 1] += base[q];
   }
   __syncthreads();
-  if (k < K) {
-    const int bk = base[k];
-    for (int b = 0; b < B; ++b) rowbase[(size_t)b * K + k] += bk;
-    for (int t = bk >> 8; t < (base[k + 1] >> 8) && t < max_tiles; ++t) tile_group[t] = k;
+  if (act) {
+    int run = base[k] + part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) {
+      rowbase[(size_t)b * K + k] = run;
+      run += lab_off[(size_t)b * (K + 1) + k + 1] - lab_off[(size_t)b * (K + 1) + k];
+    }
   }
+  __syncthreads();   // the -1 fill above is complete
+  if ((int)threadIdx.x < K)
+    for (int t = base[threadIdx.x] >> 8; t < (base[threadIdx.x + 1] >> 8) && t < max_tiles; ++t) tile_group[t] = threadIdx.x;
 }
 
 int sv_launch_group_plan(segvlad_ctx* ctx, const int32_t* lab_off, int B, int K, int32_t* rowbase, int32_t* tile_group,
                          int max_tiles) {
   if (K > 256) return ctx->fail(SEGVLAD_ERR_LIMIT, "group_plan: K=%d > 256", K);
-  hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(256), 0, ctx->stream, lab_off, B, K, rowbase, tile_group, max_tiles);
+  hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, lab_off, B, K, rowbase, tile_group, max_tiles);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
 
-// ---- constants of a (vocabulary, PCA model) pair -----------------------------------------------------------------------
-// cproj[k][p] = sum_d comps[p][k D + d] * C[k][d]  (k < K);   cproj[K][p] = sum_j comps[p][j] * mean[j]
+// ---- constant of a PCA model ------------------------------------------------------------------------------------------------
+// wmu[p] = sum_j comps[p][j] * mean[j]
 __global__ __launch_bounds__(256) void project_consts_kernel(const float* __restrict__ comps, const float* __restrict__ mean,
-                                                             const float* __restrict__ C, int P, int K, int D,
-                                                             float* __restrict__ cproj) {
-  const int p = blockIdx.x, k = blockIdx.y;
-  const size_t KD = (size_t)K * D;
-  const float* w = comps + (size_t)p * KD + (k < K ? (size_t)k * D : 0);
-  const float* v = k < K ? C + (size_t)k * D : mean;
-  const int len = k < K ? D : (int)KD;
-  double acc = 0.0;   // one-off, tiny: fp64 so that the constants carry no rounding of their own
-  for (int j = threadIdx.x; j < len; j += 256) acc += (double)w[j] * (double)v[j];
+                                                             int P, int64_t KD, float* __restrict__ wmu) {
+  const int p = blockIdx.x;
+  const float* w = comps + (size_t)p * KD;
+  double acc = 0.0;   // one-off, tiny: fp64 so that the constant carries no rounding of its own
+  for (int64_t j = threadIdx.x; j < KD; j += 256) acc += (double)w[j] * (double)mean[j];
   __shared__ double red[256];
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -84,12 +93,11 @@ __global__ __launch_bounds__(256) void project_consts_kernel(const float* __rest
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) cproj[(size_t)k * P + p] = (float)red[0];
+  if (threadIdx.x == 0) wmu[p] = (float)red[0];
 }
 
-int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* mean, const float* centres, int P, int K, int D,
-                             float* cproj) {
-  hipLaunchKernelGGL(project_consts_kernel, dim3(P, K + 1), dim3(256), 0, ctx->stream, comps, mean, centres, P, K, D, cproj);
+int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* mean, int P, int64_t KD, float* wmu) {
+  hipLaunchKernelGGL(project_consts_kernel, dim3(P), dim3(256), 0, ctx->stream, comps, mean, P, KD, wmu);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -98,10 +106,10 @@ int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* 
 // Workgroup = (256 output columns, image); 8 waves, wave w owns columns [32 w, 32 w + 32) for up to 64 segments (two
 // 32x32 accumulators).  The image's projected tokens are walked cluster by cluster in tiles of 32 rows staged through
 // LDS (coalesced 16-B loads); MFMA 32x32x2 f32 with A = the segment's weight a_sk where its column-mask bit is set, else 0,
-// B = z.  The centre / mean terms are folded in as K + 1 "virtual tokens" (the rows of cproj) with weights -a_sk n_sk / -1.
+// B = z.  The mean term W mu and the whitening scale are applied in the epilogue.
 constexpr int PJ_T = 32;
 
-__global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __restrict__ Z, const float* __restrict__ cproj,
+__global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __restrict__ Z, const float* __restrict__ wmu,
                                                                 const float* __restrict__ bn, const float* __restrict__ gscale,
                                                                 const uint64_t* __restrict__ colmask,
                                                                 const int32_t* __restrict__ lab_off,
@@ -111,8 +119,7 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int KS = K + 1;                                            // row stride of ag / coef: conflict-free column reads
   float* ag = reinterpret_cast<float*>(smem);                      // [64][KS]  a_sk = g_s / ||V_sk||   (0 for empty blocks)
-  float* coef = ag + 64 * KS;                                      // [64][KS]  a_sk * n_sk
-  float* zt = coef + 64 * KS;                                      // [PJ_T][256] staged rows
+  float* zt = ag + 64 * KS;                                        // [PJ_T][256] staged rows
   uint64_t* mk = reinterpret_cast<uint64_t*>(zt + PJ_T * 256);     // [PJ_T] column masks of the staged tokens
   const int b = blockIdx.y, p0 = blockIdx.x * 256;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
 
   for (int sc = 0; sc < SCb; ++sc) {
     const int Sc = min(64, S - 64 * sc);
-    __syncthreads();   // the previous chunk's readers of ag / coef are done
+    __syncthreads();   // the previous chunk's readers of ag are done
     for (int idx = tid; idx < 64 * K; idx += 512) {
       const int s = idx / K, k = idx - s * K;
       float a = 0.f;
@@ -134,15 +141,6 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
       ag[s * KS + k] = a;
     }
     __syncthreads();
-    {  // n_sk = number of cluster-k tokens covered by segment s; thread (s, part) walks clusters part, part + 8, ...
-      const int s = tid & 63;
-      for (int k = tid >> 6; k < K; k += 8) {
-        int cnt = 0;
-        for (int j = lo[k]; j < lo[k + 1]; ++j) cnt += (int)((colmask[((size_t)b * N + j) * SC + sc] >> s) & 1ull);
-        coef[s * KS + k] = ag[s * KS + k] * (float)cnt;
-      }
-    }
-    __syncthreads();
     f32x16 acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -150,9 +148,8 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
       for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     const bool two = Sc > 32;
 
-    // one staged tile of nt <= 32 rows starting at src (row stride P); weights: token tiles use masks + ag[.][k],
-    // virtual tiles use -coef[.][row] / -1
-    auto stage = [&](const float* src, int nt, const uint64_t* msrc /*null: virtual rows*/) {
+    // one staged tile of nt <= 32 rows starting at src (row stride P) and the column masks of its tokens
+    auto stage = [&](const float* src, int nt, const uint64_t* msrc) {
       __syncthreads();   // previous tile consumed
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
         if (row < nt && p0 + 4 * c4 < P) v = *reinterpret_cast<const float4*>(src + (size_t)row * P + p0 + 4 * c4);
         *reinterpret_cast<float4*>(zt + row * 256 + 4 * c4) = v;
       }
-      if (tid < PJ_T) mk[tid] = (msrc != nullptr && tid < nt) ? msrc[(size_t)tid * SC] : 0ull;
+      if (tid < PJ_T) mk[tid] = tid < nt ? msrc[(size_t)tid * SC] : 0ull;
       __syncthreads();
     };
 
@@ -185,48 +182,32 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
         }
       }
     }
-    // virtual tokens: rows 0..K-1 of cproj with weights -a_sk n_sk, row K (W mu) with weight -1 for every segment
-    for (int r0 = 0; r0 <= K; r0 += PJ_T) {
-      const int nt = min(PJ_T, K + 1 - r0);
-      stage(cproj + (size_t)r0 * P, nt, nullptr);
-      for (int pr = 0; 2 * pr < nt; ++pr) {
-        const int j = 2 * pr + kk, row = r0 + j;
-        const float bv = (j < nt) ? zt[j * 256 + 32 * w + i] : 0.f;
-        float a0 = 0.f, a1 = 0.f;
-        if (j < nt) {
-          a0 = row < K ? -coef[i * KS + row] : (i < Sc ? -1.f : 0.f);
-          a1 = row < K ? -coef[(32 + i) * KS + row] : (32 + i < Sc ? -1.f : 0.f);
-        }
-        acc[0] = MFMA32(a0, bv, acc[0]);
-        if (two) acc[1] = MFMA32(a1, bv, acc[1]);
-      }
-    }
     if (pcol < P) {
-      const float cs = col_scale ? col_scale[pcol] : 1.f;
+      const float cs = col_scale ? col_scale[pcol] : 1.f, mu = wmu[pcol];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         if (mt == 1 && !two) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int s = 32 * mt + pj_frag_row(r, kk);
-          if (s < Sc) Y[(size_t)(s0 + 64 * sc + s) * P + pcol] = acc[mt][r] * cs;
+          if (s < Sc) Y[(size_t)(s0 + 64 * sc + s) * P + pcol] = (acc[mt][r] - mu) * cs;
         }
       }
     }
   }
 }
 
-int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* cproj, const float* block_norms, const float* gscale,
+int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* wmu, const float* block_norms, const float* gscale,
                                 const uint64_t* colmask, const int32_t* lab_off, const int32_t* rowbase, const int32_t* seg_off_dev,
                                 int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y) {
   if (B <= 0 || S_max <= 0) return SEGVLAD_OK;
   if (P % 4) return ctx->fail(SEGVLAD_ERR_ARG, "project_aggregate: P=%d must be a multiple of 4", P);
-  const size_t lds = (size_t)2 * 64 * (K + 1) * 4 + (size_t)PJ_T * 256 * 4 + (size_t)PJ_T * 8;
+  const size_t lds = (size_t)64 * (K + 1) * 4 + (size_t)PJ_T * 256 * 4 + (size_t)PJ_T * 8;
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d needs %zu B of LDS", K, lds);
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(project_aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
-  hipLaunchKernelGGL(project_aggregate_kernel, dim3((P + 255) / 256, B), dim3(512), lds, ctx->stream, Z, cproj, block_norms, gscale,
+  hipLaunchKernelGGL(project_aggregate_kernel, dim3((P + 255) / 256, B), dim3(512), lds, ctx->stream, Z, wmu, block_norms, gscale,
                      colmask, lab_off, rowbase, seg_off_dev, N, K, P, SC, col_scale, Y);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;

@@ -816,6 +816,29 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
 //   (|v| <= 1 by construction, which is what makes the scale known in advance).
 typedef const __attribute__((address_space(1))) void* agg_gptr_t;
 typedef __attribute__((address_space(3))) void* agg_lptr_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Raw LDS reads for the loops that keep global->LDS DMAs in flight.  The compiler cannot tell the DMA'd queue slots from
+// any other LDS address, so before every LDS load IT emits it waits for all outstanding DMAs (s_waitcnt vmcnt(0)) -- which
+// turns a queue of QD loads in flight into one round trip per step.  Reads issued from inline asm are invisible to that
+// pass; the counted s_waitcnt in the loop is then the only wait.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(agg_lptr_t)p; }
+// one step's operands: the queue slot (16 B), 1/||x|| and the column mask of the lane's token
+__device__ __forceinline__ void lds_step_read(unsigned a_slot, unsigned a_rn, unsigned a_m, f32x4& x, float& rn, uint64_t& m) {
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(x), "=&v"(rn), "=&v"(m)
+               : "v"(a_slot), "v"(a_rn), "v"(a_m)
+               : "memory");
+}
+__device__ __forceinline__ int lds_read_i32(unsigned a) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ f32x4 lds_read_f32x4(unsigned a) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+  return v;
+}
 __device__ unsigned long long sv_agg_phase_cycles[8];   // ABL == 9: s_memtime phase sums of wave 0 (SEGVLAD_AGG_ABL=9 prints)
 #define SV_APHASE(k)                                                              \
   if (ABL == 9) {                                                                 \
@@ -824,13 +847,10 @@ __device__ unsigned long long sv_agg_phase_cycles[8];   // ABL == 9: s_memtime p
     phase_t0 = now_;                                                              \
   }
 
-// MODE 0: the normalised fp32 descriptor blocks go to `out`.  MODE 1 ("planes"): additionally / instead the two fp16 planes
-// (v - mean) * xscale = h1 + h2 of the descriptor, in the blocked layout the projection GEMM reads.  MODE 2 ("project then
-// aggregate"): nothing of the descriptor is stored -- only its block norms -- and the kernel emits the fp16 planes of the
-// NORMALISED TOKENS x^ * xscale, rows grouped by cluster across the batch (rowbase[b][k] = first row of image b's cluster-k
-// tokens): the projection then runs per token with its cluster's slice of the components (half the flops of projecting the
-// K*D-wide descriptor) and the segments are aggregated in the projected space (project_kernels.hip).
-template <int MODE, int ABL = 0>   // ABL: timing ablations (SEGVLAD_AGG_ABL; wrong results)
+// PLANES: additionally / instead of the fp32 blocks, the two fp16 planes (v - mean) * xscale = h1 + h2 of the descriptor, in the
+// blocked layout the projection GEMM reads (the "planes" form of segvlad_images_pca; its "project" form uses
+// token_norms_kernel below instead of this kernel).
+template <bool PLANES, int ABL = 0>   // ABL: timing ablations (SEGVLAD_AGG_ABL; wrong results)
 __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
                                                         const int32_t* __restrict__ tok_order,
                                                         const int32_t* __restrict__ lab_off,
@@ -840,8 +860,7 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
                                                         int Ncap, float* __restrict__ out,
                                                         float* __restrict__ block_norms, const float* __restrict__ mean,
                                                         float xscale, _Float16* __restrict__ h1, _Float16* __restrict__ h2,
-                                                        int kpb, const int32_t* __restrict__ rowbase) {
-  constexpr bool PLANES = MODE == 1;
+                                                        int kpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -906,7 +925,7 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
     {
       unsigned char* qbase = xq + (size_t)__builtin_amdgcn_readfirstlane(w) * (QD * 1024);   // wave-uniform: lives in M0
       auto issue = [&](int p) {
-        const int t = tokl[2 * p + kk];
+        const int t = lds_read_i32(lds_addr(tokl + 2 * p + kk));
         // lanes beyond D (a partial last wave) fetch a valid dummy address: their 16 B are never used
         const float* src = dvalid ? Xb + (size_t)t * D : Xt;
         __builtin_amdgcn_global_load_lds((agg_gptr_t)src, (agg_lptr_t)(qbase + (p % QD) * 1024), 16, 0, 0);
@@ -915,8 +934,6 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
         for (int q = 0; q < QD && q < npairs; ++q) issue(q);
       for (int p = 0; p < npairs; ++p) {
         const int j = 2 * p + kk;
-        const float rn = rnl[j];
-        const uint64_t m = mskl[j];
         const int rem = npairs - 1 - p;   // DMAs issued after pair p's
         if (rem >= QD - 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (rem == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -924,24 +941,13 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
         else if (rem == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float4 x = *reinterpret_cast<const float4*>(qbase + (p % QD) * 1024 + l * 16);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is read before it is refilled
+        f32x4 x;
+        float rn;
+        uint64_t m;
+        lds_step_read(lds_addr(qbase + (p % QD) * 1024 + l * 16), lds_addr(rnl + j), lds_addr(mskl + j), x, rn, m);
+        // (the slot has been read -- lgkmcnt(0) inside -- before it is refilled)
         if (ABL != 1 && p + QD < npairs) issue(p + QD);
-        if (!dvalid || ABL == 1) x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 2 && sc == 0 && dvalid && j < n) {   // the normalised token's fp16 planes, grouped row rowbase + j
-          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-          const float s_ = rn * xscale;
-          const float f[4] = {x.x * s_, x.y * s_, x.z * s_, x.w * s_};
-          h4 p1, p2;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            p1[e] = (_Float16)f[e];
-            p2[e] = (_Float16)(f[e] - (float)p1[e]);
-          }
-          const size_t ob = sv_x3_off((int64_t)rowbase[(size_t)b * K + k] + j, dcol, D);
-          *reinterpret_cast<h4*>(h1 + ob) = p1;
-          *reinterpret_cast<h4*>(h2 + ob) = p2;
-        }
+        if (!dvalid || ABL == 1) x = f32x4{0.f, 0.f, 0.f, 0.f};
         const float b0 = fmaf(x.x, rn, -c4.x), b1 = fmaf(x.y, rn, -c4.y);
         const float b2 = fmaf(x.z, rn, -c4.z), b3 = fmaf(x.w, rn, -c4.w);
         const float a0 = ((m >> i) & 1ull) ? 1.f : 0.f;
@@ -993,7 +999,7 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
     SV_APHASE(7)  // row sums
     __syncthreads();
     SV_APHASE(2)  // barrier
-    if (MODE != 2 && dvalid) {
+    if (dvalid) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         if (mt == 1 && !two) break;
@@ -1029,11 +1035,226 @@ __global__ __launch_bounds__(768) void aggregate_kernel(const float* __restrict_
   }
 }
 
+// ---- block norms + grouped token planes ("project then aggregate", project_kernels.hip) -------------------------------------
+// What segvlad_images_pca needs from the D-space when the projection runs per token: the block norms ||V_sk|| and the fp16
+// planes of the token residuals x^_t - C_k(t), grouped by cluster.  No descriptor is stored, so nothing forces the workgroup-wide
+// geometry of aggregate_kernel (12 waves side by side over D, two barriers per cluster): here ONE WAVE owns a whole
+// (image, cluster) task and walks D in 128-column chunks, tokens streaming through a wave-private DMA queue that never
+// drains between chunks; squared sums stay in registers until the task ends.  No barrier anywhere.
+constexpr int TNK_QD = 8, TNK_LCAP = 256, TNK_WAVES = 4;
+
+// s_waitcnt vmcnt(n), n in 0 .. 23.  vmcnt counts loads AND stores on gfx9 and both retire in issue order, so the plane
+// stores between two DMAs are part of the count: "DMA f has landed" = "at most (DMAs + stores issued after it) outstanding".
+__device__ __forceinline__ void tnk_wait_vm(int n) {
+#define TNK_W(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
+  switch (n) {
+    TNK_W(0) TNK_W(1) TNK_W(2) TNK_W(3) TNK_W(4) TNK_W(5) TNK_W(6) TNK_W(7) TNK_W(8) TNK_W(9) TNK_W(10) TNK_W(11)
+    TNK_W(12) TNK_W(13) TNK_W(14) TNK_W(15) TNK_W(16) TNK_W(17) TNK_W(18) TNK_W(19) TNK_W(20) TNK_W(21) TNK_W(22)
+    default: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+  }
+#undef TNK_W
+}
+
+template <bool BIG>   // BIG: the (rare) clusters with >= TNK_LCAP tokens of one image, lists read from global memory step by step
+__global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
+                                                                    const int32_t* __restrict__ tok_order,
+                                                                    const int32_t* __restrict__ lab_off,
+                                                                    const uint64_t* __restrict__ colmask,
+                                                                    const float* __restrict__ C,
+                                                                    const int32_t* __restrict__ seg_off, int N, int D, int K, int SC,
+                                                                    int Dpad, float* __restrict__ block_norms, float xscale,
+                                                                    _Float16* __restrict__ h1, _Float16* __restrict__ h2,
+                                                                    const int32_t* __restrict__ rowbase, int64_t dummy_row) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = (int)blockIdx.x * TNK_WAVES + w;
+  if (k >= K) return;   // (no barriers in this kernel)
+  const size_t wsz = (size_t)TNK_QD * 1024 + (size_t)TNK_LCAP * 16 + (size_t)Dpad * 4;
+  unsigned char* qbase = smem + (size_t)w * wsz;                                  // [QD][1 KiB] DMA queue
+  uint64_t* mskl = reinterpret_cast<uint64_t*>(qbase + TNK_QD * 1024);            // [LCAP]
+  int* tokl = reinterpret_cast<int*>(mskl + TNK_LCAP);                            // [LCAP]
+  float* rnl = reinterpret_cast<float*>(tokl + TNK_LCAP);                         // [LCAP]
+  float* cl = rnl + TNK_LCAP;                                                     // [Dpad] centre k
+  const int o0 = lab_off[(size_t)b * (K + 1) + k];
+  const int n = lab_off[(size_t)b * (K + 1) + k + 1] - o0;
+  const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
+  const int SCb = (S + 63) >> 6;
+  const int npairs = (n + 1) >> 1;
+  const int nd = Dpad >> 7, total = nd * npairs;
+  const size_t tb = (size_t)b * N + o0;
+  if ((n >= TNK_LCAP) != BIG) return;   // the other instantiation's task
+  if (n == 0) {   // an empty cluster: zero norms, no rows
+    for (int s = l; s < S; s += 64) block_norms[(size_t)(s0 + s) * K + k] = 0.f;
+    return;
+  }
+  for (int d = 4 * l; d < Dpad; d += 256)
+    *reinterpret_cast<float4*>(cl + d) = d < D ? *reinterpret_cast<const float4*>(C + (size_t)k * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr bool single = !BIG;   // the token list fits the wave's LDS lists
+  if (single) {
+    for (int j = l; j < n; j += 64) {
+      tokl[j] = tok_order[tb + j];
+      rnl[j] = rnorm[tb + j];
+    }
+    if (l == 0 && (n & 1)) {
+      tokl[n] = 0;
+      rnl[n] = 0.f;
+    }
+  }
+  const int64_t grow0 = rowbase[(size_t)b * K + k];
+  const float* Xb = Xt + (size_t)b * N * D;
+
+  for (int sc = 0; sc < SCb; ++sc) {
+    if (single) {
+      for (int j = l; j < n; j += 64) mskl[j] = colmask[(tb + j) * SC + sc];
+      if (l == 0 && (n & 1)) mskl[n] = 0;
+    }
+    const int Sc = min(64, S - 64 * sc);
+    const bool two = Sc > 32;
+    f32x16 acc[2][4];
+    float nsq[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        nsq[a][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][q][r] = 0.f;
+      }
+    // step f = (chunk dc, pair p), dc-major; the DMA of step f + QD is issued when step f's slot has been read
+    int idc = 0, ip = 0, fi = 0;   // issue cursor
+    auto issue = [&]() {
+      const int j = 2 * ip + kk;
+      const int t = single ? lds_read_i32(lds_addr(tokl + j)) : (j < n ? tok_order[tb + j] : 0);
+      const int dcol = idc * 128 + 4 * i;
+      const float* src = dcol < D ? Xb + (size_t)t * D + dcol : Xt;   // lanes beyond D fetch a valid dummy address
+      __builtin_amdgcn_global_load_lds((agg_gptr_t)src, (agg_lptr_t)(qbase + (fi % TNK_QD) * 1024), 16, 0, 0);
+      ++fi;
+      if (++ip == npairs) {
+        ip = 0;
+        ++idc;
+      }
+    };
+    for (int q = 0; q < TNK_QD && q < total; ++q) issue();
+    int f = 0;
+    for (int dc = 0; dc < nd; ++dc) {
+      const int dcol = dc * 128 + 4 * i;
+      const bool dvalid = dcol < D;
+      const f32x4 c4 = lds_read_f32x4(lds_addr(cl + dcol));
+      for (int p = 0; p < npairs; ++p, ++f) {
+        const int j = 2 * p + kk;
+        float rn = 0.f;
+        uint64_t m = 0ull;
+        f32x4 x;
+        if (!single) {
+          rn = j < n ? rnorm[tb + j] : 0.f;
+          m = j < n ? colmask[(tb + j) * SC + sc] : 0ull;
+        }
+        // ops issued after step f's DMA: min(QD - 1, rem) later DMAs and, on the first segment chunk, two plane stores for
+        // each of the last min(QD, f) steps (always issued: lanes without a valid element write the dummy row)
+        const int rem = total - 1 - f;
+        if (single && dummy_row >= 0)
+          tnk_wait_vm((rem < TNK_QD - 1 ? rem : TNK_QD - 1) + (sc == 0 ? 2 * (f < TNK_QD ? f : TNK_QD) : 0));
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // list entries come from global memory on this path
+        if (single)
+          lds_step_read(lds_addr(qbase + (f % TNK_QD) * 1024 + l * 16), lds_addr(rnl + j), lds_addr(mskl + j), x, rn, m);
+        else
+          x = lds_read_f32x4(lds_addr(qbase + (f % TNK_QD) * 1024 + l * 16));
+        // (the slot has been read -- lgkmcnt(0) inside -- before it is refilled)
+        if (fi < total) issue();
+        if (!dvalid) x = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float b0 = fmaf(x.x, rn, -c4.x), b1 = fmaf(x.y, rn, -c4.y);
+        const float b2 = fmaf(x.z, rn, -c4.z), b3 = fmaf(x.w, rn, -c4.w);
+        if (sc == 0) {   // the residual's fp16 planes, grouped row grow0 + j
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          const float fv[4] = {b0 * xscale, b1 * xscale, b2 * xscale, b3 * xscale};
+          h4 p1, p2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p1[e] = (_Float16)fv[e];
+            p2[e] = (_Float16)(fv[e] - (float)p1[e]);
+          }
+          const bool real = dvalid && j < n;
+          const size_t ob = real ? sv_x3_off(grow0 + j, dcol, D) : sv_x3_off(dummy_row < 0 ? -dummy_row : dummy_row, (4 * i) % D, D);
+          *reinterpret_cast<h4*>(h1 + ob) = p1;
+          *reinterpret_cast<h4*>(h2 + ob) = p2;
+        }
+        const float a0 = ((m >> i) & 1ull) ? 1.f : 0.f;
+        acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+        acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+        acc[0][2] = MFMA32(a0, b2, acc[0][2]);
+        acc[0][3] = MFMA32(a0, b3, acc[0][3]);
+        if (two) {
+          const float a1 = ((m >> (32 + i)) & 1ull) ? 1.f : 0.f;
+          acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+          acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+          acc[1][2] = MFMA32(a1, b2, acc[1][2]);
+          acc[1][3] = MFMA32(a1, b3, acc[1][3]);
+        }
+      }
+      // this chunk's 128 columns of every block row: square, add, restart the accumulators
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !two) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float q2 = nsq[mt][r];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            q2 = fmaf(acc[mt][q][r], acc[mt][q][r], q2);
+            acc[mt][q][r] = 0.f;
+          }
+          nsq[mt][r] = q2;
+        }
+      }
+    }
+    // row sums over the 32 lanes of each half-wave (DPP inside the 16-lane rows, one cross-row exchange)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (mt == 1 && !two) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = nsq[mt][r];
+        p += dpp_f32<0xB1>(p);
+        p += dpp_f32<0x4E>(p);
+        p += dpp_f32<0x141>(p);
+        p += dpp_f32<0x140>(p);
+        p += __shfl_xor(p, 16);
+        const int row = 32 * mt + frag_row(r, kk);
+        if (i == 0 && row < Sc) block_norms[(size_t)(s0 + 64 * sc + row) * K + k] = sqrtf(p);
+      }
+    }
+  }
+}
+
+int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* colmask, const float* centres, int K, int D,
+                          const int32_t* seg_off_dev, int B, int N, int SC, float* block_norms, float xscale, uint16_t* h1,
+                          uint16_t* h2, const int32_t* rowbase, int64_t dummy_row) {
+  if (D % 4) return ctx->fail(SEGVLAD_ERR_ARG, "token_norms: D=%d must be a multiple of 4", D);
+  const int Dpad = (D + 127) & ~127;
+  const size_t lds = (size_t)TNK_WAVES * ((size_t)TNK_QD * 1024 + (size_t)TNK_LCAP * 16 + (size_t)Dpad * 4);
+  if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "token_norms: D=%d needs %zu B of LDS", D, lds);
+  for (int big = 0; big < 2; ++big) {
+    if (big && N < TNK_LCAP) break;
+    auto kern = big ? token_norms_kernel<true> : token_norms_kernel<false>;
+    if (lds > 64 * 1024)
+      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((K + TNK_WAVES - 1) / TNK_WAVES, B), dim3(64 * TNK_WAVES), lds, ctx->stream, xt,
+                       ctx->s_rnsorted.as<float>(), ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres,
+                       seg_off_dev, N, D, K, SC, Dpad, block_norms, xscale, reinterpret_cast<_Float16*>(h1),
+                       reinterpret_cast<_Float16*>(h2), rowbase, dummy_row);
+    SV_HIP(hipGetLastError());
+  }
+  return SEGVLAD_OK;
+}
+
 int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm: label-grouped copy from prep*/,
                         const uint8_t* /*labels: grouped by prep*/,
                         const uint64_t* colmask, const float* centres, int K, int D, const int32_t* seg_off_dev,
                         const float* gscale, int B, int N, int SC, float* out, float* block_norms, const float* mean,
-                        float xscale, uint16_t* h1, uint16_t* h2, const int32_t* rowbase) {
+                        float xscale, uint16_t* h1, uint16_t* h2) {
   const int nwaves = (D + 127) / 128;
   if (nwaves > 12)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: D=%d exceeds the 1536-wide workgroup of this build", D);
@@ -1043,15 +1264,14 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
   lds = (lds + 15) & ~(size_t)15;
   lds += (size_t)nwaves * 6 * 1024;   // DMA queue
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "aggregate: N=%d tokens need %zu B of LDS (limit 160 KiB)", N, lds);
-  // rowbase != null: "project then aggregate" (token planes + block norms); else h1 != null: descriptor planes
-  auto kern = (rowbase != nullptr) ? aggregate_kernel<2> : (h1 != nullptr) ? aggregate_kernel<1> : aggregate_kernel<0>;
+  auto kern = (h1 != nullptr) ? aggregate_kernel<true> : aggregate_kernel<false>;
   bool phases = false;
 #ifdef SEGVLAD_ABLATIONS   // timing ablations / phase timing: development builds only
   if (const char* ab = getenv("SEGVLAD_AGG_ABL")) {
-    if (atoi(ab) == 1) kern = aggregate_kernel<0, 1>;
-    if (atoi(ab) == 2) kern = aggregate_kernel<0, 2>;
+    if (atoi(ab) == 1) kern = aggregate_kernel<false, 1>;
+    if (atoi(ab) == 2) kern = aggregate_kernel<false, 2>;
     if (atoi(ab) == 9) {
-      kern = aggregate_kernel<0, 9>;
+      kern = aggregate_kernel<false, 9>;
       phases = true;
       unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       SV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sv_agg_phase_cycles), z, sizeof(z)));
@@ -1066,7 +1286,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
                      ctx->s_tokorder.as<int32_t>(),
                      ctx->s_laboff.as<int32_t>(), colmask, centres, seg_off_dev,
                      gscale, N, D, K, SC, Ncap, out, block_norms, mean, xscale, reinterpret_cast<_Float16*>(h1),
-                     reinterpret_cast<_Float16*>(h2), kpb, rowbase);
+                     reinterpret_cast<_Float16*>(h2), kpb);
   SV_HIP(hipGetLastError());
 #ifdef SEGVLAD_ABLATIONS
   if (phases) {

@@ -648,6 +648,40 @@ def test_pca_f16_split_path_is_fp32_class(eng):
     assert (1 - cos).max() < 5e-7   # fp32 outputs: the cosine itself is only resolved to ~1e-7
 
 
+def test_images_pca_project_form_big_clusters_and_partial_chunk(eng):
+    """The "project then aggregate" form of segvlad_images_pca where its token kernel leaves the common case: a cluster
+    holding >= 256 tokens of one image (lists read from global memory), D = 96 (a partial 128-column chunk), S > 64
+    (two segment chunks) and an image without segments -- against the fp64 oracle and the "planes" form."""
+    D, K, N, P = 96, 8, 40 * 18, 24
+    C = synth().make_vocab(K, D, seed=191)
+    rng = np.random.Generator(np.random.PCG64(192))
+    toks, incs, adjs = [], [], []
+    for b, S in enumerate([70, 0, 9]):
+        toks.append(synth().make_tokens(C[:2] if b == 0 else C, N, seed=1950 + b, noise=0.3))   # b == 0: ~360 tokens per cluster
+        incs.append(rng.random((S, N)) < 0.1)
+        adjs.append(np.eye(S, dtype=bool) | (rng.random((S, S)) < 0.05))
+    mean, comps, var = synth().make_pca_model(K * D, P, seed=19)
+    eng.set_vocab(C)
+    eng.pca_set(mean, comps, var, whiten=True)
+    offs = np.concatenate([[0], np.cumsum([i.shape[0] for i in incs])]).astype(np.int32)
+    bits = np.concatenate([O().pack_bits_u64(i) for i in incs]).view(np.int64)
+    adj = cat_adj(adjs)
+    tk = np.stack(toks)
+    lab = eng.seg_vlad(tk, bits, offs, adj, want_labels=True)["labels"].cpu().numpy()
+    assert np.bincount(lab[0], minlength=K).max() >= 256
+    ref = np.concatenate([O().seg_vlad(toks[b], incs[b], C, adjs[b]) for b in range(3) if incs[b].shape[0]])
+    ref = O().pca_transform(ref, mean, comps, var, True)
+    ys = {}
+    for path in ("project", "planes"):
+        eng.set_option("pca_path", path)
+        try:
+            ys[path] = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=False)["out"].cpu().numpy()
+        finally:
+            eng.set_option("pca_path", "auto")
+        assert np.abs(ys[path] - ref).max() <= 3e-5 * np.abs(ref).max()
+    assert np.abs(ys["project"] - ys["planes"]).max() <= 1e-5 * np.abs(ref).max()
+
+
 # ------------------------------------------------------------------------------------------------
 # fused segment-VLAD -> PCA (segvlad_images_pca): the aggregation kernel emits the projection GEMM's fp16 planes
 # ------------------------------------------------------------------------------------------------

@@ -83,3 +83,34 @@ for path in ("planes", "project"):
     eng.set_profiling(False)
     print(f"{path:8s} B={B}: wall {dt * 1e3:.2f} ms  stages {st}")
 print("batch: project vs planes max abs diff (unit rows):", (outs["project"] - outs["planes"]).abs().max().item())
+
+# determinism / safe-wait comparison of the project path
+eng.set_option("pca_path", "project")
+a = eng.seg_vlad_pca(x, bits, offs, adj, l2norm=False)["out"].clone()
+b2 = eng.seg_vlad_pca(x, bits, offs, adj, l2norm=False)["out"].clone()
+eng.set_option("debug_search", "7")
+c = eng.seg_vlad_pca(x, bits, offs, adj, l2norm=False)["out"].clone()
+eng.set_option("debug_search", "0")
+print("repeat equal:", torch.equal(a, b2), " safe-wait equal:", torch.equal(a, c), " max diff:", (a - c).abs().max().item(),
+      " rows differing:", int(((a != c).any(1)).sum()), "of", a.shape[0])
+
+# identity "PCA": y must equal the descriptor itself -- localises any wrong token / chunk / norm
+K2, D2, N2 = 4, 128, 200
+C2 = synth.make_vocab(K2, D2, seed=77)
+eng.set_vocab(C2)
+I = np.eye(K2 * D2, dtype=np.float32)
+eng.pca_set(np.zeros(K2 * D2, np.float32), I, np.ones(K2 * D2, np.float32), whiten=False)
+rng = np.random.Generator(np.random.PCG64(5))
+tk2, inc2, adj2 = [], [], []
+for b, S2 in enumerate([7, 40, 66, 3]):
+    tk2.append(synth.make_tokens(C2, N2, seed=300 + b, noise=0.3))
+    inc2.append(rng.random((S2, N2)) < 0.2)
+    adj2.append(np.eye(S2, dtype=bool))
+offs2 = np.concatenate([[0], np.cumsum([i.shape[0] for i in inc2])]).astype(np.int32)
+bits2 = np.concatenate([O.pack_bits_u64(i) for i in inc2]).view(np.int64)
+adjc = np.concatenate([a.astype(np.uint8).reshape(-1) for a in adj2])
+for path in ("planes", "project"):
+    eng.set_option("pca_path", path)
+    y = eng.seg_vlad_pca(np.stack(tk2), bits2, offs2, adjc, l2norm=False)["out"].cpu().numpy().astype(np.float64)
+    ref = np.concatenate([O.seg_vlad(tk2[b], inc2[b], C2, adj2[b]) for b in range(4)])
+    print(f"identity PCA {path:8s}: max abs err {np.abs(y - ref).max():.2e}  (|ref| max {np.abs(ref).max():.2f})")
