@@ -396,22 +396,40 @@ def main():
         roof = {"kernel": "segment-VLAD kernels (incidence+assign+prep+aggregate)", "bound": "hbm", "achieved": ach,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None, "dominant_stage": dom}
     # secondary: the HBM-bound VLAD stage, always reported.  With the fused projection the K*D-wide fp32 descriptor
-    # never reaches HBM: the stage writes two fp16 planes of the same size instead (4 S K D bytes either way).
+    # never reaches HBM.  In its "planes" form the stage writes two fp16 planes of the same size instead (4 S K D bytes
+    # either way); in its "project" form (see roofline_pca) it writes the fp16 planes of the token residuals (4 N D) and
+    # the block norms (4 S K).
+    pca_form = None
+    if use_pca:
+        pca_form = "project" if (eng_pca_products(K * D, P) == 3 and D % 32 == 0 and P % 4 == 0 and S * K >= 1.25 * N) else "planes"
     vlad_ms = sum(stages[s]["ms_per_step"] for s in ("incidence", "assign", "prep", "aggregate") if s in stages)
-    bytes_img = 4 * D * N + 4 * S * K * D + S * N / 8 + S * S + S * Hm * Wm
+    out_bytes = 4 * N * D + 4 * S * K if pca_form == "project" else 4 * S * K * D
+    bytes_img = 4 * D * N + out_bytes + S * N / 8 + S * S + S * Hm * Wm
     vlad_roof = {"bound": "hbm", "achieved": bytes_img * nq_local / (vlad_ms * 1e-3) / 1e9 if vlad_ms else None,
                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "alg_bytes_per_image": bytes_img}
     if vlad_roof["achieved"]:
         vlad_roof["frac"] = vlad_roof["achieved"] / PEAK_HBM_GBS
-    agg_traffic, _, agg_src = pmc_counters("aggregate_kernel", wl_key)
+    agg_kernel = "token_norms_kernel" if pca_form == "project" else "aggregate_kernel"
+    agg_traffic, _, agg_src = pmc_counters(agg_kernel, wl_key)
+    vlad_roof["aggregate_kernel"] = agg_kernel
     vlad_roof["aggregate_traffic"] = agg_traffic
     pca_roof = None
     if use_pca and "pca" in stages:
-        pf = 2.0 * nq_local * S * (K * D) * P * eng_pca_products(K * D, P) / (stages["pca"]["ms_per_step"] * 1e-3) / 1e12
+        # The fused call picks the smaller product (api.hip, images_impl): "project" = every token's residual times its
+        # cluster's D x P slice of the components, segments aggregated afterwards in the P-d space (N D P per image);
+        # "planes" = the finished descriptors times the components (S K D P per image).  `achieved` counts the flops
+        # EXECUTED by the chosen form (fp16 products: 3 per multiply); the stage also holds the P-space aggregation /
+        # the row normalisation.
+        prods = eng_pca_products(K * D, P)
+        form = pca_form
+        rows, depth = (nq_local * N, D) if form == "project" else (nq_local * S, K * D)
+        pf = 2.0 * rows * depth * P * prods / (stages["pca"]["ms_per_step"] * 1e-3) / 1e12
         pt, pu, psrc = pmc_counters("gemm_f16x3_kernel", wl_key)
-        pca_roof = {"bound": "mfma", "achieved": pf, "peak": PEAK_16BIT_MFMA_TFLOPS if eng_pca_products(K * D, P) == 3 else PEAK_F32_MFMA_TFLOPS,
+        pca_roof = {"bound": "mfma", "form": form, "achieved": pf,
+                    "peak": PEAK_16BIT_MFMA_TFLOPS if prods == 3 else PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "traffic": pt, "mfma_util": pu, "traffic_source": psrc,
-                    "alg_bytes_per_launch": 2.0 * 2 * (nq_local * S * K * D + P * K * D) + 4.0 * nq_local * S * P}
+                    "flops_vs_descriptor_projection": rows * depth / (nq_local * S * K * D),
+                    "alg_bytes_per_launch": 2.0 * 2 * (rows * depth + P * K * D) + 4.0 * rows * P * (2 if form == "project" else 1)}
         pca_roof["frac"] = pca_roof["achieved"] / pca_roof["peak"]
 
     # secondary: the kNN stage in its HBM-bound regime (B_q <= 50, i.e. ONE query image per pass)

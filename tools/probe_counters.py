@@ -4,7 +4,7 @@ instead of the 600 k torch dispatches of bench.py's synthetic-image factory, und
 round 1):
 
   * knn_f16_filter_kernel ... segvlad_search of 10 000 query segments x 1 M rows x 1024  (NQ, NR, D)
-  * aggregate_kernel<PLANES> + gemm_f16x3_kernel ... segvlad_images_pca of B = 200 images, K = 64, D = 1536, N = 1530,
+  * token_norms_kernel + gemm_f16x3_kernel (grouped) + project_aggregate_kernel ... segvlad_images_pca of B = 200 images, K = 64, D = 1536, N = 1530,
     S = 50, P = 1024 (the fused VLAD -> PCA call of the bench step)
   * one torch.sign over 1 GiB as the byte-count calibration of FETCH_SIZE / WRITE_SIZE (tools/pmc_summary.py)
 
