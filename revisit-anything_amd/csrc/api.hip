@@ -812,7 +812,7 @@ struct SearchPlan {
   int64_t n = 0;
   float c_eps = 0.f, inv_scale = 1.f, rn_max = 0.f;
 };
-constexpr int SV_RATIO = 16, SV_CAP = 8192, SV_RCAP = 512, SV_CHUNK = 4096;
+constexpr int SV_RATIO = 16, SV_CAP = 8192, SV_RCAP = 512, SV_CHUNK = 16384;
 
 // Smallest rank r such that a threshold at the r-th smallest value of a 1/16 sample admits, 4 sigma below its
 // expectation 16 r, still `target` values of the full set (relative spread of the r-th order statistic ~ 1/sqrt(r)).
