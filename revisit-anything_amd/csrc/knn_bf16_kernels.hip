@@ -367,6 +367,19 @@ __device__ unsigned long long sv_f16_phase_cycles[8];
     phase_t0 = now_;                                                                         \
   }
 
+// Accumulator element for the epilogue.  FROM_AGPR (the 128 x 128 wave tiles: 256 accumulator registers per lane, held in
+// AGPRs by the MFMA loop): read through an explicit v_accvgpr_read so that the value STAYS in its AGPR until this use --
+// left to itself the register allocator copies all 256 to VGPRs at the loop exit and spills half of them to scratch.
+template <bool FROM_AGPR>
+__device__ __forceinline__ float acc_elem(const f32x16& v, int r) {
+  if (FROM_AGPR) {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(v[r]));
+    return x;
+  }
+  return v[r];
+}
+
 // POL: cache policy of the operand DMA (never changes a result): bit 0 = database rows (B) non-temporal, bit 1 = queries (A)
 // PP : 0 = every wave runs the k-tile as one segment (one barrier per k-tile); PP > 0 = "ping-pong": the k-tile is cut
 //      into PP phases of [load segment: LDS fragment reads + DMA issue][barrier][MFMA segment][barrier], and the second
@@ -382,6 +395,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   constexpr int NW = WM * WN;
   constexpr int AUXA = (POL & 2) ? 2 : 0, AUXB = (POL & 1) ? 2 : 0;   // aux = 2: "nt" (streaming) hint
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr bool ACC_A = TM * TN > 8;   // 256 accumulator registers per lane: they live in AGPRs (see acc_elem)
   constexpr int RB = HBK * 2;            // row bytes per k-tile
   constexpr int CH = RB / 16;            // 16-B chunks per row (4 or 8)
   constexpr int RP = 1024 / RB;          // rows per 1-KiB DMA piece
@@ -593,6 +607,108 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       ib = (ib + 1 >= NB) ? 0 : ib + 1;
     }
     if (!lag) __builtin_amdgcn_s_barrier();  // the leading half waits for the lagging half's last MFMA segment
+  } else if (PP < 0) {
+    // One wave per SIMD (4 waves of 128 x 128: 0.5 LDS fragment reads per MFMA instead of 0.75): nothing else hides a
+    // wave's LDS latency, so the loop is software-pipelined -- the fragments of k-step s+1 are read (into the other half
+    // of a register double buffer) before the MFMAs of step s are issued, and the ONE barrier of a k-tile sits before
+    // its last MFMA group: every wave has then finished reading the tile's LDS stages (they may be overwritten), the
+    // next tile's operands have landed for every wave, and its first fragments are fetched under that MFMA group.
+    static_assert(PP >= 0 || (KS % 2 == 0 && TM == 4 && TN == 4 && CH == 8), "register double buffer; 128 x 128 wave tiles of 128-B rows");
+    // The fragment reads are raw ds_read_b128 (inline asm) with counted s_waitcnt lgkmcnt: while a global->LDS DMA is
+    // pending the compiler only ever waits with lgkmcnt(0) / vmcnt(0) before an LDS read it can see (it cannot tell the
+    // DMA'd stages from the fragments' addresses), which would serialise the prefetch behind the MFMA group it is meant
+    // to overlap.  The waits below carry the fragment registers as operands so that no MFMA can be scheduled above them.
+    constexpr int DPS = (JA + JB) / KS;   // DMA pieces per k-step and wave
+    f16x8 fa[2][4], fb[2][4];
+    // row ra = fa0 + 32 t: the swizzle term (ra >> 1) & 7 does not depend on t -> one lane address per k-step, t in the
+    // instruction's immediate offset (32 rows x 128 B = 4096)
+    unsigned offa[KS], offb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      offa[ks] = (unsigned)(fa0 * RB + swz(fa0, 2 * ks + kk) * 16);
+      offb[ks] = (unsigned)(fb0 * RB + swz(fb0, 2 * ks + kk) * 16);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+#define SV_RD4(dst, addr)                                                                                      \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\tds_read_b128 %2, %4 offset:8192\n\t" \
+                 "ds_read_b128 %3, %4 offset:12288"                                                            \
+                 : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3])                                  \
+                 : "v"(addr))
+#define SV_RD1(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define SV_WAIT_FRAGS(N, A, B)                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                   \
+                 : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]))
+    {
+      const unsigned aa = lds0 + a_off(ia) + offa[0], ab = lds0 + b_off(ib) + offb[0];
+      SV_RD4(fa[0], aa);
+      SV_RD4(fb[0], ab);
+    }
+    // DMA schedule: the stages of tile kt are free from that tile's barrier on, so the pieces of "slot 0" of the NEXT tile's
+    // quota (its first A pieces) are issued right behind the barrier, one k-step earlier than their tile starts
+    {
+      const int ibn0 = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
+#pragma unroll
+      for (int pz = 0; pz < DPS; ++pz) dma_piece(pz, 0, ia ^ 1, ibn0);
+    }
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
+      const int ib1 = (ib + 1 >= NB) ? 0 : ib + 1;
+      const int ibn1 = (ib1 + BAHEAD >= NB) ? ib1 + BAHEAD - NB : ib1 + BAHEAD;
+      const unsigned SAo = lds0 + a_off(ia), SBo = lds0 + b_off(ib);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        const bool last = ks + 1 == KS;
+        bool fetched = true;
+        unsigned aa, ab;
+        if (!last) {
+          aa = SAo + offa[ks + 1];
+          ab = SBo + offb[ks + 1];
+        } else {
+          // A(kt+1) and B(kt+1) have landed (B(kt+2), the youngest JB DMA instructions, may still fly) and this wave's
+          // reads of tile kt are complete (they were waited for at the top of the previous step ... and below)
+          if (NB == 3 && kt + 2 < ntiles)
+            wait_vm_lgkm0<JB>();
+          else
+            wait_vm_lgkm0<0>();
+          __builtin_amdgcn_s_barrier();
+          fetched = kt + 1 < ntiles;
+          aa = lds0 + a_off(ia ^ 1) + offa[0];
+          ab = lds0 + b_off(ib1) + offb[0];
+        }
+        // this step's fragments were requested under the previous MFMA group
+        SV_WAIT_FRAGS(0, fa[cur], fb[cur]);
+        __builtin_amdgcn_sched_barrier(0);
+        // 16 MFMAs; the next step's 8 fragment reads and this step's DMA pieces are issued in the gaps between them (the
+        // matrix pipe takes a new MFMA every 32 cycles: a lone wave that issues its loads in a block leaves it idle)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int mt = j >> 2, nt = j & 3;
+          acc[mt][nt] = MFMA_F16(fa[cur][mt], fb[cur][nt], acc[mt][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (fetched) {
+            if (j == 0) SV_RD1(fa[nxt][0], aa, 0);
+            if (j == 1) SV_RD1(fa[nxt][1], aa, 4096);
+            if (j == 2) SV_RD1(fa[nxt][2], aa, 8192);
+            if (j == 3) SV_RD1(fa[nxt][3], aa, 12288);
+            if (j == 4) SV_RD1(fb[nxt][0], ab, 0);
+            if (j == 5) SV_RD1(fb[nxt][1], ab, 4096);
+            if (j == 6) SV_RD1(fb[nxt][2], ab, 8192);
+            if (j == 7) SV_RD1(fb[nxt][3], ab, 12288);
+          }
+          if (j >= 8 && j < 8 + DPS) {
+            if (!last) dma_piece((ks + 1) * DPS + (j - 8), kt, ia ^ 1, ibn);
+            else if (fetched) dma_piece(j - 8, kt + 1, ia, ibn1);   // A(kt+2) -> tile kt's A stage (free since the barrier)
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      ia ^= 1;
+      ib = ib1;
+    }
+#undef SV_RD1
+#undef SV_RD4
+#undef SV_WAIT_FRAGS
   } else {
   for (int kt = 0; kt < ntiles; ++kt) {
       const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
@@ -713,22 +829,35 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // this lane's 16 * TM screening bounds, fetched up front with 16-B reads (accumulator element r of tile mt belongs to
   // row mt*32 + 8*(r>>2) + 4*kk + (r&3): four consecutive rows per (mt, r>>2)) -- a per-iteration LDS read put ~100
   // cycles of latency into each of the 32 screening steps (two waves per SIMD cannot hide it)
-  float4 tq[TM][4];
+  // (TM > 2 -- the 128 x 128 wave tiles -- fetches them per 32-row tile instead: 64 registers would not fit)
+  constexpr bool TQ_UPFRONT = TM <= 2;
+  float4 tq[TQ_UPFRONT ? TM : 1][4];
+  if (TQ_UPFRONT) {
 #pragma unroll
-  for (int mt = 0; mt < TM; ++mt)
+    for (int mt = 0; mt < (TQ_UPFRONT ? TM : 1); ++mt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      tq[mt][g] = *reinterpret_cast<const float4*>(taul + wm * (32 * TM) + mt * 32 + 8 * g + 4 * kk);
+      for (int g = 0; g < 4; ++g)
+        tq[mt][g] = *reinterpret_cast<const float4*>(taul + wm * (32 * TM) + mt * 32 + 8 * g + 4 * kk);
+  }
 #pragma unroll
-  for (int mt = 0; mt < TM; ++mt)
+  for (int mt = 0; mt < TM; ++mt) {
+    if (!TQ_UPFRONT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        tq[0][g] = *reinterpret_cast<const float4*>(taul + wm * (32 * TM) + mt * 32 + 8 * g + 4 * kk);
+      __builtin_amdgcn_sched_barrier(0);   // one tile's bounds at a time
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const uint32_t lrow16 = (uint32_t)(wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) << 16;
-      const float4 tq4 = tq[mt][r >> 2];
+      const float4 tq4 = tq[TQ_UPFRONT ? mt : 0][r >> 2];
       const float tau = (r & 3) == 0 ? tq4.x : (r & 3) == 1 ? tq4.y : (r & 3) == 2 ? tq4.z : tq4.w;
-      float dd[TN];
+      float av[TN], dd[TN];
 #pragma unroll
-      for (int nt = 0; nt < TN; ++nt) dd[nt] = acc[mt][nt][r] - cnh[nt];
+      for (int nt = 0; nt < TN; ++nt) {
+        av[nt] = acc_elem<ACC_A>(acc[mt][nt], r);
+        dd[nt] = av[nt] - cnh[nt];
+      }
       float best = dd[0];
 #pragma unroll
       for (int nt = 1; nt < TN; ++nt) best = fmaxf(best, dd[nt]);
@@ -742,12 +871,13 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
             uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
             pos = pos < (uint32_t)LCAP ? pos : (uint32_t)LCAP;   // beyond the list: the dump slot (the block turns dense below)
             if (hit)
-              wlist[pos] = make_uint2(__float_as_uint(acc[mt][nt][r]), lrow16 | (uint32_t)(wn * (32 * TN) + nt * 32 + i));
+              wlist[pos] = make_uint2(__float_as_uint(av[nt]), lrow16 | (uint32_t)(wn * (32 * TN) + nt * 32 + i));
             wave_cnt += (uint32_t)__popcll(mk);
           }
         }
       }
     }
+  }
   if ((ABL == 9 || ABL == 12) && tid == 0) atomicAdd(&sv_f16_phase_cycles[6], (unsigned long long)dbg_bodies);
   SV_PHASE(3)  // pass 1
   // pass 2a: exact test of this wave's hits, dense (the list is wave-private: no barrier needed before reading it)
@@ -779,7 +909,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
           const float4 rr = rrec[lrow];
-          const float v = sv_d2(rr.x, cn[nt], acc[mt][nt][r] * isc);
+          const float v = sv_d2(rr.x, cn[nt], acc_elem<ACC_A>(acc[mt][nt], r) * isc);
           if (v <= rr.y && v < INFINITY) atomicAdd(&rowcnt[lrow], 1u);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the 32 row-record loads from being hoisted (register pressure)
@@ -819,7 +949,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         for (int nt = 0; nt < TN; ++nt) {
           const float4 rr = rrec[lrow];
           {
-            const float v = sv_d2(rr.x, cn[nt], acc[mt][nt][r] * isc);
+            const float v = sv_d2(rr.x, cn[nt], acc_elem<ACC_A>(acc[mt][nt], r) * isc);
             if (v <= rr.y && v < INFINITY) {
               const uint32_t slot = atomicAdd(&rowcnt[lrow], 1u);
               if (slot < (uint32_t)cap) {
@@ -886,6 +1016,10 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   // tile configuration: option "f16_cfg" (default chosen from measurements)
   // r02 measurements (10 000 x 1 M x 1024, random unit vectors, filter launches only): 0 -> 22.5 ms, 50 (ping-pong) -> 21.7,
   // 200 (persistent) -> 21.7, 250 (persistent + ping-pong) -> 21.5; HBK = 32 variants (4, 1) 24.1 / 25.3
+  // 4 waves of 128 x 128 (a third fewer LDS fragment reads per MFMA; accumulators in AGPRs, epilogue through acc_elem):
+  // 5 (compiler-scheduled loop) -> 21.8 ms, 55 (software-pipelined: reads / DMA issued between the MFMAs, one barrier per
+  // k-tile) -> 21.9, 255 (55 + persistent) -> 22.1, against 20.9-21.1 for 250 in the same sessions: with one wave per SIMD
+  // nothing covers the per-tile barrier and the epilogue, and the kernel sits at the same power-limited clock either way.
   // streaming regime (M <= 128, e.g. one 50-segment query image per pass over 1 M rows): 2 -> 0.41 ms, 3 -> 0.51 ms
   const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : 2);
   switch (c) {
@@ -934,8 +1068,14 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
     case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB
     case 5: return launch_f16_filter<256, 256, 2, 2, 64, 3>(SV_F16_ARGS);  // 4 waves of 128 x 128: 0.5 LDS fragment / MFMA
+    case 55: return launch_f16_filter<256, 256, 2, 2, 64, 3, 0, false, 0, -1>(SV_F16_ARGS);  // + software-pipelined loop
+    case 255:
+      if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
+        return launch_f16_filter<256, 256, 2, 2, 64, 3, 0, true, 0, -1>(SV_F16_ARGS);       // + persistent
+      return launch_f16_filter<256, 256, 2, 2, 64, 3, 0, false, 0, -1>(SV_F16_ARGS);
 #ifdef SEGVLAD_ABLATIONS
     case 15: return launch_f16_filter<256, 256, 2, 2, 64, 3, 1>(SV_F16_ARGS);
+    case 155: return launch_f16_filter<256, 256, 2, 2, 64, 3, 1, false, 0, -1>(SV_F16_ARGS);
 #endif
     case 6: return launch_f16_filter<256, 256, 2, 2, 32, 3>(SV_F16_ARGS);
     case 7: return launch_f16_filter<256, 128, 4, 1, 32, 3>(SV_F16_ARGS);  // 56 KiB, 4 waves: 2 independent workgroups / CU
