@@ -77,8 +77,12 @@ int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm
  *      seg_offsets [B+1] int32 HOST, order >= 1.  adj_out: concatenated per-image [S_b][S_b] byte
  *      matrices = (A1^order > 0), A1 = Delaunay neighbours + self loop; images with S_b <= 3 get the
  *      reference's special rows e0(+e1).  Computed on the device (empty-circle test per point pair;
- *      identical to Qhull for points in general position).  n_empty_out (HOST, may be NULL): number of
- *      NaN centroids (= empty masks, for which the reference raises ValueError); passing it synchronises. */
+ *      identical to Qhull for points in general position).  n_empty_out (HOST, may be NULL; passing it
+ *      synchronises): low 16 bits = number of NaN centroids (= empty masks, for which the reference raises
+ *      ValueError); bits 16.. = number of images holding a NON-GENERIC configuration (a duplicate centroid, or
+ *      four exactly co-circular centroids with an empty circle), where the Delaunay triangulation is not unique
+ *      and Qhull's choice cannot be reproduced: callers that need the reference's result bit for bit recompute
+ *      such batches with Qhull (pipeline.py does). */
 int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
                       uint8_t* adj_out, uint32_t* n_empty_out);
 

@@ -292,8 +292,10 @@ int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
 // on the left of u->v excludes t > tau_p, a point on the right excludes t < tau_p, with
 //     tau_p = ((p-u).(p-v)) / cross(v-u, p-u)            (a cotangent of the angle u-p-v).
 // So the edge exists iff max_{right} tau <= min_{left} tau, and a point strictly inside the segment
-// blocks it.  O(S) per pair, fp64.  Generic inputs give exactly Qhull's triangulation; exactly
-// co-circular quadruples (where the triangulation is not unique) keep both diagonals.
+// blocks it.  O(S) per pair, fp64.  Generic inputs give exactly Qhull's triangulation.  Non-generic inputs -- exactly
+// co-circular quadruples (max_right tau == min_left tau: the triangulation is not unique, both diagonals are kept here,
+// Qhull picks one) and duplicate centroids (Qhull drops the coplanar duplicate) -- are COUNTED: every image that holds
+// one adds 65536 to *n_bad, so that the caller can route the batch through the reference's own Qhull path.
 // S <= 3 reproduces the reference's special case: every row = e0 (+ e1).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict__ cent,
@@ -318,6 +320,8 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
     if (px[s] != px[s] && n_bad) atomicAdd(n_bad, 1u);  // NaN centroid = empty mask (reference: ValueError)
   }
   for (int j = tid; j < S * SW; j += 256) A1[j] = 0;
+  __shared__ int degenerate;
+  if (tid == 0) degenerate = 0;
   __syncthreads();
   if (S <= 3) {
     for (int j = tid; j < S * S; j += 256) {
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
     if (u > v) continue;
     const double ux = px[u], uy = py[u], vx = px[v], vy = py[v];
     const double ex = vx - ux, ey = vy - uy;
+    if (ex == 0.0 && ey == 0.0) degenerate = 1;   // duplicate centroid
     double tmin = INFINITY, tmax = -INFINITY;
     bool blocked = false;
     for (int p = 0; p < S; ++p) {
@@ -351,12 +356,14 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
         blocked = true;
       }
     }
+    if (!blocked && tmax == tmin) degenerate = 1;   // an empty circle through four points: either diagonal is Delaunay
     if (!blocked && tmax <= tmin) {
       atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (v >> 6)]), 1ull << (v & 63));
       atomicOr(reinterpret_cast<unsigned long long*>(&A1[v * SW + (u >> 6)]), 1ull << (u & 63));
     }
   }
   __syncthreads();
+  if (tid == 0 && degenerate && n_bad) atomicAdd(n_bad, 65536u);
   for (int j = tid; j < S * SW; j += 256) P[j] = A1[j];
   __syncthreads();
   for (int it = 1; it < order; ++it) {  // P <- (P . A1) > 0

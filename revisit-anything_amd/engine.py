@@ -159,7 +159,9 @@ class SegVLADEngine:
     def adjacency(self, centroids, seg_offsets, order: int, check_empty: bool = False) -> torch.Tensor:
         """centroids [S_tot,2] fp64 -> uint8 buffer with the concatenated per-image [S_b,S_b] (A1^order > 0)
         blocks, computed on the device.  check_empty=True synchronises and raises ValueError on an empty mask
-        (the reference's behaviour)."""
+        (the reference's behaviour), and SegVLADError("... degenerate ...") when an image holds a non-generic centroid
+        configuration (duplicate or exactly co-circular points: Qhull's triangulation is then a matter of its own
+        tie-breaking; SegVLADPipeline catches this and uses the reference's Qhull path for that batch)."""
         c = _as(centroids, np.float64, torch.float64)
         so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
         B = len(so) - 1
@@ -170,8 +172,11 @@ class SegVLADEngine:
         self._check(self.lib.segvlad_adjacency(self._h, _ptr(c), _ptr(so), B, int(order), _ptr(out),
                                                C.cast(n_bad, C.c_void_p) if check_empty else None), "adjacency")
         self._keep = [c]
-        if check_empty and n_bad[0]:
-            raise ValueError(f"{n_bad[0]} empty mask(s): centroid undefined")
+        if check_empty and n_bad[0] & 0xFFFF:
+            raise ValueError(f"{n_bad[0] & 0xFFFF} empty mask(s): centroid undefined")
+        if check_empty and n_bad[0] >> 16:
+            raise SegVLADError(f"adjacency: {n_bad[0] >> 16} image(s) with a degenerate centroid configuration "
+                               "(duplicate or co-circular centroids): the Delaunay triangulation is not unique")
         return out
 
     # ---- segment VLAD -----------------------------------------------------------------------------

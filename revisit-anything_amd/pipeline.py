@@ -71,9 +71,11 @@ class SegVLADPipeline:
                 try:
                     adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
                 except SegVLADError as e:
-                    if "LDS budget" not in str(e):
+                    if "LDS budget" not in str(e) and "degenerate" not in str(e):
                         raise
-                    # an image with more segments (~620) than the in-LDS Delaunay holds: the reference's own Qhull path
+                    # an image with more segments (~620) than the in-LDS Delaunay holds, or a non-generic centroid
+                    # configuration (duplicate / exactly co-circular centroids, where the triangulation is Qhull's
+                    # tie-breaking): the reference's own Qhull path for this batch
                     adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
         else:
             bits = eng.incidence(masks, self.H, self.W, self.patch)

@@ -115,6 +115,23 @@ def image_to_tokens(img_rgb: np.ndarray, extractor, cfg: Optional[dict] = None, 
     return torch.nn.functional.normalize(feat, dim=1) if normalize else feat
 
 
+def process_single_DINO(cfg: dict, img_bgr: np.ndarray, extractor) -> tuple:
+    """func_vpr.py:549-562: BGR -> RGB, resize when cfg['resize'], value-facet tokens L2-normalised over channels;
+    returns (the processed RGB image, float32 ``[1, D, h, w]``)."""
+    img = np.ascontiguousarray(np.asarray(img_bgr)[:, :, ::-1])
+    img_p = resize_like_cv2(img, cfg["desired_width"], cfg["desired_height"]) if cfg.get("resize") else img
+    return img_p, image_to_tokens(img_p, extractor, None, normalize=True)
+
+
+def dino_given_image(extractor, img_bgr: np.ndarray, cfg: dict) -> torch.Tensor:
+    """func_vpr.py:626-644 with the image already decoded: crop rows ``rmin:`` (the caller-side crop every reference
+    loader applies before process_single_DINO -- also process_dino_ft_to_h5, func_vpr.py:647-662), resize to the
+    configured DINO resolution, tokens on the CPU like the reference returns them."""
+    im = np.asarray(img_bgr)[int(cfg.get("rmin", 0)):, :, :]
+    cfg_dino = {"desired_width": cfg["desired_width"], "desired_height": cfg["desired_height"], "resize": True}
+    return process_single_DINO(cfg_dino, im, extractor)[1].detach().cpu()
+
+
 # =====================================================================================================================
 # SAM automatic masks (SURVEY.md section 8, row f3, second half)
 # =====================================================================================================================

@@ -538,6 +538,42 @@ def test_adjacency_empty_mask_raises(eng):
         eng.adjacency(cent, np.array([0, 5], np.int32), 2, check_empty=True)
 
 
+def test_adjacency_flags_non_generic_centroids_and_the_pipeline_uses_qhull(eng):
+    """Exactly co-circular centroids (a lattice rectangle with an empty circle) and duplicate centroids have no unique
+    Delaunay triangulation: the device kernel keeps both diagonals / links the duplicates, Qhull picks one diagonal /
+    drops the duplicate.  The kernel reports such images (bits 16.. of the counter); with check_empty the engine raises
+    and SegVLADPipeline recomputes the batch with the reference's Qhull path."""
+    import torch
+    from revisit_anything_amd._lib import SegVLADError
+    from revisit_anything_amd.pipeline import SegVLADPipeline
+
+    generic = np.array([[3.0, 4.0], [40.5, 7.25], [21.0, 33.0], [8.0, 29.5], [30.0, 18.0]])
+    rect = np.array([[10.0, 10.0], [30.0, 10.0], [30.0, 22.0], [10.0, 22.0], [55.0, 60.0]])    # 4 co-circular + 1 far away
+    dup = np.array([[5.0, 5.0], [25.0, 6.0], [25.0, 6.0], [9.0, 31.0], [40.0, 28.0]])
+    offs = np.array([0, 5], np.int32)
+    eng.adjacency(generic, offs, 1, check_empty=True)                                            # generic: no complaint
+    for c in (rect, dup):
+        with pytest.raises(SegVLADError, match="degenerate"):
+            eng.adjacency(c, offs, 1, check_empty=True)
+        eng.adjacency(c, offs, 1)                                                                # unchecked: still computes
+    a = eng.adjacency(rect, offs, 1).cpu().numpy().reshape(5, 5).astype(bool)
+    assert a[0, 2] and a[1, 3]                                                                   # both diagonals kept
+    q = O().adjacency_from_centroids(rect, 1)
+    assert q[0, 2] != q[1, 3]                                                                    # Qhull keeps exactly one
+    # pipeline: masks whose centroids form the rectangle -> descriptors equal the host-Qhull pipeline's bit for bit
+    K, D, H, W = 8, 64, 112, 140
+    C = synth().make_vocab(K, D, seed=2)
+    eng.set_vocab(C)
+    m = np.zeros((5, 56, 70), np.uint8)
+    for j, (x, y) in enumerate([(10, 10), (30, 10), (30, 22), (10, 22), (55, 44)]):
+        m[j, y - 2:y + 3, x - 2:x + 3] = 1                                                       # 5 x 5 squares: centroid = centre
+    toks = torch.from_numpy(synth().make_tokens(C, 80, seed=77, noise=0.2)[None]).to(eng.device)
+    masks = torch.from_numpy(m).to(eng.device)
+    d_dev = SegVLADPipeline(eng, H, W, order=1, use_pca=False).describe(toks, masks, offs).cpu().numpy()
+    d_host = SegVLADPipeline(eng, H, W, order=1, use_pca=False, host_adjacency=True).describe(toks, masks, offs).cpu().numpy()
+    assert np.array_equal(d_dev, d_host)
+
+
 def test_pipeline_device_adjacency_equals_host_qhull(eng):
     import torch
     from revisit_anything_amd.pipeline import SegVLADPipeline

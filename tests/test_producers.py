@@ -59,6 +59,21 @@ def test_image_to_tokens_layout_and_preprocessing(tiny):
     assert out2.shape == (1, 48, 4, 6)
 
 
+def test_dino_given_image_crops_rmin_rows_then_resizes(tiny):
+    """func_vpr.py:626-644: the loader-side ``[rmin:, :, :]`` crop happens BEFORE the resize; BGR in, unit tokens out."""
+    rng = np.random.Generator(np.random.PCG64(8))
+    bgr = rng.integers(0, 256, (90, 100, 3), dtype=np.uint8)
+    cfg = {"rmin": 20, "desired_width": 70, "desired_height": 56}
+    t = pr.dino_given_image(tiny, bgr, cfg)
+    assert t.shape == (1, 48, 4, 5) and t.device.type == "cpu"
+    assert torch.allclose(t.norm(dim=1), torch.ones(1, 4, 5), atol=1e-5)
+    rgb_crop = np.ascontiguousarray(bgr[20:, :, ::-1])
+    ref = pr.image_to_tokens(rgb_crop, tiny, {"resize": True, "desired_width": 70, "desired_height": 56})
+    assert torch.allclose(t, ref.cpu(), atol=1e-6)
+    img_p, t2 = pr.process_single_DINO({"resize": False}, bgr[20:76, :70], tiny)
+    assert img_p.shape == (56, 70, 3) and np.array_equal(img_p, bgr[20:76, :70, ::-1]) and t2.shape == (1, 48, 4, 5)
+
+
 def test_input_validation(tiny):
     with pytest.raises(ValueError):
         tiny(torch.zeros(1, 3, 50, 70))
