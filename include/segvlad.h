@@ -104,7 +104,10 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
 /* ---- fused segvlad_images + segvlad_pca_apply: the per-batch pair of place_rec_main.py:259-270
  *      (seg_vlad_gpu_single per image, then apply_pca_transform_from_pkl on the batch) in one call.  The
  *      aggregation kernel emits the projection GEMM's input planes directly, so the K*D-wide fp32 descriptor is
- *      neither measured (max |x|), nor re-read, nor -- when desc_out is NULL -- written to HBM at all.
+ *      neither measured (max |x|), nor re-read, nor -- when desc_out is NULL -- written to HBM at all; with
+ *      desc_out == NULL the call may not even form it (option "pca_path": the tokens' residuals are projected with
+ *      their cluster's slice of the components and the segments aggregated in the P-dimensional space -- the same
+ *      linear map in another order, fp32-class like the other form).
  *      y [S_tot][P] fp32 (l2norm != 0: rows normalised as normalizeFeat); desc_out [S_tot][K*D] fp32 or NULL;
  *      other arguments as segvlad_images.  Requires segvlad_set_vocab and segvlad_pca_set (KD == K*D).      */
 int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
@@ -185,6 +188,12 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *        "search_stats" 0 | 1                          record list occupancies (segvlad_search_stats)
  *        "knn_heuristic" 1 | 0                         low-rank, a-posteriori verified level thresholds (5-10x fewer
  *                                                      candidates per level) | rigorous k-th-rank thresholds only
+ *        "pca_path"      auto | planes | project       form of segvlad_images_pca when no descriptor output is asked
+ *                                                      for: "planes" projects the finished K*D-wide descriptors,
+ *                                                      "project" projects every token's residual with its cluster's
+ *                                                      slice of the components and aggregates the segments in the
+ *                                                      P-dimensional space (same fp32-class result, N*D*P instead of
+ *                                                      S*K*D*P flops per image); auto = the smaller product
  *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning   */
 int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
 
