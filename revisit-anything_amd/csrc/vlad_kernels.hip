@@ -553,8 +553,14 @@ __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restric
                                                           const float* __restrict__ bt, float* __restrict__ Xt,
                                                           uint8_t* __restrict__ labels, float* __restrict__ rnorm,
                                                           float* __restrict__ gap) {
-  constexpr int DC = 32, TS = 130;
-  __shared__ __attribute__((aligned(16))) float tile[2 * DC * TS];   // also [128][NT*32+1] scores at the end (NT <= 2)
+  // LDS tile [d][token], row stride 128 floats, row d ROTATED by rot(d) = 8 (d >> 2) + 32 (d & 1) tokens: the MFMA A
+  // operand reads two rows d, d+1 per instruction (their rotations differ by 32 banks: disjoint), the transposed gather
+  // that writes Xt reads (4 c4 + e, tok) for 8 values of c4 and 8 consecutive tokens (banks tok + 8 c4: all 64 distinct),
+  // and the loader stores whole 16-B quads.  (PMC, round 2: with a plain stride of 130 floats 39 % of the LDS cycles of
+  // this kernel were bank conflicts -- two-way on the A reads and on the 8-B stores.)
+  constexpr int DC = 32, TS = 128;
+  auto rot = [](int d) { return 8 * (d >> 2) + 32 * (d & 1); };
+  __shared__ __attribute__((aligned(16))) float tile[2 * DC * TS + 128];   // also [128][NT*32+1] scores at the end (NT <= 2)
   __shared__ float ssum[128];
   const int b = blockIdx.y, t0 = blockIdx.x * 128;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -582,9 +588,9 @@ __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restric
   }
 #define SV_PARK_CHUNK(buf)                                                            \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
-    float* q = tile + (buf) * (DC * TS) + (lr + 8 * j) * TS + 4 * lq;                 \
-    *reinterpret_cast<float2*>(q) = make_float2(v[j].x, v[j].y);                      \
-    *reinterpret_cast<float2*>(q + 2) = make_float2(v[j].z, v[j].w);                  \
+    const int d_ = lr + 8 * j;                                                        \
+    float* q = tile + (buf) * (DC * TS) + d_ * TS + ((4 * lq + rot(d_)) & 127);       \
+    *reinterpret_cast<float4*>(q) = v[j];                                             \
   }
   SV_LOAD_CHUNK(0)
   SV_PARK_CHUNK(0)
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restric
     const float* tl = tile + (c & 1) * (DC * TS);
 #pragma unroll 8
     for (int st = 0; st < DC / 2; ++st) {
-      const float x = tl[(2 * st + kk) * TS + 32 * w + i];
+      const float x = tl[(2 * st + kk) * TS + ((32 * w + i + rot(2 * st + kk)) & 127)];
       ss = fmaf(x, x, ss);
       const float* bp = bt + ((size_t)(c * (DC / 2) + st) * NT) * 64 + l;
 #pragma unroll
@@ -605,8 +611,9 @@ __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restric
       const int idx = it * 256 + tid;
       const int tok = idx >> 3, c4 = idx & 7;
       if (t0 + tok < N) {
-        const float* q = tl + (4 * c4) * TS + tok;
-        const float4 o = make_float4(q[0], q[TS], q[2 * TS], q[3 * TS]);
+        const float* q = tl + (4 * c4) * TS;   // rows 4 c4 + e: rotation 8 c4 + 32 (e & 1)
+        const int t_a = (tok + 8 * c4) & 127, t_b = (tok + 8 * c4 + 32) & 127;
+        const float4 o = make_float4(q[t_a], q[TS + t_b], q[2 * TS + t_a], q[3 * TS + t_b]);
         *reinterpret_cast<float4*>(Xt + ((size_t)b * N + t0 + tok) * D + c * DC + 4 * c4) = o;
       }
     }

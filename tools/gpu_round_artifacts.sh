@@ -34,6 +34,11 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   REPS=1 timeout 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
        --kernel-trace --output-format csv -d /tmp/prof_SQ -- python $REPO/tools/probe_counters.py > /tmp/prof_SQ.log 2> /tmp/prof_SQ.err \
        || echo "PMC pass SQ: timeout or failure"
+  rm -rf /tmp/prof_LDS
+  REPS=1 timeout 150 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_BUSY_CYCLES \
+       --kernel-trace --output-format csv -d /tmp/prof_LDS -- python $REPO/tools/probe_counters.py > /tmp/prof_LDS.log 2> /tmp/prof_LDS.err \
+       || echo "PMC pass LDS: timeout or failure"
+  fl=$(find /tmp/prof_LDS -name '*counter_collection.csv' 2>/dev/null | head -1)
   ff=$(find /tmp/prof_FETCH_SIZE -name '*counter_collection.csv' 2>/dev/null | head -1)
   fw=$(find /tmp/prof_WRITE_SIZE -name '*counter_collection.csv' 2>/dev/null | head -1)
   fs=$(find /tmp/prof_SQ -name '*counter_collection.csv' 2>/dev/null | head -1)
@@ -41,6 +46,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   cat /tmp/prof_SQ.log | tail -3
   if [ -n "$ff" ] && [ -n "$fw" ]; then
     SQARGS=""; [ -n "$fs" ] && [ -n "$ft" ] && SQARGS="--sq $fs --sq-trace $ft"
+    [ -n "$fl" ] && SQARGS="$SQARGS --lds $fl"
     python $REPO/tools/pmc_summary.py --key q200x50_db1000000_d1024_k64_w1 --fetch $ff --write $fw $SQARGS \
        > $OUT/${TAG}_pmc_traffic.json 2> $OUT/${TAG}_pmc.err
     head -c 2500 $OUT/${TAG}_pmc_traffic.json

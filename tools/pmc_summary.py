@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--write", required=True)
     ap.add_argument("--sq", default=None)
     ap.add_argument("--sq-trace", default=None)
+    ap.add_argument("--lds", default=None, help="counter_collection.csv of the LDS pass (SQ_LDS_* / SQ_INSTS_LDS / SQ_ACTIVE_INST_LDS ...)")
     a = ap.parse_args()
     F, Wc = load_counters(a.fetch), load_counters(a.write)
     fcal = next((avg(v["FETCH_SIZE"]) for k, v in F.items() if "sign_kernel" in k and v.get("FETCH_SIZE")), None)
@@ -73,6 +74,7 @@ def main():
     fscale, wscale = float(1 << 30) / fcal, float(1 << 30) / wcal
     SQ = load_counters(a.sq) if a.sq else {}
     DUR = load_durations(a.sq_trace) if a.sq_trace else {}
+    LDS = load_counters(a.lds) if a.lds else {}
     kernels = []
     for name, c in F.items():
         if "elementwise" in name or "sign_kernel" in name or not c.get("FETCH_SIZE"):
@@ -101,6 +103,15 @@ def main():
                           "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F16"):
                 if s.get(extra):
                     k[extra.lower()] = avg(s[extra])
+        ld = LDS.get(name)
+        if ld:   # LDS pass: raw per-launch averages (summed over all SIMDs / XCDs) + two ratios that do not depend on units
+            k["lds_pass"] = {c.lower(): avg(v) for c, v in ld.items() if v}
+            act, conf = ld.get("SQ_LDS_IDX_ACTIVE"), ld.get("SQ_LDS_BANK_CONFLICT")
+            if act and conf and avg(act):
+                k["lds_bank_conflict_frac"] = avg(conf) / avg(act)      # conflict cycles / cycles the LDS index unit was active
+            busy, lact = ld.get("SQ_BUSY_CYCLES"), ld.get("SQ_ACTIVE_INST_LDS")
+            if busy and lact and avg(busy):
+                k["lds_inst_active_per_busy_cycle"] = avg(lact) / avg(busy)
         kernels.append(k)
     kernels.sort(key=lambda k: -k["hbm_bytes_per_launch"] * k["launches"])
     json.dump({"workload_key": a.key, "kernel_src_sha": kernel_src_sha(),
