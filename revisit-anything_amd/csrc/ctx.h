@@ -90,7 +90,7 @@ struct SvOptions {
   int knn_filter = 0;     // 0 auto (fp16 when d % 64 == 0, else bf16x3 when d % 32 == 0, else fp32), 1 f16, 2 bf16x3, 3 fp32
   int pca_fp32 = 0;       // 1: plain fp32-MFMA projection instead of the fp16x3 split GEMM
   int f16_cfg = -1;       // kNN fp16 filter tile configuration (-1 = chosen from the shape)
-  int f16_gm = 4;         // tile-block height of the XCD-aware order (0 = plain tm-fastest order)
+  int f16_gm = -1;        // tile-block height of the XCD-aware order (-1 = by the number of query tiles, 0 = plain tm-fastest order)
   int x3_tile = 0;        // PCA split GEMM tile (0 = from the shape, 128, 256)
   int x3_gm = -1;         // PCA split GEMM XCD-aware block height (-1 = default of the kernel, 0 = plain order)
   int search_stats = 0;   // 1: segvlad_search records list occupancies (synchronises once per chunk)

@@ -978,7 +978,11 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
                              int cap) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (n_sample + BN - 1) / BN;
   int64_t tiles = (int64_t)tiles_m * tiles_n;
-  int gm = ctx->opt.f16_gm;  // tile-block height of the XCD-aware order (0 = plain tm-fastest order)
+  // tile-block height of the XCD-aware order (0 = plain tm-fastest order).  Every database tile is fetched once per
+  // block ROW of query tiles: with >= 16 query tiles (one pass over 10 000 queries has 40) blocks of 8 x 4 halve that
+  // re-read against 4 x 8 (10 -> 5 fetches of the fp16 plane per launch) at the same speed; 16 x 2 is 14 % slower (the 16
+  // query tiles no longer stay in the XCD's L2).
+  int gm = ctx->opt.f16_gm >= 0 ? ctx->opt.f16_gm : (tiles_m >= 16 ? 8 : 4);
   if (PERSIST && gm <= 0) gm = 4;
   int seq_total = 0;
   if (gm > 0) {
@@ -1021,7 +1025,7 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   // k-tile) -> 21.9, 255 (55 + persistent) -> 22.1, against 20.9-21.1 for 250 in the same sessions: with one wave per SIMD
   // nothing covers the per-tile barrier and the epilogue, and the kernel sits at the same power-limited clock either way.
   // streaming regime (M <= 128, e.g. one 50-segment query image per pass over 1 M rows): 2 -> 0.41 ms, 3 -> 0.51 ms
-  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : 2);
+  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : M > 64 ? 63 : 62);
   switch (c) {
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
     case 200:   // persistent workgroups that request the next tile's head before their epilogue
@@ -1067,6 +1071,9 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 1: return launch_f16_filter<256, 256, 4, 2, 32, 2>(SV_F16_ARGS);  //  64 KiB LDS, 2 workgroups / CU
     case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
     case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB
+    case 60: return launch_f16_filter<64, 128, 1, 2, 64, 3>(SV_F16_ARGS);   //  64 KiB, 2 waves: one query image (<= 64 rows) per pass
+    case 62: return launch_f16_filter<64, 128, 1, 2, 64, 3, 0, false, 1>(SV_F16_ARGS);   // 60 + database rows non-temporal
+    case 63: return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 1>(SV_F16_ARGS);  // 2 + database rows non-temporal
     case 5: return launch_f16_filter<256, 256, 2, 2, 64, 3>(SV_F16_ARGS);  // 4 waves of 128 x 128: 0.5 LDS fragment / MFMA
     case 55: return launch_f16_filter<256, 256, 2, 2, 64, 3, 0, false, 0, -1>(SV_F16_ARGS);  // + software-pipelined loop
     case 255:
