@@ -92,7 +92,7 @@ def pmc_counters(kernel_prefix: str, workload_key: str):
             why = f"{os.path.basename(f)} was collected from kernel sources {j.get('kernel_src_sha')}, current {sha}: not quoted"
             continue
         for k in j.get("kernels", []):
-            if k["name"].startswith(kernel_prefix):
+            if k["name"].startswith(kernel_prefix) or ("_Z" in k["name"][:2] and kernel_prefix in k["name"]):   # (some names stay mangled)
                 return k.get("hbm_bytes_per_launch"), k.get("mfma_util"), os.path.basename(f) + f" (kernel sources {sha})"
     return None, None, why
 

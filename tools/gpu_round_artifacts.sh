@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the per-round measurement artifacts on the GPU box (run through gpurun from the repo root):
-#   tools/gpu_round_artifacts.sh r02 [all|bench|pmc]
+#   tools/gpu_round_artifacts.sh r02 [all|bench|pmc]      (all = the counter passes first, then the bench that quotes them)
 # -> gpurun_out/<tag>_bench_n1.json, <tag>_bench_n1_kernel_stats.csv, <tag>_pmc_traffic.json, ...
 # EVERY step runs under its own `timeout`: in round 1 a counter-collection pass without one stalled and burnt the
 # remaining 33 GPU-minutes of the round.
@@ -10,16 +10,6 @@ WHAT=${2:-all}   # all | bench | pmc
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
-  timeout 420 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
-  tail -c 600 $OUT/${TAG}_bench_n1.json
-  cd /tmp && export TMPDIR=/tmp
-  # same command under the kernel trace (the CPU-baseline leg launches no kernels)
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python $REPO/bench.py --no-cpu-baseline \
-     > $OUT/${TAG}_bench_n1_under_rocprof.json 2> /tmp/prof_kt.err
-  f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_n1_kernel_stats.csv
-  cd $REPO
-fi
 if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   cd /tmp && export TMPDIR=/tmp
   # Counter passes over tools/probe_counters.py (a few dozen dispatches replaying the bench's kernel shapes): one pass
@@ -54,5 +44,17 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
     echo "no counter_collection.csv: PMC summary skipped" | tee $OUT/${TAG}_pmc.err
     tail -5 /tmp/prof_FETCH_SIZE.err
   fi
+  cd $REPO
+  # the bench below quotes a PMC summary only if it was collected from the CURRENT kernel sources: put this one in place
+  [ -s $OUT/${TAG}_pmc_traffic.json ] && cp $OUT/${TAG}_pmc_traffic.json $REPO/profiles/${TAG}_pmc_traffic.json
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
+  timeout 420 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
+  tail -c 600 $OUT/${TAG}_bench_n1.json
+  cd /tmp && export TMPDIR=/tmp
+  # same command under the kernel trace (the CPU-baseline leg launches no kernels)
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python $REPO/bench.py --no-cpu-baseline \
+     > $OUT/${TAG}_bench_n1_under_rocprof.json 2> /tmp/prof_kt.err
+  f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_n1_kernel_stats.csv
   cd $REPO
 fi
