@@ -97,7 +97,8 @@ struct SvOptions {
   int knn_heuristic = 1;  // 1: low-rank (verified) thresholds in the level scheme; 0: rigorous k-th-rank thresholds only
   int assign_narrow = 0;  // 1: force the narrow assignment kernel
   int agg_kpb = 4;        // clusters per aggregation workgroup
-  int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises)
+  int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises); 7: token_norms_kernel waits for every
+                          //    outstanding memory operation at every step (verification of its counted waits: same bits)
   int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
 };
 

@@ -245,6 +245,12 @@ def test_images_pca_fused_bench_shape_split_k(eng):
     y_planes = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=True)["out"].cpu().numpy()
     eng.set_option("pca_path", "auto")
     assert np.array_equal(y, y_planes)                                    # the descriptor output does not change y
+    eng.set_option("debug_search", "7")                                   # token kernel with conservative waits: same bits
+    try:
+        y_safe = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=True)["out"].cpu().numpy()
+    finally:
+        eng.set_option("debug_search", "0")
+    assert np.array_equal(y_safe, y_nodesc)
     compsd = comps.astype(np.float64)
     worst = 0.0
     for b in range(B):

@@ -716,6 +716,16 @@ def test_images_pca_project_form_big_clusters_and_partial_chunk(eng):
             eng.set_option("pca_path", "auto")
         assert np.abs(ys[path] - ref).max() <= 3e-5 * np.abs(ref).max()
     assert np.abs(ys["project"] - ys["planes"]).max() <= 1e-5 * np.abs(ref).max()
+    # the token kernel's counted waits (DMA queue + plane stores in one vmcnt stream) against the same kernel waiting for
+    # everything at every step (development switch debug_search = 7): bit-identical
+    eng.set_option("pca_path", "project")
+    eng.set_option("debug_search", "7")
+    try:
+        y_safe = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=False)["out"].cpu().numpy()
+    finally:
+        eng.set_option("debug_search", "0")
+        eng.set_option("pca_path", "auto")
+    assert np.array_equal(y_safe, ys["project"])
 
 
 # ------------------------------------------------------------------------------------------------
