@@ -431,6 +431,10 @@ def main():
                     "flops_vs_descriptor_projection": rows * depth / (nq_local * S * K * D),
                     "alg_bytes_per_launch": 2.0 * 2 * (rows * depth + P * K * D) + 4.0 * rows * P * (2 if form == "project" else 1)}
         pca_roof["frac"] = pca_roof["achieved"] / pca_roof["peak"]
+        # the same stage time priced at the work the reference's formulation needs (S K D P per image, x products): what a
+        # descriptor-projection GEMM would have to sustain to be as fast
+        pca_roof["descriptor_projection_equivalent_tflops"] = pf / pca_roof["flops_vs_descriptor_projection"]
+        pca_roof["descriptor_projection_equivalent_frac"] = pca_roof["descriptor_projection_equivalent_tflops"] / pca_roof["peak"]
 
     # secondary: the kNN stage in its HBM-bound regime (B_q <= 50, i.e. ONE query image per pass)
     stream_roof = None
