@@ -104,10 +104,13 @@ int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* 
 
 // ---- aggregation in the projected space ---------------------------------------------------------------------------------
 // Workgroup = (256 output columns, image); 8 waves, wave w owns columns [32 w, 32 w + 32) for up to 64 segments (two
-// 32x32 accumulators).  The image's projected tokens are walked cluster by cluster in tiles of 32 rows staged through
-// LDS (coalesced 16-B loads); MFMA 32x32x2 f32 with A = the segment's weight a_sk where its column-mask bit is set, else 0,
-// B = z.  The mean term W mu and the whitening scale are applied in the epilogue.
-constexpr int PJ_T = 32;
+// 32x32 accumulators).  The image's projected tokens are walked cluster by cluster in tiles of <= 32 rows (a tile never
+// spans clusters: the segment weights a_sk are per-tile constants held in registers) staged through a DOUBLE-BUFFERED LDS
+// tile: the tile list is built once, the global loads of tile t+1 are issued before the MFMAs of tile t and stored behind
+// them -- one barrier per tile and no exposed load latency (a cluster holds ~24 tokens of an image: ~64 tiles per image,
+// each previously paying a full load round trip between two barriers).  MFMA 32x32x2 f32 with A = the segment's weight
+// where its column-mask bit is set, else 0, B = z.  The mean term W mu and the whitening scale are applied in the epilogue.
+constexpr int PJ_T = 32;   // rows per tile (an image has at most K + N / 32 tiles: `maxt`)
 
 __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __restrict__ Z, const float* __restrict__ wmu,
                                                                 const float* __restrict__ bn, const float* __restrict__ gscale,
@@ -115,22 +118,43 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
                                                                 const int32_t* __restrict__ lab_off,
                                                                 const int32_t* __restrict__ rowbase,
                                                                 const int32_t* __restrict__ seg_off, int N, int K, int P, int SC,
-                                                                const float* __restrict__ col_scale, float* __restrict__ Y) {
+                                                                int maxt, const float* __restrict__ col_scale,
+                                                                float* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int KS = K + 1;                                            // row stride of ag / coef: conflict-free column reads
+  const int KS = K + 1 + (K & 1);                                  // row stride of ag, always odd: conflict-free column reads
   float* ag = reinterpret_cast<float*>(smem);                      // [64][KS]  a_sk = g_s / ||V_sk||   (0 for empty blocks)
-  float* zt = ag + 64 * KS;                                        // [PJ_T][256] staged rows
-  uint64_t* mk = reinterpret_cast<uint64_t*>(zt + PJ_T * 256);     // [PJ_T] column masks of the staged tokens
+  float* zt = ag + 64 * KS;                                        // [2][PJ_T][256] staged rows
+  uint64_t* mk = reinterpret_cast<uint64_t*>(zt + 2 * PJ_T * 256); // [2][PJ_T] column masks of the staged tokens
+  int32_t* tl_k = reinterpret_cast<int32_t*>(mk + 2 * PJ_T);       // [maxt] cluster of tile t
+  int32_t* tl_j = tl_k + maxt;                                     // [maxt] first token (label-grouped order) of tile t
+  int32_t* tl_z = tl_j + maxt;                                     // [maxt] first row of Z of tile t
+  int32_t* tl_n = tl_z + maxt;                                     // [maxt] rows in tile t
+  __shared__ int s_tiles;
   const int b = blockIdx.y, p0 = blockIdx.x * 256;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
   const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
   const int SCb = (S + 63) >> 6;
   const int32_t* lo = lab_off + (size_t)b * (K + 1);
   const int pcol = p0 + 32 * w + i;
+  if (tid == 0) {   // tile list: K small serial steps, once per workgroup
+    int t = 0;
+    for (int k = 0; k < K; ++k) {
+      const int o0 = lo[k], n = lo[k + 1] - o0, g0 = rowbase[(size_t)b * K + k];
+      for (int j0 = 0; j0 < n && t < maxt; j0 += PJ_T, ++t) {
+        tl_k[t] = k;
+        tl_j[t] = o0 + j0;
+        tl_z[t] = g0 + j0;
+        tl_n[t] = min(PJ_T, n - j0);
+      }
+    }
+    s_tiles = t;
+  }
+  __syncthreads();
+  const int tiles = s_tiles;
 
   for (int sc = 0; sc < SCb; ++sc) {
     const int Sc = min(64, S - 64 * sc);
-    __syncthreads();   // the previous chunk's readers of ag are done
+    __syncthreads();   // the previous chunk's readers of ag / zt are done
     for (int idx = tid; idx < 64 * K; idx += 512) {
       const int s = idx / K, k = idx - s * K;
       float a = 0.f;
@@ -140,7 +164,6 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
       }
       ag[s * KS + k] = a;
     }
-    __syncthreads();
     f32x16 acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -148,39 +171,52 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
       for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     const bool two = Sc > 32;
 
-    // one staged tile of nt <= 32 rows starting at src (row stride P) and the column masks of its tokens
-    auto stage = [&](const float* src, int nt, const uint64_t* msrc) {
-      __syncthreads();   // previous tile consumed
+    float4 v[4];
+    uint64_t mreg = 0ull;
+    auto fetch = [&](int t) {   // global loads of tile t into registers
+      const int nt = tl_n[t];
+      const float* src = Z + (size_t)tl_z[t] * P;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int idx4 = tid + 512 * q, row = idx4 >> 6, c4 = idx4 & 63;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nt && p0 + 4 * c4 < P) v = *reinterpret_cast<const float4*>(src + (size_t)row * P + p0 + 4 * c4);
-        *reinterpret_cast<float4*>(zt + row * 256 + 4 * c4) = v;
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nt && p0 + 4 * c4 < P) v[q] = *reinterpret_cast<const float4*>(src + (size_t)row * P + p0 + 4 * c4);
       }
-      if (tid < PJ_T) mk[tid] = tid < nt ? msrc[(size_t)tid * SC] : 0ull;
-      __syncthreads();
+      if (tid < PJ_T) mreg = tid < nt ? colmask[((size_t)b * N + tl_j[t] + tid) * SC + sc] : 0ull;
     };
-
-    for (int k = 0; k < K; ++k) {
-      const int o0 = lo[k], n = lo[k + 1] - o0;
-      const float* zsrc = Z + (size_t)rowbase[(size_t)b * K + k] * P;
+    auto stash = [&](int buf) {   // registers -> LDS tile `buf`
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx4 = tid + 512 * q, row = idx4 >> 6, c4 = idx4 & 63;
+        *reinterpret_cast<float4*>(zt + (size_t)buf * PJ_T * 256 + row * 256 + 4 * c4) = v[q];
+      }
+      if (tid < PJ_T) mk[buf * PJ_T + tid] = mreg;
+    };
+    if (tiles > 0) {
+      fetch(0);
+      stash(0);
+    }
+    __syncthreads();   // ag and tile 0 visible
+    for (int t = 0; t < tiles; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < tiles) fetch(t + 1);   // in flight under this tile's MFMAs
+      const int k = tl_k[t], nt = tl_n[t];
       const float a0k = ag[i * KS + k], a1k = ag[(32 + i) * KS + k];
-      for (int j0 = 0; j0 < n; j0 += PJ_T) {
-        const int nt = min(PJ_T, n - j0);
-        stage(zsrc + (size_t)j0 * P, nt, colmask + ((size_t)b * N + o0 + j0) * SC + sc);
-        for (int pr = 0; 2 * pr < nt; ++pr) {
-          const int j = 2 * pr + kk;
-          const uint64_t m = mk[j];
-          const float bv = zt[j * 256 + 32 * w + i];
-          const float a0 = ((m >> i) & 1ull) ? a0k : 0.f;
-          acc[0] = MFMA32(a0, bv, acc[0]);
-          if (two) {
-            const float a1 = ((m >> (32 + i)) & 1ull) ? a1k : 0.f;
-            acc[1] = MFMA32(a1, bv, acc[1]);
-          }
+      const float* ztc = zt + (size_t)cur * PJ_T * 256 + 32 * w + i;
+      const uint64_t* mkc = mk + cur * PJ_T;
+      for (int pr = 0; 2 * pr < nt; ++pr) {
+        const int j = 2 * pr + kk;
+        const uint64_t m = mkc[j];
+        const float bv = ztc[j * 256];
+        const float a0 = ((m >> i) & 1ull) ? a0k : 0.f;
+        acc[0] = MFMA32(a0, bv, acc[0]);
+        if (two) {
+          const float a1 = ((m >> (32 + i)) & 1ull) ? a1k : 0.f;
+          acc[1] = MFMA32(a1, bv, acc[1]);
         }
       }
+      if (t + 1 < tiles) stash(cur ^ 1);   // (the readers of that buffer -- tile t-1 -- passed the previous barrier)
+      __syncthreads();
     }
     if (pcol < P) {
       const float cs = col_scale ? col_scale[pcol] : 1.f, mu = wmu[pcol];
@@ -202,13 +238,15 @@ int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* w
                                 int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y) {
   if (B <= 0 || S_max <= 0) return SEGVLAD_OK;
   if (P % 4) return ctx->fail(SEGVLAD_ERR_ARG, "project_aggregate: P=%d must be a multiple of 4", P);
-  const size_t lds = (size_t)64 * (K + 1) * 4 + (size_t)PJ_T * 256 * 4 + (size_t)PJ_T * 8;
-  if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d needs %zu B of LDS", K, lds);
+  const int maxt = K + (N + PJ_T - 1) / PJ_T;   // every cluster may end in a partial tile
+  const size_t lds = (size_t)64 * (K + 1 + (K & 1)) * 4 + (size_t)2 * PJ_T * 256 * 4 + (size_t)2 * PJ_T * 8 + (size_t)4 * maxt * 4;
+  if (lds > 160 * 1024)
+    return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d, N=%d need %zu B of LDS", K, N, lds);
   if (lds > 64 * 1024)
     SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(project_aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
   hipLaunchKernelGGL(project_aggregate_kernel, dim3((P + 255) / 256, B), dim3(512), lds, ctx->stream, Z, wmu, block_norms, gscale,
-                     colmask, lab_off, rowbase, seg_off_dev, N, K, P, SC, col_scale, Y);
+                     colmask, lab_off, rowbase, seg_off_dev, N, K, P, SC, maxt, col_scale, Y);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
