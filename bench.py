@@ -401,7 +401,8 @@ def main():
     # the block norms (4 S K).
     pca_form = None
     if use_pca:
-        pca_form = "project" if (eng_pca_products(K * D, P) == 3 and D % 32 == 0 and P % 4 == 0 and S * K >= 1.25 * N) else "planes"
+        pca_form = "project" if (eng_pca_products(K * D, P) == 3 and D % 32 == 0 and P % 4 == 0 and S * K >= 1.25 * N
+                                 and nq_local * N >= 128 * K) else "planes"
     vlad_ms = sum(stages[s]["ms_per_step"] for s in ("incidence", "assign", "prep", "aggregate") if s in stages)
     out_bytes = 4 * N * D + 4 * S * K if pca_form == "project" else 4 * S * K * D
     bytes_img = 4 * D * N + out_bytes + S * N / 8 + S * S + S * Hm * Wm

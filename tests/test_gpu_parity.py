@@ -764,22 +764,23 @@ def test_images_pca_fused_equals_two_calls_and_oracle(eng, P):
         if l2:
             ref = O().normalize_feat(ref)
         assert np.abs(y - ref).max() <= 3e-5 * np.abs(ref).max()
-        # without the descriptor output the call takes the "project then aggregate" form (tokens projected with their
-        # cluster's slice of the components, segments aggregated in the P-d space: ragged S incl. 0 and > 64, empty
-        # clusters, a token-less segment) -- same fp32-class result in a different summation order ...
+        # without the descriptor output: four small images hold too few tokens per cluster for the "project" form to pay
+        # (auto keeps the descriptor planes: bit-identical with or without the descriptor output) ...
         y2 = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=l2)["out"].cpu().numpy()
-        assert np.abs(y2 - ref).max() <= 3e-5 * np.abs(ref).max()
-        assert np.abs(y2 - y).max() <= 1e-5 * np.abs(ref).max()
-        # ... and with that form switched off the projection is bit-identical with or without the descriptor output
+        assert np.array_equal(y, y2)
         eng.set_option("pca_path", "planes")
         try:
             y3 = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=l2)["out"].cpu().numpy()
         finally:
             eng.set_option("pca_path", "auto")
         assert np.array_equal(y, y3)
+        # ... and the "project then aggregate" form on request (tokens' residuals projected with their cluster's slice of
+        # the components, segments aggregated in the P-d space: ragged S incl. 0 and > 64, empty clusters, a token-less
+        # segment) -- the same fp32-class result in a different summation order
         eng.set_option("pca_path", "project")
         try:
             y4 = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=l2)["out"].cpu().numpy()
         finally:
             eng.set_option("pca_path", "auto")
-        assert np.array_equal(y2, y4)              # auto chose it here (S K > 1.25 N)
+        assert np.abs(y4 - ref).max() <= 3e-5 * np.abs(ref).max()
+        assert np.abs(y4 - y).max() <= 1e-5 * np.abs(ref).max()
