@@ -1,3 +1,8 @@
+"""Development probe: vote kernel time against the concentration of the matches on few reference images (long runs of one
+image id used to be summed by ONE thread; a workgroup per query image, so the slowest image set the kernel time).
+
+    gpurun -- 'python tools/probe_vote.py'
+"""
 import sys, time, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from revisit_anything_amd.engine import SegVLADEngine
