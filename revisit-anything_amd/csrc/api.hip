@@ -194,7 +194,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_laboff,  &ctx->s_rnsorted, &ctx->s_ovf,   &ctx->s_fb_q,   &ctx->s_fb_d2,  &ctx->s_fb_idx,
                     &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
                     &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys, &ctx->s_pz, &ctx->s_rowbase,
-                    &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj};
+                    &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -853,15 +853,25 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
       StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
-      SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0));
+      SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
       sc.count();
     }
     StageScope sc(ctx, "knn_select");
-    SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, r0, thr, ctx->s_thr_idx.as<int64_t>(), r0, 0));
+    if (n0 <= 1024 && pl.kind != 3) {
+      // a short sample row: only its r0-th smallest distance is needed -- the wave-per-query register select of the
+      // candidate lists (mode 0: thr[q] = rank-th smallest), the distance block standing in for a list of n0 entries
+      SV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->s_cand_cnt.p), (int)n0, (size_t)m, ctx->stream));
+      SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_dist.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
+                                     (int)ld0, r0, 0, 0, nullptr, 0, qn, pl.c_eps, pl.rn_max, thr, ctx->s_ref_cnt.as<uint32_t>(),
+                                     ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count));
+    } else {
+      SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, r0, thr, ctx->s_thr_idx.as<int64_t>(), r0, 0));
+    }
     sc.count();
   }
-  const float* thr_ptr = thr + (r0 - 1);
-  int64_t thr_ld = r0;
+  const bool l0_small = n0 <= 1024 && pl.kind != 3;
+  const float* thr_ptr = l0_small ? thr : thr + (r0 - 1);
+  int64_t thr_ld = l0_small ? 1 : r0;
   // rigorous: level-0 thresholds are exact distances, one margin covers the filter's error.  heuristic: the final
   // check needs the collected set to reach 2 eps beyond the threshold at every level.
   float eps_mult = heuristic ? 2.f : 1.f;

@@ -157,7 +157,7 @@ struct segvlad_ctx {
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
       s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
-      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn;
+      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -223,7 +223,7 @@ int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* B
 // distance of every query to database rows 0, b_stride, 2*b_stride, ... (n_sample of them); column j of
 // `dist` is sample j
 int sv_launch_l2_strided(segvlad_ctx* ctx, const float* Q, const float* R, float* dist, int M, int n_sample, int Kd,
-                         int64_t ldc, const float* qn, const float* rn, int b_stride);
+                         int64_t ldc, const float* qn, const float* rn, int b_stride, bool split_ok = false);
 // same distances, but entries <= thr[m*thr_ld] are appended to (cand_d2, cand_id)[m][0..cap) via cand_cnt[m]
 int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M, int n_sample, int Kd, const float* qn,
                         const float* rn, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,

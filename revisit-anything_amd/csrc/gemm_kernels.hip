@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     gemm_mainloop<MODE, true>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec, kbeg, kend);
   else
     gemm_mainloop<MODE, false>(acc, lds, A, Bm, a_sub, m0, n0, M, N, Kd, ldb, tid, vec, kbeg, kend);
-  if (MODE == 0 && gridDim.y > 1) C += (int64_t)blockIdx.y * M * ldc;
+  if (MODE != 2 && gridDim.y > 1) C += (int64_t)blockIdx.y * M * ldc;   // split-K: un-scaled partial tiles
 
   // ---- epilogue ---------------------------------------------------------------------------------
 #pragma unroll
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
           } else {
             const float v = sv_d2(row_add[row], cs, acc[mt][nt][r]);
             if (MODE == 1) {
-              C[row * ldc + col] = v;
+              C[row * ldc + col] = (gridDim.y > 1) ? acc[mt][nt][r] : v;
             } else if (v <= thr[row * thr_ld]) {
               const uint32_t slot = atomicAdd(&cand_cnt[row], 1u);
               if (slot < (uint32_t)cap) {
@@ -249,10 +249,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   out[j] = (col < N && col_scale) ? s * col_scale[col] : s;
 }
 
+// split-K reduction of a distance block: out = ||q||^2 + ||r||^2 - 2 * (sum_s part[s]), slices added in index order
+__global__ __launch_bounds__(256) void splitk_reduce_d2_kernel(const float* __restrict__ part, int splits, int M, int N, int64_t ldc,
+                                                               const float* __restrict__ row_add,
+                                                               const float* __restrict__ col_add, int b_stride,
+                                                               float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t mn = (int64_t)M * ldc;
+  if (j >= mn) return;
+  const int64_t row = j / ldc, col = j - row * ldc;
+  if (col >= N) return;
+  float s = part[j];
+  for (int t = 1; t < splits; ++t) s += part[(int64_t)t * mn + j];
+  out[j] = sv_d2(row_add[row], col_add[col * b_stride], s);
+}
+
 static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
                        int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
                        const float* col_add, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
-                       float* cand_d2, uint32_t* cand_id, int cap) {
+                       float* cand_d2, uint32_t* cand_id, int cap, bool split_d2 = false) {
   if (M <= 0 || N <= 0) return SEGVLAD_OK;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
@@ -265,8 +280,20 @@ static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* 
     k_per_split = (((Kd + splits - 1) / splits) + BK - 1) / BK * BK;
     splits = (Kd + k_per_split - 1) / k_per_split;
   }
+  // a handful of distance tiles (the sampled exact level of a single-image pass: 50 queries x 244 rows = 2 tiles whose
+  // 1024-deep fp32 k-loop is 90 us of pure latency): split K over 8-16 workgroups per tile.  Only where the caller allows
+  // it -- the distances then feed thresholds; the matrix path, whose sums are the reference for bit-identity, never splits.
+  const bool d2_split = split_d2 && mode == 1 && tiles <= 32 && Kd >= 16 * BK;
+  if (d2_split) {
+    splits = Kd / (4 * BK) < 16 ? Kd / (4 * BK) : 16;
+    k_per_split = (((Kd + splits - 1) / splits) + BK - 1) / BK * BK;
+    splits = (Kd + k_per_split - 1) / k_per_split;
+  }
   float* Cout = C;
-  if (splits > 1) {
+  if (splits > 1 && d2_split) {
+    SV_HIP(ctx->s_l0part.reserve((size_t)splits * M * ldc * sizeof(float)));
+    C = ctx->s_l0part.as<float>();
+  } else if (splits > 1) {
     SV_HIP(ctx->s_dist.reserve((size_t)splits * M * ldc * sizeof(float)));
     C = ctx->s_dist.as<float>();
   } else {
@@ -283,7 +310,12 @@ static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* 
     hipLaunchKernelGGL(gemm_nt_kernel<2>, SV_GEMM_ARGS);
 #undef SV_GEMM_ARGS
   SV_HIP(hipGetLastError());
-  if (splits > 1) {
+  if (splits > 1 && d2_split) {
+    const int64_t mn = (int64_t)M * ldc;
+    hipLaunchKernelGGL(splitk_reduce_d2_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, ctx->stream, C, splits, M, N, ldc,
+                       row_add, col_add, b_stride, Cout);
+    SV_HIP(hipGetLastError());
+  } else if (splits > 1) {
     const int64_t mn = (int64_t)M * ldc;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, ctx->stream, C, splits, mn, N, ldc,
                        col_scale, Cout);
@@ -300,9 +332,9 @@ int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* B
 }
 
 int sv_launch_l2_strided(segvlad_ctx* ctx, const float* Q, const float* R, float* dist, int M, int n_sample, int Kd,
-                         int64_t ldc, const float* qn, const float* rn, int b_stride) {
+                         int64_t ldc, const float* qn, const float* rn, int b_stride, bool split_ok) {
   return gemm_launch(ctx, 1, Q, R, dist, M, n_sample, Kd, ldc, nullptr, nullptr, qn, rn, b_stride, nullptr, 0, nullptr, nullptr,
-                     nullptr, 0);
+                     nullptr, 0, split_ok);
 }
 
 int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M, int n_sample, int Kd, const float* qn,
