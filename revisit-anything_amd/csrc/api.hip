@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <cmath>
+#include <mutex>
+#include <utility>
 
 #include "ctx.h"
 
@@ -97,6 +99,20 @@ StageScope::~StageScope() {
 #define CHECK_CTX()                 \
   if (!ctx) return SEGVLAD_ERR_ARG; \
   sv_begin(ctx)
+
+hipError_t sv_max_dyn_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> done;   // largest size granted so far
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find({dev, fn});
+  if (it != done.end() && it->second >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done[{dev, fn}] = bytes;
+  return e;
+}
 
 extern "C" {
 

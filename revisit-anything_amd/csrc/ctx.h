@@ -167,6 +167,10 @@ struct segvlad_ctx {
   int fail(int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
 };
 
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes), remembered per (device, kernel): the driver call takes a
+// lock and tens of microseconds; a launcher that repeats it before every launch leaves the GPU idle between kernels
+hipError_t sv_max_dyn_lds(const void* fn, size_t bytes);
+
 // ---- pointer staging ---------------------------------------------------------------------------
 bool sv_is_device_ptr(const void* p);
 // returns a device pointer holding `bytes` of *p (copy enqueued on ctx->stream if p is host memory)

@@ -278,7 +278,7 @@ static int launch_x3(segvlad_ctx* ctx, const uint16_t* A1, const uint16_t* A2, c
   const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
   auto kern = gemm_f16x3_kernel<BM, BN, WM, WN>;
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   // tile-block height of the XCD-aware order (0 = plain order, k-split in grid.y); measured: the plain order is ~8 %
   // faster here (probe_pca.py)
   int gm = ctx->opt.x3_gm > 0 ? ctx->opt.x3_gm : 0;
@@ -322,7 +322,7 @@ int sv_launch_gemm_f16x3_grouped(segvlad_ctx* ctx, const uint16_t* A1, const uin
   const int tiles_m = M_pad / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
   auto kern = gemm_f16x3_kernel<BM, BN, 4, 2>;
-  SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   // XCD-aware order (see the kernel): chunks of 32 / tiles_n row tiles, chunk c on XCD c % 8
   const int rows_per_chunk = 32 / tiles_n > 0 ? 32 / tiles_n : 1;
   const int chunks = (tiles_m + rows_per_chunk - 1) / rows_per_chunk;

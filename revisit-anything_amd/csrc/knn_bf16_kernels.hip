@@ -265,7 +265,7 @@ static int launch_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Q
   const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
   auto kern = knn_bf16_filter_kernel<BM, BN, WM, WN, DEPTH>;
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Ql, Rh, Rl, M, n_sample, d, b_stride,
                      tiles_m, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
   SV_HIP(hipGetLastError());
@@ -1005,7 +1005,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   }
   auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP>;
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
                      gm, seq_total, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
   SV_HIP(hipGetLastError());
@@ -1395,8 +1395,7 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
                        rpad, k, d2_out, idx_out);
   } else {
     if (lds > 64 * 1024)
-      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine_exact_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<true>), (size_t)lds));
     hipLaunchKernelGGL(refine_exact_kernel<true>, dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
                        rpad, k, d2_out, idx_out);
   }

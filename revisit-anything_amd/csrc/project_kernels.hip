@@ -243,8 +243,7 @@ int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* w
   if (lds > 160 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d, N=%d need %zu B of LDS", K, N, lds);
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(project_aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(project_aggregate_kernel), (size_t)lds));
   hipLaunchKernelGGL(project_aggregate_kernel, dim3((P + 255) / 256, B), dim3(512), lds, ctx->stream, Z, wmu, block_norms, gscale,
                      colmask, lab_off, rowbase, seg_off_dev, N, K, P, SC, maxt, col_scale, Y);
   SV_HIP(hipGetLastError());

@@ -239,8 +239,7 @@ int sv_launch_select_cand(segvlad_ctx* ctx, const uint32_t* cand_cnt, const floa
   const size_t lds = (size_t)cap * 8;
   if (lds > 128 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "select_cand: cap=%d exceeds the LDS sort", cap);
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_cand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(select_cand_kernel), (size_t)lds));
   hipLaunchKernelGGL(select_cand_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, k, d2_out,
                      idx_out, ovf_rows, ovf_count);
   SV_HIP(hipGetLastError());
@@ -298,8 +297,7 @@ int sv_launch_merge_topk(segvlad_ctx* ctx, const float* d2_parts, const int64_t*
   const size_t lds = (size_t)cpad * sizeof(KeyId);
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "merge: %d candidates per query exceed the LDS sort (max 8192)", cand);
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(merge_topk_kernel), (size_t)lds));
   hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), lds, ctx->stream, d2_parts, idx_parts, cand, cpad, k, d2_out,
                      idx_out);
   SV_HIP(hipGetLastError());

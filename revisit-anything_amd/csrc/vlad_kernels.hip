@@ -224,8 +224,7 @@ int sv_launch_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
   const size_t lds = (size_t)Hm * ((Wm + 31) / 32) * 4;
   if ((Wm % 16) == 0 && (reinterpret_cast<uintptr_t>(masks) & 15) == 0 && lds <= 150 * 1024) {
     if (lds > 64 * 1024)
-      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(incidence_fused_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(incidence_fused_kernel), (size_t)lds));
     hipLaunchKernelGGL(incidence_fused_kernel, dim3(S), dim3(256), lds, ctx->stream, masks, Hm, Wm, H, W, patch, dh, dw, sh, sw,
                        inc_bits, nw, centroids);
     SV_HIP(hipGetLastError());
@@ -398,8 +397,7 @@ int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg
   if (lds > 160 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "adjacency: %d segments in one image exceed the LDS budget (%zu B)", S_max, lds);
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adjacency_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(adjacency_kernel), (size_t)lds));
   hipLaunchKernelGGL(adjacency_kernel, dim3(B), dim3(256), lds, ctx->stream, cent, seg_off_dev, adj_off_dev, order, S_max,
                      adj, n_bad);
   SV_HIP(hipGetLastError());
@@ -808,7 +806,7 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
     return ctx->fail(SEGVLAD_ERR_LIMIT, "prep: (S_max=%d + K=%d) x %d token words needs %zu B of LDS (limit 160 KiB)", S_max,
                      K, nw, lds);
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(prep_kernel), (size_t)lds));
   hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, ctx->stream, labels, inc_bits, seg_off_dev, adj_off_dev, adj, N,
                      K, S_max, SC, colmask, gscale, ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(),
                      ctx->s_rnorm.as<float>(), ctx->s_rnsorted.as<float>());
@@ -1254,7 +1252,7 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
     if (big && N < TNK_LCAP) break;
     auto kern = big ? token_norms_kernel<true> : token_norms_kernel<false>;
     if (lds > 64 * 1024)
-      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
     hipLaunchKernelGGL(kern, dim3((K + TNK_WAVES - 1) / TNK_WAVES, B), dim3(64 * TNK_WAVES), lds, ctx->stream, xt,
                        ctx->s_rnsorted.as<float>(), ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres,
                        seg_off_dev, N, D, K, SC, Dpad, block_norms, xscale, reinterpret_cast<_Float16*>(h1),
@@ -1293,7 +1291,7 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* /*rnorm:
   }
 #endif
   if (lds > 64 * 1024)
-    SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   int kpb = ctx->opt.agg_kpb;   // clusters per workgroup
   if (kpb < 1) kpb = 1;
   hipLaunchKernelGGL(kern, dim3((K + kpb - 1) / kpb, B), dim3(nwaves * 64), lds, ctx->stream, xt, ctx->s_rnsorted.as<float>(),

@@ -251,8 +251,7 @@ int sv_launch_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, cons
     const int fast = Epad <= 4096 ? 1 : 0;   // + per-run fp64 sums (order-independent when exact, see the header)
     if (fast) lds = (size_t)Epad * 20;
     if (lds > 64 * 1024)
-      SV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vote_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(vote_kernel<false>), (size_t)lds));
     hipLaunchKernelGGL(vote_kernel<false>, dim3(n_img), dim3(VOTE_THREADS), lds, ctx->stream, idx, sims, img_of_seg, n_ref_seg, qoff_dev,
                        k, minmax_dev, n_top, mode, ctx->s_misc.as<Run>(), stride, pred, score, use_wl, E_LDS,
                        (const int32_t*)nullptr, (uint64_t*)nullptr, (int64_t)0, fast);
