@@ -327,6 +327,39 @@ def test_vote_golden_bit_exact(eng):
     assert pred.cpu().numpy()[0].tolist() == z["tie_pred"].tolist()
 
 
+def test_vote_long_runs_exact_and_inexact_sums_are_bit_identical(eng):
+    """The vote kernel adds an image's fp64 weights with LDS atomics when every weight of the run is 0 or in [2^-17, 1]
+    (all partial sums are then exact: the order cannot matter) and sequentially, in the reference's visiting order,
+    otherwise.  Three query images whose matches concentrate on a few reference images (runs of hundreds of entries):
+    (a) ordinary similarities, (b) the same with a handful of weights pushed below 2^-17 (the sums are no longer exact:
+    the sequential path must be taken, and only it reproduces the reference's rounding), (c) k = 3 short lists.  fp64
+    scores bit-identical to the oracle's python-float sums, ids identical."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    S, k, n_ref_img = 40, 50, 60
+    imInds = np.repeat(np.arange(n_ref_img), 20).astype(np.int32)              # 1200 reference segments
+    off = np.array([0, S, 2 * S, 2 * S + 3], np.int32)
+    nseg = int(off[-1])
+    matches = rng.integers(0, len(imInds), size=(nseg, k))
+    hot = rng.random((nseg, k)) < 0.8
+    matches = np.where(hot, rng.integers(0, 40, size=(nseg, k)), matches).astype(np.int64)   # 80 % on images 0 and 1
+    sims = rng.random((nseg, k)).astype(np.float32)
+    sims_tiny = sims.copy()
+    lo = float(sims.min())
+    flat = sims_tiny.reshape(-1)
+    pick = rng.choice(flat.size, size=12, replace=False)
+    flat[pick] = np.float32(lo) + np.float32(1e-6) * rng.random(12).astype(np.float32)       # weights ~1e-6 < 2^-17
+    segRange = [np.arange(off[i], off[i + 1]) for i in range(len(off) - 1)]
+    for sm in (sims, sims_tiny):
+        pred, sc = eng.vote(matches, sm, off, n_top=5, img_of_seg=imInds)
+        opred, rs = O().get_matches_wt_borda_im(matches, len(segRange), sm, segRange, imInds, n=5, return_scores=True)
+        got = sc.cpu().numpy()
+        for i, row in enumerate(rs):
+            assert np.array_equal(got[i][:len(row)], np.array(row)), i                         # bit-identical fp64 sums
+            assert pred.cpu().numpy()[i][:len(row)].tolist() == [int(p) for p in opred[i][:len(row)]]
+    w = (sims_tiny - sims_tiny.min()) / (sims_tiny.max() - sims_tiny.min())
+    assert ((w > 0) & (w < 2.0 ** -17)).sum() >= 8                                             # the case really is exercised
+
+
 def test_e2e_small_golden(eng):
     """recall_segloc chain on the device: normalise -> add -> search 200 -> keep 50 -> 2-d2 -> vote -> recall."""
     z = np.load(os.path.join(G, "e2e_small.npz"))
