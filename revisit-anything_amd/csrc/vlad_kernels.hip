@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ l
                                                    int N, int K, int S_max, int SC, uint64_t* __restrict__ colmask,
                                                    float* __restrict__ gscale, int32_t* __restrict__ tok_order,
                                                    int32_t* __restrict__ lab_off, const float* __restrict__ rnorm,
-                                                   float* __restrict__ rn_sorted) {
+                                                   float* __restrict__ rn_sorted, int stage, int ord_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   const int nw = (N + 63) >> 6;
@@ -717,17 +717,49 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ l
   uint64_t* inc2 = reinterpret_cast<uint64_t*>(smem);  // [S_max][nw]
   uint64_t* lbits = inc2 + (size_t)S_max * nw;         // [K][nw]
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < S * nw; idx += 256) {
-    const int s = idx / nw, w = idx - s * nw;
-    uint64_t v = 0;
-    if (adj) {
-      const uint8_t* a = adj + adj_off[b] + (size_t)s * S;
-      for (int u = 0; u < S; ++u)
-        if (a[u]) v |= inc[(size_t)(s0 + u) * nw + w];
-    } else {
-      v = inc[(size_t)(s0 + s) * nw + w];
+  if (adj && stage) {
+    // neighbour-union of the incidence rows, from LDS: the image's own rows and its adjacency (as bit rows) are staged
+    // with coalesced loads first -- walking the S adjacency bytes of a row in global memory with a conditional 8-B load
+    // behind each (S x nw x S dependent round trips spread over 256 threads) was 0.1 of this kernel's 0.16 ms
+    const int SW = (S_max + 63) >> 6;
+    uint64_t* inc0 = reinterpret_cast<uint64_t*>(reinterpret_cast<int*>(lbits + (size_t)K * nw) + ord_n);   // [S_max][nw]
+    uint64_t* nbr = inc0 + (size_t)S_max * nw;                                                                       // [S_max][SW]
+    for (int idx = tid; idx < S * nw; idx += 256) inc0[idx] = inc[(size_t)s0 * nw + idx];
+    for (int idx = tid; idx < S * SW; idx += 256) nbr[idx] = 0;
+    __syncthreads();
+    const uint8_t* a = adj + adj_off[b];
+    for (int e = tid; e < S * S; e += 256)
+      if (a[e]) {
+        const int s = e / S, u = e - s * S;
+        atomicOr(reinterpret_cast<unsigned long long*>(&nbr[s * SW + (u >> 6)]), 1ull << (u & 63));
+      }
+    __syncthreads();
+    for (int idx = tid; idx < S * nw; idx += 256) {
+      const int s = idx / nw, w = idx - s * nw;
+      uint64_t v = 0;
+      for (int uw = 0; uw < SW; ++uw) {
+        uint64_t m = nbr[s * SW + uw];
+        while (m) {
+          const int u = (uw << 6) + __builtin_ctzll(m);
+          m &= m - 1;
+          v |= inc0[u * nw + w];
+        }
+      }
+      inc2[idx] = v;
     }
-    inc2[idx] = v;
+  } else {
+    for (int idx = tid; idx < S * nw; idx += 256) {
+      const int s = idx / nw, w = idx - s * nw;
+      uint64_t v = 0;
+      if (adj) {
+        const uint8_t* a = adj + adj_off[b] + (size_t)s * S;
+        for (int u = 0; u < S; ++u)
+          if (a[u]) v |= inc[(size_t)(s0 + u) * nw + w];
+      } else {
+        v = inc[(size_t)(s0 + s) * nw + w];
+      }
+      inc2[idx] = v;
+    }
   }
   for (int idx = tid; idx < K * nw; idx += 256) lbits[idx] = 0;
   __syncthreads();
@@ -740,7 +772,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ l
   // token list, the tokens' 1/||x|| and their segment masks from CONTIGUOUS ranges instead of re-scanning all N
   // labels and gathering per token (one dependent global round trip instead of four)
   __shared__ int kcnt[257];
-  int* ord = reinterpret_cast<int*>(lbits + (size_t)K * nw);   // [N]
+  int* ord = reinterpret_cast<int*>(lbits + (size_t)K * nw);   // [ord_n >= max(N, S)]
   for (int k = tid; k < K; k += 256) {
     int c = 0;
     for (int w = 0; w < nw; ++w) c += __popcll(lbits[k * nw + w]);
@@ -782,15 +814,19 @@ __global__ __launch_bounds__(256) void prep_kernel(const uint8_t* __restrict__ l
     }
   }
   __syncthreads();
-  for (int s = tid; s < S; s += 256) {
-    int nnz = 0;
-    for (int k = 0; k < K; ++k) {
-      uint64_t any = 0;
-      for (int w = 0; w < nw; ++w) any |= inc2[s * nw + w] & lbits[k * nw + w];
-      nnz += (any != 0);
-    }
-    gscale[s0 + s] = nnz > 0 ? (float)(1.0 / sqrt((double)nnz)) : 0.f;
+  // number of non-empty (segment, cluster) blocks per segment: one thread per PAIR (a thread per segment walked K * nw
+  // word pairs alone while 200 threads idled), counted in the (now free) token-order array
+  int* nnz = ord;
+  for (int s = tid; s < S; s += 256) nnz[s] = 0;
+  __syncthreads();
+  for (int idx = tid; idx < S * K; idx += 256) {
+    const int s = idx / K, k = idx - s * K;
+    uint64_t any = 0;
+    for (int w = 0; w < nw; ++w) any |= inc2[s * nw + w] & lbits[k * nw + w];
+    if (any != 0) atomicAdd(&nnz[s], 1);
   }
+  __syncthreads();
+  for (int s = tid; s < S; s += 256) gscale[s0 + s] = nnz[s] > 0 ? (float)(1.0 / sqrt((double)nnz[s])) : 0.f;
 }
 
 int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_bits, const int32_t* seg_off_dev,
@@ -801,15 +837,21 @@ int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_
   SV_HIP(ctx->s_tokorder.reserve((size_t)B * N * sizeof(int32_t)));
   SV_HIP(ctx->s_laboff.reserve((size_t)B * (K + 1) * sizeof(int32_t)));
   SV_HIP(ctx->s_rnsorted.reserve((size_t)B * N * sizeof(float)));
-  const size_t lds = ((size_t)S_max + K) * nw * sizeof(uint64_t) + (size_t)N * sizeof(int);
+  const int ord_n = ((N > S_max ? N : S_max) + 1) & ~1;   // token order, later the per-segment block counts
+  size_t lds = ((size_t)S_max + K) * nw * sizeof(uint64_t) + (size_t)ord_n * sizeof(int);
   if (lds > 160 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "prep: (S_max=%d + K=%d) x %d token words needs %zu B of LDS (limit 160 KiB)", S_max,
                      K, nw, lds);
+  // staged neighbour union (the image's incidence rows + adjacency bit rows in LDS) when it fits beside the rest
+  const size_t lds_staged = ((size_t)S_max + K) * nw * 8 + (size_t)ord_n * 4 + (size_t)S_max * nw * 8 +
+                            (size_t)S_max * ((S_max + 63) / 64) * 8;
+  const int stage = (adj != nullptr && lds_staged <= 150 * 1024) ? 1 : 0;
+  if (stage) lds = lds_staged;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(prep_kernel), (size_t)lds));
   hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, ctx->stream, labels, inc_bits, seg_off_dev, adj_off_dev, adj, N,
                      K, S_max, SC, colmask, gscale, ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(),
-                     ctx->s_rnorm.as<float>(), ctx->s_rnsorted.as<float>());
+                     ctx->s_rnorm.as<float>(), ctx->s_rnsorted.as<float>(), stage, ord_n);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

@@ -717,6 +717,25 @@ def test_pca_f16_split_path_is_fp32_class(eng):
     assert (1 - cos).max() < 5e-7   # fp32 outputs: the cosine itself is only resolved to ~1e-7
 
 
+def test_seg_vlad_more_segments_than_tokens(eng):
+    """S > N (70 segments over 48 tokens): the per-image scratch that first holds the token order and then the
+    per-segment block counts must be sized by the larger of the two."""
+    D, K, N = 64, 8, 48
+    C = synth().make_vocab(K, D, seed=291)
+    rng = np.random.Generator(np.random.PCG64(292))
+    toks, incs, adjs = [], [], []
+    for b, S in enumerate([70, 3]):
+        toks.append(synth().make_tokens(C, N, seed=2950 + b, noise=0.3))
+        incs.append(rng.random((S, N)) < 0.2)
+        adjs.append(np.eye(S, dtype=bool) | (rng.random((S, S)) < 0.1))
+    eng.set_vocab(C)
+    offs = np.concatenate([[0], np.cumsum([i.shape[0] for i in incs])]).astype(np.int32)
+    bits = np.concatenate([O().pack_bits_u64(i) for i in incs]).view(np.int64)
+    out = eng.seg_vlad(np.stack(toks), bits, offs, cat_adj(adjs))["out"].cpu().numpy()
+    ref = np.concatenate([O().seg_vlad(toks[b], incs[b], C, adjs[b]) for b in range(2)])
+    assert np.abs(out - ref).max() < 2e-6
+
+
 def test_images_pca_project_form_big_clusters_and_partial_chunk(eng):
     """The "project then aggregate" form of segvlad_images_pca where its token kernel leaves the common case: a cluster
     holding >= 256 tokens of one image (lists read from global memory), D = 96 (a partial 128-column chunk), S > 64
