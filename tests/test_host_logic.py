@@ -129,3 +129,39 @@ def test_synth_generators_are_seed_stable():
     assert np.allclose(np.linalg.norm(synth.make_tokens(C, 10, seed=2), axis=0), 1, atol=1e-6)
     R, img = synth.make_planted_db(8, 3, 16, seed=3)
     assert R.shape == (24, 16) and img.tolist()[:4] == [0, 0, 0, 1]
+
+
+def test_pipeline_falls_back_to_qhull_when_the_device_adjacency_declines():
+    """SegVLADPipeline.describe: a device adjacency that reports a non-generic centroid configuration ("degenerate") or
+    more segments than its LDS holds ("LDS budget") is replaced, for that batch, by the reference's Qhull path; any other
+    error propagates.  (Stub engine: this is host control flow.)"""
+    import pytest
+
+    from revisit_anything_amd._lib import SegVLADError
+    from revisit_anything_amd.pipeline import SegVLADPipeline
+
+    cent = np.array([[10.0, 10.0], [30.0, 10.0], [30.0, 22.0], [10.0, 22.0], [55.0, 60.0]])   # 4 co-circular + 1
+    offs = np.array([0, 5], np.int32)
+
+    class Stub:
+        def __init__(self, msg):
+            self.msg, self.got_adj = msg, None
+
+        def incidence_centroids(self, masks, H, W, patch):
+            return "bits", torch.from_numpy(cent)
+
+        def adjacency(self, c, so, order, check_empty=False):
+            raise SegVLADError(self.msg)
+
+        def seg_vlad(self, tokens, bits, so, adj):
+            self.got_adj = np.asarray(adj)
+            return {"out": "desc"}
+
+    for msg in ("adjacency: 1 image(s) with a degenerate centroid configuration", "adjacency: 700 segments exceed the LDS budget"):
+        st = Stub(msg)
+        out = SegVLADPipeline(st, 112, 140, order=1, use_pca=False).describe("tok", "masks", offs)
+        assert out == "desc"
+        want = O.adjacency_from_centroids(cent, 1).astype(np.uint8).reshape(-1)
+        assert np.array_equal(st.got_adj, want)                     # Qhull's choice, not the device kernel's
+    with pytest.raises(SegVLADError):
+        SegVLADPipeline(Stub("hipErrorLaunchFailure"), 112, 140, order=1, use_pca=False).describe("tok", "masks", offs)
