@@ -1157,6 +1157,8 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
     }
   }
   const int64_t grow0 = rowbase[(size_t)b * K + k];
+  const size_t nkb_d = (size_t)(D >> 5);
+  const size_t ob_dummy = sv_x3_off(dummy_row < 0 ? -dummy_row : dummy_row, (4 * i) % D, D);
   const float* Xb = Xt + (size_t)b * N * D;
 
   for (int sc = 0; sc < SCb; ++sc) {
@@ -1196,6 +1198,8 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
       const int dcol = dc * 128 + 4 * i;
       const bool dvalid = dcol < D;
       const f32x4 c4 = lds_read_f32x4(lds_addr(cl + dcol));
+      const size_t kb_dc = (size_t)(dcol >> 5);                       // k-block of this lane's four columns
+      const unsigned lane_c = (unsigned)((dcol & 31) >> 3), lane_o = (unsigned)(dcol & 7);
       for (int p = 0; p < npairs; ++p, ++f) {
         const int j = 2 * p + kk;
         float rn = 0.f;
@@ -1208,10 +1212,17 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
         // ops issued after step f's DMA: min(QD - 1, rem) later DMAs and, on the first segment chunk, two plane stores for
         // each of the last min(QD, f) steps (always issued: lanes without a valid element write the dummy row)
         const int rem = total - 1 - f;
-        if (single && dummy_row >= 0)
-          tnk_wait_vm((rem < TNK_QD - 1 ? rem : TNK_QD - 1) + (sc == 0 ? 2 * (f < TNK_QD ? f : TNK_QD) : 0));
-        else
+        if (single && dummy_row >= 0) {
+          // steady state (a full queue behind and ahead): the count is the constant QD - 1 (+ 2 QD plane stores)
+          if (f >= TNK_QD && rem >= TNK_QD - 1) {
+            if (sc == 0) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+          } else {
+            tnk_wait_vm((rem < TNK_QD - 1 ? rem : TNK_QD - 1) + (sc == 0 ? 2 * (f < TNK_QD ? f : TNK_QD) : 0));
+          }
+        } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // list entries come from global memory on this path
+        }
         if (single)
           lds_step_read(lds_addr(qbase + (f % TNK_QD) * 1024 + l * 16), lds_addr(rnl + j), lds_addr(mskl + j), x, rn, m);
         else
@@ -1231,7 +1242,10 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
             p2[e] = (_Float16)(fv[e] - (float)p1[e]);
           }
           const bool real = dvalid && j < n;
-          const size_t ob = real ? sv_x3_off(grow0 + j, dcol, D) : sv_x3_off(dummy_row < 0 ? -dummy_row : dummy_row, (4 * i) % D, D);
+          // sv_x3_off(grow0 + j, dcol, D) with the lane / chunk constants of this 128-column chunk taken out of the loop
+          const unsigned rr = (unsigned)(grow0 + j);
+          const size_t ob = real ? ((size_t)(rr >> 7) * nkb_d + kb_dc) * 4096 + (size_t)(((rr & 127u) << 5) + (((lane_c ^ ((rr >> 2) & 3u)) << 3) | lane_o))
+                                 : ob_dummy;
           *reinterpret_cast<h4*>(h1 + ob) = p1;
           *reinterpret_cast<h4*>(h2 + ob) = p2;
         }
