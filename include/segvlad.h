@@ -197,16 +197,18 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning   */
 int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
 
-/* ---- statistics of the last segvlad_search on this context (HOST array, up to 9 values):
+/* ---- statistics of the last segvlad_search on this context (HOST array, up to 10 values):
  *      [0] filter levels run after the sampled exact level (0 = distance-matrix path)
  *      [1] filter arithmetic used (0 none, 1 f16, 2 bf16x3, 3 fp32)
- *      [2] query rows whose candidate / refine list overflowed and that were redone, alone, on the
+ *      [2] query rows whose candidate list overflowed and that were redone, as one dense batch, on the
  *          exact distance-matrix path (the other rows keep their filtered result)
  *      [3] max and [4] sum of the last level's candidate-list lengths   (option search_stats = 1)
  *      [5] max and [6] sum of the exact-refinement list lengths         (option search_stats = 1)
  *      [7] number of query rows
  *      [8] query rows whose low-rank ("heuristic") level thresholds did not verify and that were redone
- *          with the rigorous k-th-rank thresholds (option knn_heuristic = 0 disables the low-rank thresholds) */
+ *          with the rigorous k-th-rank thresholds (option knn_heuristic = 0 disables the low-rank thresholds)
+ *      [9] query rows whose refine band held more rows than the first-tier list (512) and that were refined
+ *          from their whole candidate list instead (second tier; temporally redundant databases)            */
 int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n);
 
 #ifdef __cplusplus

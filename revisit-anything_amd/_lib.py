@@ -11,6 +11,8 @@ c_ctx_p = C.c_void_p
 _f32p = C.c_void_p  # all bulk pointers are passed as raw addresses (host or device)
 
 SEGVLAD_OK = 0
+# error codes of include/segvlad.h (SegVLADError.code)
+SEGVLAD_ERR_ARG, SEGVLAD_ERR_HIP, SEGVLAD_ERR_STATE, SEGVLAD_ERR_LIMIT, SEGVLAD_ERR_NOMEM = -1, -2, -3, -4, -5
 VOTE_WT_BORDA_IM = 0
 VOTE_COUNT = 1
 
@@ -57,7 +59,17 @@ _lib = None
 
 
 class SegVLADError(RuntimeError):
-    pass
+    """A failed C-ABI call.  ``code`` is the library's return value (SEGVLAD_ERR_*; None when the failure happened on
+    the Python side): callers branch on the CODE / the exception TYPE, never on the wording of the message."""
+
+    def __init__(self, msg: str = "", code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+class SegVLADDegenerateError(SegVLADError):
+    """The device Delaunay met a non-generic centroid configuration (duplicate or co-circular centroids): the
+    triangulation is then a matter of Qhull's tie-breaking, and the caller should take the reference's Qhull path."""
 
 
 def lib_path() -> str:

@@ -80,7 +80,7 @@ int sv_finish(segvlad_ctx* ctx) {
 }
 
 StageScope::StageScope(segvlad_ctx* c, const char* name) : ctx(c) {
-  if (!c->profiling) return;
+  if (!c->profiling || c->scope_mute) return;
   t = &c->timers[name];
   if (t->used * 2 >= (int)t->ev.size()) {
     hipEvent_t a = nullptr, b = nullptr;
@@ -191,8 +191,8 @@ int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n) {
   if (!ctx) return SEGVLAD_ERR_ARG;
   if (!stats_out || n < 0) return ctx->fail(SEGVLAD_ERR_ARG, "search_stats: bad arguments");
   const SvSearchStats& t = ctx->sstats;
-  const int64_t v[9] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo};
-  for (int j = 0; j < n && j < 9; ++j) stats_out[j] = v[j];
+  const int64_t v[10] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo, t.n_refine2};
+  for (int j = 0; j < n && j < 10; ++j) stats_out[j] = v[j];
   return SEGVLAD_OK;
 }
 
@@ -210,7 +210,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_laboff,  &ctx->s_rnsorted, &ctx->s_ovf,   &ctx->s_fb_q,   &ctx->s_fb_d2,  &ctx->s_fb_idx,
                     &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
                     &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys, &ctx->s_pz, &ctx->s_rowbase,
-                    &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part};
+                    &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part, &ctx->s_rovf,   &ctx->s_ref_lim};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -853,7 +853,7 @@ static int heur_rank(int target) {
 // q16a / q16b: this chunk's 16-bit query planes (f16: plane, unused; bf16x3: hi, lo).  fail_rows [m] / fail_count: flags.
 static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, const float* qp, const uint16_t* q16a,
                         const uint16_t* q16b, const float* qn, int m, float* out_d2, int64_t* out_idx, uint32_t* fail_rows,
-                        uint32_t* fail_count) {
+                        uint32_t* fail_count, uint32_t* n_fail_host) {
   const int d = pl.d, k = pl.k, levels = pl.levels;
   const int64_t n = pl.n;
   const float* R = ctx->db_rows.as<float>();
@@ -865,6 +865,16 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   const int64_t n0 = (n + pl.stride0 - 1) / pl.stride0;
   const int64_t ld0 = (n0 + 3) & ~3ll;
   float* thr = ctx->s_thr_d2.as<float>();
+  // second refinement tier (filters with an approximate domain only): [m] row flags + 1 count, [m] band limits
+  uint32_t* rovf_rows = nullptr;
+  float* ref_lim = nullptr;
+  if (pl.kind != 3) {
+    SV_HIP(ctx->s_rovf.reserve(((size_t)m + 1) * 4));
+    SV_HIP(ctx->s_ref_lim.reserve((size_t)m * 4));
+    SV_HIP(hipMemsetAsync(ctx->s_rovf.p, 0, ((size_t)m + 1) * 4, ctx->stream));
+    rovf_rows = ctx->s_rovf.as<uint32_t>();
+    ref_lim = ctx->s_ref_lim.as<float>();
+  }
   const int r0 = rank[0];
   {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
@@ -933,12 +943,29 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
       StageScope sc(ctx, "knn_select");
       SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
                                      SV_CAP, rank[lv], last ? 1 : 0, heuristic ? 1 : 0, thr_ptr, thr_ld, qn, pl.c_eps, pl.rn_max, thr,
-                                     ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count));
+                                     ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count,
+                                     rovf_rows, rovf_rows + m, ref_lim));
       sc.count();
       if (last) {
         SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, k,
                                       out_d2, out_idx));
         sc.count();
+        // one read-back per chunk: rows flagged for the redo / matrix-path fallback (handled by the caller) and rows whose
+        // refine band outgrew the first-tier list.  The latter are refined here, straight from their candidate lists,
+        // which the next chunk would overwrite.
+        uint32_t h_cnt[2] = {0, 0};
+        SV_HIP(hipMemcpyAsync(&h_cnt[0], fail_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SV_HIP(hipMemcpyAsync(&h_cnt[1], rovf_rows + m, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SV_HIP(hipStreamSynchronize(ctx->stream));
+        if (n_fail_host) *n_fail_host = h_cnt[0];
+        if (h_cnt[1]) {
+          SV_TRY(sv_launch_refine2_compact(ctx, rovf_rows, ref_lim, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
+                                           ctx->s_cand_id.as<uint32_t>(), m, SV_CAP));
+          SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP,
+                                        k, out_d2, out_idx, rovf_rows));
+          sc.count(2);
+          ctx->sstats.n_refine2 += h_cnt[1];
+        }
         if (ctx->opt.search_stats) {
           hcnt.resize(m);
           SV_HIP(hipStreamSynchronize(ctx->stream));
@@ -968,6 +995,10 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
       sc.count();
       thr_ptr = thr + (k - 1);
       thr_ld = k;
+      if (last && n_fail_host) {
+        SV_HIP(hipMemcpyAsync(n_fail_host, fail_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SV_HIP(hipStreamSynchronize(ctx->stream));
+      }
     }
   }
   return SEGVLAD_OK;
@@ -996,8 +1027,12 @@ static int fallback_rows(segvlad_ctx* ctx, const SearchPlan& pl, const float* q,
   hipLaunchKernelGGL(gather_rows_kernel, dim3(nf), dim3(256), 0, ctx->stream, q, qn, ctx->s_fb_rows.as<int32_t>(), d, fq, fqn);
   SV_HIP(hipGetLastError());
   {
-    StageScope sc(ctx, "knn_fallback");
-    SV_TRY(search_matrix(ctx, fq, nf, pl.n, d, k, fqn, ctx->s_fb_d2.as<float>(), ctx->s_fb_idx.as<int64_t>()));
+    StageScope sc(ctx, "knn_fallback");   // one stage (the matrix path's own scopes are muted: no double counting)
+    const bool was_muted = ctx->scope_mute;
+    ctx->scope_mute = true;
+    const int rc = search_matrix(ctx, fq, nf, pl.n, d, k, fqn, ctx->s_fb_d2.as<float>(), ctx->s_fb_idx.as<int64_t>());
+    ctx->scope_mute = was_muted;
+    SV_TRY(rc);
     sc.count(nf);
   }
   hipLaunchKernelGGL(scatter_topk_kernel, dim3(nf), dim3(256), 0, ctx->stream, ctx->s_fb_d2.as<float>(), ctx->s_fb_idx.as<int64_t>(),
@@ -1094,6 +1129,9 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     return ldexpf(1.f, 14 - e);
   };
   float qscale = 1.f;
+  // per-query scratch is sized for the rows of one chunk -- min(nq, SV_CHUNK), not SV_CHUNK: a one-image search on a large
+  // index used to allocate > 1 GiB of candidate lists (the buffers only ever grow, so a later large batch re-allocates once)
+  const size_t mrows = (size_t)std::min(nq, SV_CHUNK);
   if (f16_path || bf16_path) {
     if (ctx->db_rn_max_rows < n) {
       float m = 0.f;
@@ -1102,8 +1140,8 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       ctx->db_rn_max_rows = n;
     }
     pl.rn_max = ctx->db_rn_max;
-    SV_HIP(ctx->s_ref_cnt.reserve((size_t)SV_CHUNK * 4));
-    SV_HIP(ctx->s_ref_id.reserve((size_t)SV_CHUNK * SV_RCAP * 4));
+    SV_HIP(ctx->s_ref_cnt.reserve((size_t)mrows * 4));
+    SV_HIP(ctx->s_ref_id.reserve((size_t)mrows * SV_RCAP * 4));
   }
   if (f16_path) {
     if (ctx->db_f16_rows < n) {
@@ -1126,8 +1164,8 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_HIP(ctx->s_qf16.reserve((size_t)nq * d * 2));
     SV_TRY(sv_launch_to_f16(ctx, (const float*)dq, (int64_t)nq * d, qscale, ctx->s_qf16.as<uint16_t>()));
     pl.inv_scale = 1.f / (qscale * ctx->db_f16_scale);
-    // |d2~ - d2| <= 2 * (2^-10 + 2^-22 + 2*d*2^-24) * ||q|| * ||r||   (+25 % slack)
-    pl.c_eps = 2.5f * (1.f / 1024.f + 1.f / 4194304.f + 2.f * (float)d / 16777216.f);
+    // |d2~ - d2| <= c_eps ||q|| ||r||: ctx.h, sv_f16_c_eps (the constant of the kernel variant that will run)
+    pl.c_eps = sv_f16_c_eps(d, sv_f16_kblock(ctx->opt, d));
   } else if (bf16_path) {
     // lazily extend the bf16 planes to the rows added since the last search
     if (ctx->db_split_rows < n) {
@@ -1144,13 +1182,13 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_HIP(ctx->s_ql.reserve((size_t)nq * d * 2));
     SV_TRY(sv_launch_split_bf16(ctx, (const float*)dq, (int64_t)nq * d, ctx->s_qh.as<uint16_t>(), ctx->s_ql.as<uint16_t>()));
   }
-  SV_HIP(ctx->s_cand_cnt.reserve((size_t)SV_CHUNK * 4));
-  SV_HIP(ctx->s_cand_d2.reserve((size_t)SV_CHUNK * SV_CAP * 4));
-  SV_HIP(ctx->s_cand_id.reserve((size_t)SV_CHUNK * SV_CAP * 4));
-  SV_HIP(ctx->s_thr_d2.reserve((size_t)SV_CHUNK * k * 4));
-  SV_HIP(ctx->s_thr_idx.reserve((size_t)SV_CHUNK * k * 8));
+  SV_HIP(ctx->s_cand_cnt.reserve(mrows * 4));
+  SV_HIP(ctx->s_cand_d2.reserve(mrows * SV_CAP * 4));
+  SV_HIP(ctx->s_cand_id.reserve(mrows * SV_CAP * 4));
+  SV_HIP(ctx->s_thr_d2.reserve(mrows * k * 4));
+  SV_HIP(ctx->s_thr_idx.reserve(mrows * k * 8));
   const int64_t n0 = (n + pl.stride0 - 1) / pl.stride0;
-  SV_HIP(ctx->s_dist.reserve((size_t)SV_CHUNK * ((n0 + 3) & ~3ll) * 4));
+  SV_HIP(ctx->s_dist.reserve(mrows * ((n0 + 3) & ~3ll) * 4));
   // Flags: [nq] rows + 1 count.  A heuristic pass flags the queries whose low-rank thresholds did not verify (-> redo
   // with the rigorous thresholds, below); a rigorous pass flags list overflows (-> exact distance-matrix path, alone).
   plh.c_eps = pl.c_eps;
@@ -1163,16 +1201,14 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   auto plane_a = [&](const DevBuf& f16, const DevBuf& hi, int64_t q0) -> const uint16_t* {
     return (pl.kind == 1 ? reinterpret_cast<const uint16_t*>(f16.p) : reinterpret_cast<const uint16_t*>(hi.p)) + (size_t)q0 * d;
   };
+  uint32_t n_flag = 0;   // running count of the flagged rows, read back by every chunk (levels_chunk synchronises once)
   for (int q0 = 0; q0 < nq; q0 += SV_CHUNK) {
     const int m = (nq - q0 < SV_CHUNK) ? (nq - q0) : SV_CHUNK;
     SV_TRY(levels_chunk(ctx, heuristic ? plh : pl, heuristic, (const float*)dq + (size_t)q0 * d,
                         pl.kind == 3 ? nullptr : plane_a(ctx->s_qf16, ctx->s_qh, q0),
                         pl.kind == 2 ? ctx->s_ql.as<uint16_t>() + (size_t)q0 * d : nullptr, qn + q0, m, (float*)dd2 + (size_t)q0 * k,
-                        (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count));
+                        (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count, &n_flag));
   }
-  uint32_t n_flag = 0;
-  SV_HIP(hipMemcpyAsync(&n_flag, flag_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-  SV_HIP(hipStreamSynchronize(ctx->stream));
   if (n_flag && !heuristic) {
     int nf = 0;
     SV_TRY(fallback_rows(ctx, pl, (const float*)dq, qn, flag_rows, nq, (float*)dd2, (int64_t*)didx, &nf));
@@ -1207,17 +1243,20 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       SV_TRY(sv_launch_split_bf16(ctx, rq, (int64_t)nr * d, ctx->s_rd_p1.as<uint16_t>(), ctx->s_rd_p2.as<uint16_t>()));
     }
     uint32_t* rflags = ctx->s_rd_flags.as<uint32_t>();
+    uint32_t n_ovf = 0;
     for (int q0 = 0; q0 < nr; q0 += SV_CHUNK) {
       const int m = (nr - q0 < SV_CHUNK) ? (nr - q0) : SV_CHUNK;
-      StageScope sc(ctx, "knn_redo");
-      SV_TRY(levels_chunk(ctx, pl, false, rq + (size_t)q0 * d, ctx->s_rd_p1.as<uint16_t>() + (size_t)q0 * d,
-                          pl.kind == 2 ? ctx->s_rd_p2.as<uint16_t>() + (size_t)q0 * d : nullptr, rqn + q0, m,
-                          ctx->s_rd_d2.as<float>() + (size_t)q0 * k, ctx->s_rd_idx.as<int64_t>() + (size_t)q0 * k, rflags + q0, rflags + nr));
+      StageScope sc(ctx, "knn_redo");   // the whole redo is ONE stage: its inner level / filter / select scopes are muted,
+      ctx->scope_mute = true;           // so "knn_gemm" etc. keep describing the main pass only (no double counting)
+      const int rc = levels_chunk(ctx, pl, false, rq + (size_t)q0 * d, ctx->s_rd_p1.as<uint16_t>() + (size_t)q0 * d,
+                                  pl.kind == 2 ? ctx->s_rd_p2.as<uint16_t>() + (size_t)q0 * d : nullptr, rqn + q0, m,
+                                  ctx->s_rd_d2.as<float>() + (size_t)q0 * k, ctx->s_rd_idx.as<int64_t>() + (size_t)q0 * k, rflags + q0,
+                                  rflags + nr, &n_ovf);
+      ctx->scope_mute = false;
+      SV_TRY(rc);
       sc.count(m);
     }
-    uint32_t n_ovf = 0;
-    SV_HIP(hipMemcpyAsync(&n_ovf, rflags + nr, 4, hipMemcpyDeviceToHost, ctx->stream));
-    SV_HIP(hipStreamSynchronize(ctx->stream));   // also: rows[] lives on this frame
+    SV_HIP(hipStreamSynchronize(ctx->stream));   // rows[] lives on this frame
     if (n_ovf) {
       int nf = 0;
       SV_TRY(fallback_rows(ctx, pl, rq, rqn, rflags, nr, ctx->s_rd_d2.as<float>(), ctx->s_rd_idx.as<int64_t>(), &nf));

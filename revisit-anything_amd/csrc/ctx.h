@@ -102,6 +102,26 @@ struct SvOptions {
   int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
 };
 
+// fp16 filter of the exact kNN: length of the accumulation blocks (0 = one running fp32 accumulator over the whole row).
+// Rows of d >= 4096 (raw K*D descriptors) take the blocked kernel (option f16_cfg = 300 forces it for any d, any other
+// explicit f16_cfg switches it off); the error constant below must describe the kernel that actually runs.
+constexpr int SV_F16_KBLOCK = 1024;
+inline int sv_f16_kblock(const SvOptions& o, int d) {
+  if (o.f16_cfg == 300) return SV_F16_KBLOCK;
+  return (o.f16_cfg < 0 && d >= 4096) ? SV_F16_KBLOCK : 0;
+}
+// |d2~ - d2| <= sv_f16_c_eps * ||q|| * ||r|| for the single-product fp16 filter (25 % slack included):
+//   2^-10        both operands rounded to fp16 (relative 2^-11 each; products of two fp16 are exact in fp32),
+//   2^-22        power-of-two scaling, sub-normal operands, second-order terms,
+//   accumulation one running accumulator: <= 2 roundings per product, 2 d 2^-24;
+//                blocked (kb > 0): 2 kb 2^-24 inside a block -- whatever order the matrix pipe sums a k-step in -- plus
+//                (d / kb + 1) 2^-24 for the fp32 additions of the block sums,
+// all relative to sum_i |q_i r_i| <= ||q|| ||r||; the factor 2 turns the error of the dot product into that of d2.
+inline float sv_f16_c_eps(int d, int kb) {
+  const float acc = kb > 0 ? (2.f * (float)kb + (float)((d + kb - 1) / kb) + 1.f) / 16777216.f : 2.f * (float)d / 16777216.f;
+  return 2.5f * (1.f / 1024.f + 1.f / 4194304.f + acc);
+}
+
 // statistics of the last segvlad_search (segvlad_search_stats)
 struct SvSearchStats {
   int64_t levels = 0;           // filter levels after the sampled exact level (0 = matrix path)
@@ -113,6 +133,7 @@ struct SvSearchStats {
   int64_t refine_sum = 0;       // sum of refine-list lengths (search_stats only)
   int64_t n_queries = 0;
   int64_t n_redo = 0;           // query rows whose heuristic thresholds did not verify and that were redone rigorously
+  int64_t n_refine2 = 0;        // query rows whose refine band exceeded the first-tier list (SV_RCAP) and took the second tier
 };
 
 struct segvlad_ctx {
@@ -120,6 +141,7 @@ struct segvlad_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   bool profiling = false;
+  bool scope_mute = false;   // set while a redo / fallback pass runs: its inner stages are part of "knn_redo" / "knn_fallback" only
   std::map<std::string, StageTimer> timers;
   SvOptions opt;
   SvSearchStats sstats;
@@ -157,7 +179,8 @@ struct segvlad_ctx {
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
       s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
-      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part;
+      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part,
+      s_rovf, s_ref_lim;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -245,9 +268,17 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
                             float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
-                            uint32_t* fail_rows, uint32_t* fail_count);
+                            uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows = nullptr, uint32_t* rovf_count = nullptr,
+                            float* ref_lim = nullptr);
+// rovf_rows / rovf_count / ref_lim (mode 1): a refine band longer than rcap marks its row there (with the band's upper limit)
+// instead of in fail_rows: sv_launch_refine2_compact + sv_launch_refine_exact(..., rcap = cap, only_rows = rovf_rows)
+// then refine it straight from the candidate list.
+int sv_launch_refine2_compact(segvlad_ctx* ctx, const uint32_t* rovf_rows, const float* ref_lim, uint32_t* cand_cnt,
+                              const float* cand_d2, uint32_t* cand_id, int nq, int cap);
+// only_rows != null: rows whose flag is clear are skipped (their outputs stay as they are)
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
-                           const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out);
+                           const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
+                           const uint32_t* only_rows = nullptr);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);
 // gemm_f16x3_kernels.hip

@@ -385,7 +385,11 @@ __device__ __forceinline__ float acc_elem(const f32x16& v, int r) {
 //      into PP phases of [load segment: LDS fragment reads + DMA issue][barrier][MFMA segment][barrier], and the second
 //      half of the waves (the SIMD partners of the first half: waves w and w + NW/2 share a SIMD) runs one barrier
 //      behind, so that on every SIMD one wave feeds the matrix pipe while its partner reads LDS and issues DMA.
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0>
+// KBT: > 0 = BLOCKED accumulation (deep rows, e.g. raw K*D = 98 304-d descriptors): every KBT k-tiles the MFMA accumulators
+//      are added into a second register set and cleared, so that the fp32 accumulation error of a dot product is bounded
+//      by (2 KBT HBK + d / (KBT HBK)) 2^-24 sum|q_i r_i| instead of 2 d 2^-24 sum|q_i r_i| -- whatever the matrix pipe's
+//      internal summation order is (see sv_f16_c_eps).  Needs the plain loop (PP == 0) and 2 x TM x TN x 16 accumulators.
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total,
@@ -396,6 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   constexpr int AUXA = (POL & 2) ? 2 : 0, AUXB = (POL & 1) ? 2 : 0;   // aux = 2: "nt" (streaming) hint
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr bool ACC_A = TM * TN > 8;   // 256 accumulator registers per lane: they live in AGPRs (see acc_elem)
+  static_assert(KBT == 0 || (PP == 0 && !ACC_A), "blocked accumulation: plain loop, two accumulator sets in VGPRs");
   constexpr int RB = HBK * 2;            // row bytes per k-tile
   constexpr int CH = RB / 16;            // 16-B chunks per row (4 or 8)
   constexpr int RP = 1024 / RB;          // rows per 1-KiB DMA piece
@@ -493,6 +498,15 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  f32x16 accb[KBT > 0 ? TM : 1][KBT > 0 ? TN : 1];   // blocked accumulation: the sum of the finished k-blocks
+  if (KBT > 0) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[KBT > 0 ? a : 0][KBT > 0 ? b : 0][r] = 0.f;
+  }
 
   // epilogue inputs, requested now so that their latency hides under the main loop (one workgroup per CU: nothing
   // else would cover it): row tid's ||q||^2 and threshold, this lane's column norms
@@ -751,6 +765,17 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       __builtin_amdgcn_s_barrier();
       ia ^= 1;
       ib = (ib + 1 >= NB) ? 0 : ib + 1;
+      if (KBT > 0 && ((kt + 1) % (KBT > 0 ? KBT : 1) == 0 || kt + 1 == ntiles)) {   // close a k-block (wave-uniform)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              accb[KBT > 0 ? mt : 0][KBT > 0 ? nt : 0][r] += acc[mt][nt][r];
+              acc[mt][nt][r] = (kt + 1 == ntiles) ? accb[KBT > 0 ? mt : 0][KBT > 0 ? nt : 0][r] : 0.f;   // last block: acc = the total
+            }
+      }
     }
   }
 
@@ -971,7 +996,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   }   // tile loop
 }
 
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0>
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1003,7 +1028,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT>;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -1025,8 +1050,13 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   // k-tile) -> 21.9, 255 (55 + persistent) -> 22.1, against 20.9-21.1 for 250 in the same sessions: with one wave per SIMD
   // nothing covers the per-tile barrier and the epilogue, and the kernel sits at the same power-limited clock either way.
   // streaming regime (M <= 128, e.g. one 50-segment query image per pass over 1 M rows): 2 -> 0.41 ms, 3 -> 0.51 ms
-  const int c = ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : M > 64 ? 63 : 62);
+  // deep rows (raw K*D descriptors, d >= 4096): blocked accumulation (configuration 300), which is what keeps the
+  // filter's error margin -- and with it the refine band -- as tight as at d = 1024 (sv_f16_c_eps)
+  const int c = sv_f16_kblock(ctx->opt, d) ? 300 : ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : M > 64 ? 63 : 62);
   switch (c) {
+    case 300:   // 4 waves of 64 x 64, two accumulator sets, a k-block of SV_F16_KBLOCK = 16 k-tiles of 64
+      static_assert(SV_F16_KBLOCK == 16 * 64, "k-block = KBT x HBK");
+      return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 0, 16>(SV_F16_ARGS);
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
     case 200:   // persistent workgroups that request the next tile's head before their epilogue
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
@@ -1140,7 +1170,10 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ ref_id, int rcap,
                                                             uint32_t* __restrict__ ovf_rows,
                                                             uint32_t* __restrict__ ovf_count,
-                                                            const uint32_t* __restrict__ todo) {
+                                                            const uint32_t* __restrict__ todo,
+                                                            uint32_t* __restrict__ rovf_rows,
+                                                            uint32_t* __restrict__ rovf_count,
+                                                            float* __restrict__ ref_lim) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);  // [cap]
   __shared__ uint32_t hist[256];
@@ -1211,7 +1244,8 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
     flag_row();
     return;
   }
-  const uint32_t klim = f2key_(ak + 2.f * c_eps * sqrtf(qn[row] * rn_max));
+  const float flim = ak + 2.f * c_eps * sqrtf(qn[row] * rn_max);
+  const uint32_t klim = f2key_(flim);
   if (tid == 0) s_n = 0;
   __syncthreads();
   for (int j = tid; j < (int)c; j += 256) {
@@ -1223,7 +1257,15 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
   __syncthreads();
   if (tid == 0) {
     if (s_n > (uint32_t)rcap) {
-      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      // the band holds more rows than the first-tier refine list: second tier (refine2_compact_kernel + a refinement
+      // pass straight from the candidate list), or -- without one -- the exact matrix path
+      if (rovf_rows) {
+        rovf_rows[row] = 1u;
+        ref_lim[row] = flim;
+        atomicAdd(rovf_count, 1u);
+      } else if (atomicExch(&ovf_rows[row], 1u) == 0u) {
+        atomicAdd(ovf_count, 1u);
+      }
       ref_cnt[row] = 0;
     } else {
       ref_cnt[row] = s_n;
@@ -1242,7 +1284,9 @@ __global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __res
                                                            const float* __restrict__ qn, float c_eps, float rn_max,
                                                            float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
                                                            uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
-                                                           uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ todo) {
+                                                           uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ todo,
+                                                           uint32_t* __restrict__ rovf_rows, uint32_t* __restrict__ rovf_count,
+                                                           float* __restrict__ ref_lim) {
   constexpr int PER = 16;
   const int l = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1296,7 +1340,8 @@ __global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __res
     flag_row();
     return;
   }
-  const uint32_t klim = f2key_(ak + 2.f * c_eps * sqrtf(qn[row] * rn_max));
+  const float flim = ak + 2.f * c_eps * sqrtf(qn[row] * rn_max);
+  const uint32_t klim = f2key_(flim);
   uint32_t total = 0;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -1311,7 +1356,13 @@ __global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __res
   }
   if (l == 0) {
     if (total > (uint32_t)rcap) {
-      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      if (rovf_rows) {   // second tier (see select_approx_kernel)
+        rovf_rows[row] = 1u;
+        ref_lim[row] = flim;
+        atomicAdd(rovf_count, 1u);
+      } else if (atomicExch(&ovf_rows[row], 1u) == 0u) {
+        atomicAdd(ovf_count, 1u);
+      }
       ref_cnt[row] = 0;
     } else {
       ref_cnt[row] = total;
@@ -1322,55 +1373,236 @@ __global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __res
 int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
                             float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
-                            uint32_t* fail_rows, uint32_t* fail_count) {
+                            uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, uint32_t* rovf_count, float* ref_lim) {
   if (nq <= 0) return SEGVLAD_OK;
   SV_HIP(ctx->s_sel_todo.reserve((size_t)nq * 4));
   uint32_t* todo = ctx->s_sel_todo.as<uint32_t>();
   hipLaunchKernelGGL(select_small_kernel, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cand_cnt, cand_d2, cand_id, nq, cap, rank, mode,
-                     check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo);
+                     check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo,
+                     rovf_rows, rovf_count, ref_lim);
   const size_t lds = (size_t)cap * 4;
   hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, rank, mode, check,
-                     thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo);
+                     thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo,
+                     rovf_rows, rovf_count, ref_lim);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+// Second refinement tier.  A query whose band {d2~ <= A_k + 2 eps} holds more rows than the first-tier list (SV_RCAP) --
+// temporally redundant databases: every reference segment comes with its ~30 near-duplicates from the neighbouring video
+// frames, so whole clumps of rows sit inside the band -- keeps its candidate list (<= cap entries, a superset of the band):
+// this kernel compacts the band's ids to the front of that list, in place, and the exact refinement then runs straight
+// from it (rcap = cap).  Only the flagged rows do any work; nobody is sent to the distance-matrix path for this.
+__global__ __launch_bounds__(256) void refine2_compact_kernel(const uint32_t* __restrict__ rovf_rows, const float* __restrict__ ref_lim,
+                                                              uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+                                                              uint32_t* __restrict__ cid, int cap) {
+  __shared__ uint32_t wtot[4];
+  const int64_t row = blockIdx.x;
+  if (!rovf_rows[row]) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const uint32_t c = cnt[row];
+  const float lim = ref_lim[row];
+  uint32_t base = 0;
+  for (uint32_t j0 = 0; j0 < c; j0 += 256) {
+    const uint32_t j = j0 + tid;
+    const bool hit = j < c && cd2[row * cap + j] <= lim;
+    const uint32_t id = hit ? cid[row * cap + j] : 0u;
+    const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+    if (l == 0) wtot[w] = (uint32_t)__popcll(mk);
+    __syncthreads();   // every read of this chunk precedes its writes (which land at positions <= the reads': in place is safe)
+    uint32_t off = base;
+    for (int x = 0; x < w; ++x) off += wtot[x];
+    const uint32_t pos = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+    if (hit) cid[row * cap + pos] = id;
+    base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+  }
+  if (tid == 0) cnt[row] = base;
+}
+
+int sv_launch_refine2_compact(segvlad_ctx* ctx, const uint32_t* rovf_rows, const float* ref_lim, uint32_t* cand_cnt,
+                              const float* cand_d2, uint32_t* cand_id, int nq, int cap) {
+  if (nq <= 0) return SEGVLAD_OK;
+  hipLaunchKernelGGL(refine2_compact_kernel, dim3(nq), dim3(256), 0, ctx->stream, rovf_rows, ref_lim, cand_cnt, cand_d2, cand_id, cap);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
 
 // exact distances of the refine list: the sequential fp32 fma chain over k = 0..d-1 (bit-identical to the
-// v_mfma_f32_32x32x2_f32 chain of the matrix path), then (distance, id) sort and top-k.  QLDS: the query row is cached in
-// LDS (d up to ~38k); raw K*D descriptors (d = 98 304) read it through L1/L2 instead (all lanes read the same address).
+// v_mfma_f32_32x32x2_f32 chain of the matrix path), then (distance, id) sort and top-k.  One thread per candidate row; the
+// query row is cached in LDS (QLDS; d up to ~38k).  The row is walked with EIGHT 16-byte loads in flight per thread (a
+// register double buffer): a 50-query pass has fewer waves than the chip has SIMDs, so the loop is pure load latency --
+// one round trip per 8 x 16 B instead of one per 16 B.
+// only_rows != null: rows whose flag is clear are left untouched (second refinement tier).
 template <bool QLDS>
 __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
                                                            const float* __restrict__ qn, const float* __restrict__ rn,
                                                            const uint32_t* __restrict__ ref_cnt,
                                                            const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
-                                                           float* __restrict__ d2_out, int64_t* __restrict__ idx_out) {
+                                                           float* __restrict__ d2_out, int64_t* __restrict__ idx_out,
+                                                           const uint32_t* __restrict__ only_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* qs = reinterpret_cast<float*>(smem);                                     // [d] when QLDS
   uint64_t* a = reinterpret_cast<uint64_t*>(smem + (QLDS ? (size_t)d * 4 : 0));   // [rpad]
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
+  if (only_rows && !only_rows[row]) return;
   const int n = (int)ref_cnt[row];
+  int np2 = 2;   // sort length: the smallest power of two holding the list (<= rpad)
+  while (np2 < n) np2 <<= 1;
   if (QLDS)
     for (int j = tid; j < d; j += 256) qs[j] = Q[row * d + j];
-  for (int j = tid; j < rpad; j += 256) a[j] = ~0ull;
+  for (int j = tid; j < np2; j += 256) a[j] = ~0ull;
   __syncthreads();
   const float q2 = qn[row];
+  const float4* qp = QLDS ? reinterpret_cast<const float4*>(qs) : reinterpret_cast<const float4*>(Q + row * d);
+  const int n4 = d >> 2;
   for (int j = tid; j < n; j += 256) {
     const uint32_t id = ref_id[row * rcap + j];
     const float4* rp = reinterpret_cast<const float4*>(R + (size_t)id * d);
     float acc = 0.f;
-    for (int t = 0; t < (d >> 2); ++t) {
-      const float4 rv = rp[t];
-      const float4 qv = QLDS ? reinterpret_cast<const float4*>(qs)[t] : reinterpret_cast<const float4*>(Q + row * d)[t];
-      acc = fmaf(qv.x, rv.x, acc);
-      acc = fmaf(qv.y, rv.y, acc);
-      acc = fmaf(qv.z, rv.z, acc);
-      acc = fmaf(qv.w, rv.w, acc);
+    int t = 0;
+    if ((n4 & 7) == 0 && n4 >= 16) {
+      float4 cur[8], nxt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = rp[u];
+      for (; t + 8 < n4; t += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nxt[u] = rp[t + 8 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float4 qv = qp[t + u];
+          acc = fmaf(qv.x, cur[u].x, acc);
+          acc = fmaf(qv.y, cur[u].y, acc);
+          acc = fmaf(qv.z, cur[u].z, acc);
+          acc = fmaf(qv.w, cur[u].w, acc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 qv = qp[t + u];
+        acc = fmaf(qv.x, cur[u].x, acc);
+        acc = fmaf(qv.y, cur[u].y, acc);
+        acc = fmaf(qv.z, cur[u].z, acc);
+        acc = fmaf(qv.w, cur[u].w, acc);
+      }
+    } else {
+      for (; t < n4; ++t) {
+        const float4 rv = rp[t];
+        const float4 qv = qp[t];
+        acc = fmaf(qv.x, rv.x, acc);
+        acc = fmaf(qv.y, rv.y, acc);
+        acc = fmaf(qv.z, rv.z, acc);
+        acc = fmaf(qv.w, rv.w, acc);
+      }
     }
     const float v = sv_d2(q2, rn[id], acc);
     a[j] = ((uint64_t)f2key_(v) << 32) | id;
   }
-  bitonic64(a, rpad, tid);
+  bitonic64(a, np2, tid);
+  for (int j = tid; j < k; j += 256) {
+    float dd = INFINITY;
+    int64_t id = -1;
+    if (j < n) {
+      dd = key2f_((uint32_t)(a[j] >> 32));
+      id = (int64_t)(uint32_t)a[j];
+    }
+    d2_out[row * k + j] = dd;
+    idx_out[row * k + j] = id;
+  }
+}
+
+// Deep rows (raw K*D descriptors: d = 98 304 is 384 KiB per row, far beyond the LDS and -- one row per lane -- beyond what
+// L1 can keep of 256 private streams): the same sequential chain, but the candidate rows are fetched COALESCED -- eight
+// lanes per 128-byte line, 16 B each -- into an LDS tile [rows][32 k (+4 pad)], double buffered, which every thread then
+// walks along ITS OWN row(s) with conflict-free ds_read_b128 (row stride 144 B).  RT rows per thread and pass: a first-tier
+// list (<= 512 rows) is ONE pass of 2 rows per thread -- a second pass over a dozen left-over rows would cost a full
+// 3072-step latency chain again.  d % 32 == 0.
+template <int RT>
+__global__ __launch_bounds__(256) void refine_exact_wide_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
+                                                                const float* __restrict__ qn, const float* __restrict__ rn,
+                                                                const uint32_t* __restrict__ ref_cnt,
+                                                                const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
+                                                                float* __restrict__ d2_out, int64_t* __restrict__ idx_out,
+                                                                const uint32_t* __restrict__ only_rows) {
+  constexpr int KC = 32, LDR = KC + 4, ROWS = 256 * RT, NP = 8 * RT;   // NP 16-byte pieces per thread and k-chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                                 // [2][ROWS][LDR]
+  float* qs = tile + 2 * ROWS * LDR;                                            // [2][KC]
+  uint32_t* ids = reinterpret_cast<uint32_t*>(qs + 2 * KC);                     // [ROWS]
+  uint64_t* a = reinterpret_cast<uint64_t*>(ids + ROWS);                        // [rpad]
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  if (only_rows && !only_rows[row]) return;
+  const int n = (int)ref_cnt[row];
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  for (int j = tid; j < np2; j += 256) a[j] = ~0ull;
+  const float q2 = qn[row];
+  const float* qrow = Q + row * d;
+  const int nch = d / KC;
+  const int lrow0 = tid >> 3, seg = tid & 7;   // piece u of this thread: tile row lrow0 + 32 u, 16-byte segment seg
+  for (int base = 0; base < n; base += ROWS) {
+    const int cnt = (n - base < ROWS) ? (n - base) : ROWS;
+    __syncthreads();   // the previous pass is done with ids[] and the tile
+    for (int j = tid; j < cnt; j += 256) ids[j] = ref_id[row * rcap + base + j];
+    __syncthreads();
+    const float* src[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int lr = lrow0 + 32 * u;
+      src[u] = R + (size_t)ids[lr < cnt ? lr : 0] * d + seg * 4;
+    }
+    float4 g[NP], gq = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int c) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (lrow0 + 32 * u < cnt) g[u] = *reinterpret_cast<const float4*>(src[u] + (size_t)c * KC);
+      if (tid < 8) gq = *reinterpret_cast<const float4*>(qrow + (size_t)c * KC + tid * 4);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (lrow0 + 32 * u < cnt) *reinterpret_cast<float4*>(tile + ((size_t)buf * ROWS + lrow0 + 32 * u) * LDR + seg * 4) = g[u];
+      if (tid < 8) *reinterpret_cast<float4*>(qs + buf * KC + tid * 4) = gq;
+    };
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < nch) gload(c + 1);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const float* tr = tile + ((size_t)buf * ROWS + tid + 256 * r) * LDR;
+#pragma unroll
+        for (int s4 = 0; s4 < KC / 4; ++s4) {
+          const float4 rv = *reinterpret_cast<const float4*>(tr + s4 * 4);
+          const float4 qv = *reinterpret_cast<const float4*>(qs + buf * KC + s4 * 4);
+          acc[r] = fmaf(qv.x, rv.x, acc[r]);
+          acc[r] = fmaf(qv.y, rv.y, acc[r]);
+          acc[r] = fmaf(qv.z, rv.z, acc[r]);
+          acc[r] = fmaf(qv.w, rv.w, acc[r]);
+        }
+      }
+      if (c + 1 < nch) sstore(buf ^ 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const int lr = tid + 256 * r;
+      if (lr < cnt) {
+        const uint32_t id = ids[lr];
+        a[base + lr] = ((uint64_t)f2key_(sv_d2(q2, rn[id], acc[r])) << 32) | id;
+      }
+    }
+  }
+  bitonic64(a, np2, tid);
   for (int j = tid; j < k; j += 256) {
     float dd = INFINITY;
     int64_t id = -1;
@@ -1384,21 +1616,34 @@ __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restri
 }
 
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
-                           const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out) {
+                           const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
+                           const uint32_t* only_rows) {
   if (nq <= 0) return SEGVLAD_OK;
   int rpad = 2;
   while (rpad < rcap) rpad <<= 1;
   size_t lds = (size_t)d * 4 + (size_t)rpad * 8;
-  if (lds > 160 * 1024) {
-    lds = (size_t)rpad * 8;
-    hipLaunchKernelGGL(refine_exact_kernel<false>, dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
-                       rpad, k, d2_out, idx_out);
+#define SV_REFINE_ARGS dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap, rpad, k, d2_out, idx_out, only_rows
+  if (lds <= 160 * 1024) {
+    if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<true>), lds));
+    hipLaunchKernelGGL(refine_exact_kernel<true>, SV_REFINE_ARGS);
+  } else if (d % 32 == 0) {
+    const bool two = rcap <= 512;   // a first-tier list: one pass of two rows per thread (150 KiB of LDS)
+    const int rows = two ? 512 : 256;
+    lds = (size_t)(2 * rows * 36 + 64 + rows) * 4 + (size_t)rpad * 8;
+    if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "refine: a %d-entry list of %d-d rows exceeds the LDS", rcap, d);
+    if (two) {
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<2>), lds));
+      hipLaunchKernelGGL(refine_exact_wide_kernel<2>, SV_REFINE_ARGS);
+    } else {
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<1>), lds));
+      hipLaunchKernelGGL(refine_exact_wide_kernel<1>, SV_REFINE_ARGS);
+    }
   } else {
-    if (lds > 64 * 1024)
-      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<true>), (size_t)lds));
-    hipLaunchKernelGGL(refine_exact_kernel<true>, dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
-                       rpad, k, d2_out, idx_out);
+    lds = (size_t)rpad * 8;
+    if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<false>), lds));
+    hipLaunchKernelGGL(refine_exact_kernel<false>, SV_REFINE_ARGS);
   }
+#undef SV_REFINE_ARGS
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SegVLADError
+from ._lib import SegVLADDegenerateError, SegVLADError
 
 
 def _ptr(x) -> int:
@@ -72,7 +72,7 @@ class SegVLADEngine:
     def _check(self, rc: int, what: str):
         if rc != 0:
             msg = self.lib.segvlad_last_error(self._h)
-            raise SegVLADError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}")
+            raise SegVLADError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}", code=int(rc))
 
     def _stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
@@ -97,9 +97,10 @@ class SegVLADEngine:
 
     def search_stats(self) -> dict:
         """Statistics of the last search(): levels, filter arithmetic, rows redone on the exact path, list occupancies."""
-        v = (C.c_int64 * 9)()
-        self._check(self.lib.segvlad_search_stats(self._h, v, 9), "search_stats")
-        names = ("levels", "filter", "n_fallback", "cand_max", "cand_sum", "refine_max", "refine_sum", "n_queries", "n_redo")
+        v = (C.c_int64 * 10)()
+        self._check(self.lib.segvlad_search_stats(self._h, v, 10), "search_stats")
+        names = ("levels", "filter", "n_fallback", "cand_max", "cand_sum", "refine_max", "refine_sum", "n_queries", "n_redo",
+                 "n_refine2")
         d = dict(zip(names, [int(x) for x in v]))
         d["filter"] = {0: "none", 1: "f16", 2: "bf16x3", 3: "fp32"}[d["filter"]]
         return d
@@ -159,7 +160,7 @@ class SegVLADEngine:
     def adjacency(self, centroids, seg_offsets, order: int, check_empty: bool = False) -> torch.Tensor:
         """centroids [S_tot,2] fp64 -> uint8 buffer with the concatenated per-image [S_b,S_b] (A1^order > 0)
         blocks, computed on the device.  check_empty=True synchronises and raises ValueError on an empty mask
-        (the reference's behaviour), and SegVLADError("... degenerate ...") when an image holds a non-generic centroid
+        (the reference's behaviour), and SegVLADDegenerateError when an image holds a non-generic centroid
         configuration (duplicate or exactly co-circular points: Qhull's triangulation is then a matter of its own
         tie-breaking; SegVLADPipeline catches this and uses the reference's Qhull path for that batch)."""
         c = _as(centroids, np.float64, torch.float64)
@@ -175,8 +176,8 @@ class SegVLADEngine:
         if check_empty and n_bad[0] & 0xFFFF:
             raise ValueError(f"{n_bad[0] & 0xFFFF} empty mask(s): centroid undefined")
         if check_empty and n_bad[0] >> 16:
-            raise SegVLADError(f"adjacency: {n_bad[0] >> 16} image(s) with a degenerate centroid configuration "
-                               "(duplicate or co-circular centroids): the Delaunay triangulation is not unique")
+            raise SegVLADDegenerateError(f"adjacency: {n_bad[0] >> 16} image(s) with a degenerate centroid configuration "
+                                         "(duplicate or co-circular centroids): the Delaunay triangulation is not unique")
         return out
 
     # ---- segment VLAD -----------------------------------------------------------------------------

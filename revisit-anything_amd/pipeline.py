@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SegVLADError
+from ._lib import SEGVLAD_ERR_LIMIT, SegVLADDegenerateError, SegVLADError
 from .engine import SegVLADEngine
 from .func_vpr import adjacency_from_centroids
 
@@ -71,7 +71,9 @@ class SegVLADPipeline:
                 try:
                     adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
                 except SegVLADError as e:
-                    if "LDS budget" not in str(e) and "degenerate" not in str(e):
+                    # typed, not message-matched: a documented implementation limit (SEGVLAD_ERR_LIMIT) or the
+                    # degenerate-configuration report are recoverable; anything else is not
+                    if not isinstance(e, SegVLADDegenerateError) and e.code != SEGVLAD_ERR_LIMIT:
                         raise
                     # an image with more segments (~620) than the in-LDS Delaunay holds, or a non-generic centroid
                     # configuration (duplicate / exactly co-circular centroids, where the triangulation is Qhull's

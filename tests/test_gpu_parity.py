@@ -577,7 +577,7 @@ def test_adjacency_flags_non_generic_centroids_and_the_pipeline_uses_qhull(eng):
     drops the duplicate.  The kernel reports such images (bits 16.. of the counter); with check_empty the engine raises
     and SegVLADPipeline recomputes the batch with the reference's Qhull path."""
     import torch
-    from revisit_anything_amd._lib import SegVLADError
+    from revisit_anything_amd._lib import SegVLADDegenerateError, SegVLADError  # noqa: F401
     from revisit_anything_amd.pipeline import SegVLADPipeline
 
     generic = np.array([[3.0, 4.0], [40.5, 7.25], [21.0, 33.0], [8.0, 29.5], [30.0, 18.0]])
@@ -586,7 +586,7 @@ def test_adjacency_flags_non_generic_centroids_and_the_pipeline_uses_qhull(eng):
     offs = np.array([0, 5], np.int32)
     eng.adjacency(generic, offs, 1, check_empty=True)                                            # generic: no complaint
     for c in (rect, dup):
-        with pytest.raises(SegVLADError, match="degenerate"):
+        with pytest.raises(SegVLADDegenerateError):
             eng.adjacency(c, offs, 1, check_empty=True)
         eng.adjacency(c, offs, 1)                                                                # unchecked: still computes
     a = eng.adjacency(rect, offs, 1).cpu().numpy().reshape(5, 5).astype(bool)

@@ -137,31 +137,35 @@ def test_pipeline_falls_back_to_qhull_when_the_device_adjacency_declines():
     error propagates.  (Stub engine: this is host control flow.)"""
     import pytest
 
-    from revisit_anything_amd._lib import SegVLADError
+    from revisit_anything_amd._lib import SEGVLAD_ERR_HIP, SEGVLAD_ERR_LIMIT, SegVLADDegenerateError, SegVLADError
     from revisit_anything_amd.pipeline import SegVLADPipeline
 
     cent = np.array([[10.0, 10.0], [30.0, 10.0], [30.0, 22.0], [10.0, 22.0], [55.0, 60.0]])   # 4 co-circular + 1
     offs = np.array([0, 5], np.int32)
 
     class Stub:
-        def __init__(self, msg):
-            self.msg, self.got_adj = msg, None
+        def __init__(self, exc):
+            self.exc, self.got_adj = exc, None
 
         def incidence_centroids(self, masks, H, W, patch):
             return "bits", torch.from_numpy(cent)
 
         def adjacency(self, c, so, order, check_empty=False):
-            raise SegVLADError(self.msg)
+            raise self.exc
 
         def seg_vlad(self, tokens, bits, so, adj):
             self.got_adj = np.asarray(adj)
             return {"out": "desc"}
 
-    for msg in ("adjacency: 1 image(s) with a degenerate centroid configuration", "adjacency: 700 segments exceed the LDS budget"):
-        st = Stub(msg)
+    # the decision is taken on the exception TYPE / the library's error CODE -- the wording is free to change
+    for exc in (SegVLADDegenerateError("reworded: non-generic point set"),
+                SegVLADError("reworded: too many segments for the on-chip triangulation", code=SEGVLAD_ERR_LIMIT)):
+        st = Stub(exc)
         out = SegVLADPipeline(st, 112, 140, order=1, use_pca=False).describe("tok", "masks", offs)
         assert out == "desc"
         want = O.adjacency_from_centroids(cent, 1).astype(np.uint8).reshape(-1)
         assert np.array_equal(st.got_adj, want)                     # Qhull's choice, not the device kernel's
-    with pytest.raises(SegVLADError):
-        SegVLADPipeline(Stub("hipErrorLaunchFailure"), 112, 140, order=1, use_pca=False).describe("tok", "masks", offs)
+    for exc in (SegVLADError("hipErrorLaunchFailure", code=SEGVLAD_ERR_HIP),
+                SegVLADError("a message that merely mentions the LDS budget and the word degenerate")):   # no code, wrong type
+        with pytest.raises(SegVLADError):
+            SegVLADPipeline(Stub(exc), 112, 140, order=1, use_pca=False).describe("tok", "masks", offs)
