@@ -80,11 +80,19 @@ int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm
  *      identical to Qhull for points in general position).  n_empty_out (HOST, may be NULL; passing it
  *      synchronises): low 16 bits = number of NaN centroids (= empty masks, for which the reference raises
  *      ValueError); bits 16.. = number of images holding a NON-GENERIC configuration (a duplicate centroid, or
- *      four exactly co-circular centroids with an empty circle), where the Delaunay triangulation is not unique
+ *      four centroids co-circular -- exactly or to within rounding -- with an empty circle), where the Delaunay triangulation is not unique
  *      and Qhull's choice cannot be reproduced: callers that need the reference's result bit for bit recompute
  *      such batches with Qhull (pipeline.py does). */
 int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
                       uint8_t* adj_out, uint32_t* n_empty_out);
+
+/*      The same, with one flag byte per image instead of the two counts: img_flags_out [B] (HOST or device; a host
+ *      pointer synchronises): bit 0 = the image holds an empty mask (NaN centroid), bit 1 = it holds a non-generic
+ *      centroid configuration (duplicate centroids, or four centroids co-circular exactly or to within rounding).
+ *      A caller that needs the reference's result bit for bit recomputes exactly the flagged images with Qhull
+ *      (pipeline.py does: ~0.2 ms of host work per flagged image instead of the whole batch). */
+int segvlad_adjacency_flagged(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
+                              uint8_t* adj_out, uint8_t* img_flags_out);
 
 /* ---- segment VLAD for a batch of B images of identical token geometry
  *      seg_vlad_gpu_single(_img) -> vlad_single -> vlad_matmuls_per_cluster   func_vpr.py:1065-1210

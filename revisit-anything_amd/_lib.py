@@ -30,6 +30,7 @@ SIGNATURES = {
                                                C.c_void_p, C.c_void_p]),
     "segvlad_mask_centroids": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "segvlad_adjacency": (C.c_int, [c_ctx_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "segvlad_adjacency_flagged": (C.c_int, [c_ctx_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "segvlad_images": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_void_p,
                                   _f32p, _f32p]),
     "segvlad_images_pca": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_int,

@@ -334,9 +334,8 @@ int segvlad_mask_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm
   return sv_finish(ctx);
 }
 
-int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
-                      uint8_t* adj_out, uint32_t* n_empty_out) {
-  CHECK_CTX();
+static int adjacency_impl(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
+                          uint8_t* adj_out, uint32_t* n_empty_out, uint8_t* img_flags_out) {
   if (B < 0 || order < 1) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency: need B>=0 and order>=1 (order 0 = pass adj=NULL)");
   if (B == 0) return SEGVLAD_OK;
   if (!centroids || !seg_offsets || !adj_out) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency: null pointer");
@@ -362,10 +361,15 @@ int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* 
   SV_HIP(hipMemcpyAsync(ctx->s_adjoff.p, adj_off.data(), (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
   uint32_t* bad = ctx->s_flag.as<uint32_t>() + 4;
   SV_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
+  void* dflags = nullptr;
+  if (img_flags_out) {
+    SV_TRY(sv_out(ctx, img_flags_out, (size_t)B, &dflags));
+    SV_HIP(hipMemsetAsync(dflags, 0, (size_t)B, ctx->stream));
+  }
   {
     StageScope sc(ctx, "adjacency");
     SV_TRY(sv_launch_adjacency(ctx, (const double*)dc, ctx->s_segoff.as<int32_t>(), ctx->s_adjoff.as<int64_t>(), B, S_max, order,
-                               (uint8_t*)dout, bad));
+                               (uint8_t*)dout, bad, (uint8_t*)dflags));
     sc.count();
   }
   if (n_empty_out) {
@@ -373,6 +377,19 @@ int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* 
     SV_HIP(hipStreamSynchronize(ctx->stream));
   }
   return sv_finish(ctx);
+}
+
+int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
+                      uint8_t* adj_out, uint32_t* n_empty_out) {
+  CHECK_CTX();
+  return adjacency_impl(ctx, centroids, seg_offsets, B, order, adj_out, n_empty_out, nullptr);
+}
+
+int segvlad_adjacency_flagged(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
+                              uint8_t* adj_out, uint8_t* img_flags_out) {
+  CHECK_CTX();
+  if (B > 0 && !img_flags_out) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency_flagged: null img_flags_out");
+  return adjacency_impl(ctx, centroids, seg_offsets, B, order, adj_out, nullptr, img_flags_out);
 }
 
 // ---- segment VLAD -----------------------------------------------------------------------------------
@@ -940,16 +957,20 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
           fprintf(stderr, "[search] %s m=%d level %d/%d ns=%lld rank %d: candidates mean %.1f max %u, %u lists over cap %d\n",
                   heuristic ? "heuristic" : "rigorous", m, lv, levels, (long long)ns, rank[lv], (double)tot / m, mx, over, SV_CAP);
       }
-      StageScope sc(ctx, "knn_select");
-      SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
-                                     SV_CAP, rank[lv], last ? 1 : 0, heuristic ? 1 : 0, thr_ptr, thr_ld, qn, pl.c_eps, pl.rn_max, thr,
-                                     ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count,
-                                     rovf_rows, rovf_rows + m, ref_lim));
-      sc.count();
-      if (last) {
-        SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, k,
-                                      out_d2, out_idx));
+      {
+        StageScope sc(ctx, "knn_select");
+        SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
+                                       SV_CAP, rank[lv], last ? 1 : 0, heuristic ? 1 : 0, thr_ptr, thr_ld, qn, pl.c_eps, pl.rn_max, thr,
+                                       ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count,
+                                       rovf_rows, rovf_rows + m, ref_lim));
         sc.count();
+        if (last) {
+          SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP,
+                                        k, out_d2, out_idx));
+          sc.count();
+        }
+      }   // (the stage's stop event is recorded before the host waits below)
+      if (last) {
         // one read-back per chunk: rows flagged for the redo / matrix-path fallback (handled by the caller) and rows whose
         // refine band outgrew the first-tier list.  The latter are refined here, straight from their candidate lists,
         // which the next chunk would overwrite.
@@ -959,6 +980,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
         SV_HIP(hipStreamSynchronize(ctx->stream));
         if (n_fail_host) *n_fail_host = h_cnt[0];
         if (h_cnt[1]) {
+          StageScope sc(ctx, "knn_select");
           SV_TRY(sv_launch_refine2_compact(ctx, rovf_rows, ref_lim, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
                                            ctx->s_cand_id.as<uint32_t>(), m, SV_CAP));
           SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP,

@@ -220,7 +220,7 @@ int sv_launch_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
                         uint64_t* inc_bits, double* centroids /* may be null */);
 int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, double* out);
 int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg_off_dev, const int64_t* adj_off_dev,
-                        int B, int S_max, int order, uint8_t* adj, uint32_t* n_bad);
+                        int B, int S_max, int order, uint8_t* adj, uint32_t* n_bad, uint8_t* img_flags = nullptr);
 int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float* xt, uint8_t* labels, float* rnorm,
                      float* gap);
 int sv_launch_prep(segvlad_ctx* ctx, const uint8_t* labels, const uint64_t* inc_bits, const int32_t* seg_off_dev,

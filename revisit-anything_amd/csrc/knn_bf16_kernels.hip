@@ -1515,19 +1515,23 @@ __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restri
 }
 
 // Deep rows (raw K*D descriptors: d = 98 304 is 384 KiB per row, far beyond the LDS and -- one row per lane -- beyond what
-// L1 can keep of 256 private streams): the same sequential chain, but the candidate rows are fetched COALESCED -- eight
-// lanes per 128-byte line, 16 B each -- into an LDS tile [rows][32 k (+4 pad)], double buffered, which every thread then
-// walks along ITS OWN row(s) with conflict-free ds_read_b128 (row stride 144 B).  RT rows per thread and pass: a first-tier
-// list (<= 512 rows) is ONE pass of 2 rows per thread -- a second pass over a dozen left-over rows would cost a full
-// 3072-step latency chain again.  d % 32 == 0.
-template <int RT>
+// L1 can keep of 256 private streams): the same sequential chain, but the candidate rows are fetched COALESCED and in LONG
+// runs: a pass takes 64 candidate rows, every k-chunk of KC floats (1 KiB of each row at KC = 256: one wave-wide 16-B load
+// per row -- DRAM pages are used whole; with 128-byte pieces of 200+ rows 384 KiB apart every access opened a new page and
+// the kernel ran at 1.4 TB/s) lands in an LDS tile [64 rows][KC (+4 pad)], double buffered, and the 64 lanes of wave 0 then
+// walk ONE ROW EACH with conflict-free ds_read_b128 (row stride = 4 banks mod 64).  The chain of a chunk (KC dependent fmas
+// per lane, ~0.45 us) is shorter than the chunk's fetch (64 KiB per CU at the CU's share of HBM: ~2 us), so one computing
+// wave per workgroup suffices; all four waves load.  d % KC == 0.
+template <int KC>
 __global__ __launch_bounds__(256) void refine_exact_wide_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
                                                                 const float* __restrict__ qn, const float* __restrict__ rn,
                                                                 const uint32_t* __restrict__ ref_cnt,
                                                                 const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
                                                                 float* __restrict__ d2_out, int64_t* __restrict__ idx_out,
                                                                 const uint32_t* __restrict__ only_rows) {
-  constexpr int KC = 32, LDR = KC + 4, ROWS = 256 * RT, NP = 8 * RT;   // NP 16-byte pieces per thread and k-chunk
+  constexpr int ROWS = 64, LDR = KC + 4, C4 = KC / 4;    // C4 16-byte pieces per row and chunk
+  constexpr int NP = ROWS * C4 / 256;                    // pieces per thread and chunk
+  static_assert(C4 <= 64 && 64 % C4 == 0 && NP * 256 == ROWS * C4, "a wave covers whole rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);                                 // [2][ROWS][LDR]
   float* qs = tile + 2 * ROWS * LDR;                                            // [2][KC]
@@ -1543,63 +1547,59 @@ __global__ __launch_bounds__(256) void refine_exact_wide_kernel(const float* __r
   const float q2 = qn[row];
   const float* qrow = Q + row * d;
   const int nch = d / KC;
-  const int lrow0 = tid >> 3, seg = tid & 7;   // piece u of this thread: tile row lrow0 + 32 u, 16-byte segment seg
+  // piece u of this thread: tile row (tid + 256 u) / C4, 16-byte segment (tid + 256 u) % C4
+  const int seg = tid % C4, lrow0 = tid / C4;
+  constexpr int RSTEP = 256 / C4;
   for (int base = 0; base < n; base += ROWS) {
     const int cnt = (n - base < ROWS) ? (n - base) : ROWS;
     __syncthreads();   // the previous pass is done with ids[] and the tile
-    for (int j = tid; j < cnt; j += 256) ids[j] = ref_id[row * rcap + base + j];
+    if (tid < cnt) ids[tid] = ref_id[row * rcap + base + tid];
     __syncthreads();
     const float* src[NP];
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-      const int lr = lrow0 + 32 * u;
+      const int lr = lrow0 + RSTEP * u;
       src[u] = R + (size_t)ids[lr < cnt ? lr : 0] * d + seg * 4;
     }
     float4 g[NP], gq = make_float4(0.f, 0.f, 0.f, 0.f);
     auto gload = [&](int c) {
 #pragma unroll
       for (int u = 0; u < NP; ++u)
-        if (lrow0 + 32 * u < cnt) g[u] = *reinterpret_cast<const float4*>(src[u] + (size_t)c * KC);
-      if (tid < 8) gq = *reinterpret_cast<const float4*>(qrow + (size_t)c * KC + tid * 4);
+        if (lrow0 + RSTEP * u < cnt) g[u] = *reinterpret_cast<const float4*>(src[u] + (size_t)c * KC);
+      if (tid < C4) gq = *reinterpret_cast<const float4*>(qrow + (size_t)c * KC + tid * 4);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < NP; ++u)
-        if (lrow0 + 32 * u < cnt) *reinterpret_cast<float4*>(tile + ((size_t)buf * ROWS + lrow0 + 32 * u) * LDR + seg * 4) = g[u];
-      if (tid < 8) *reinterpret_cast<float4*>(qs + buf * KC + tid * 4) = gq;
+        if (lrow0 + RSTEP * u < cnt) *reinterpret_cast<float4*>(tile + ((size_t)buf * ROWS + lrow0 + RSTEP * u) * LDR + seg * 4) = g[u];
+      if (tid < C4) *reinterpret_cast<float4*>(qs + buf * KC + tid * 4) = gq;
     };
-    float acc[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    float acc = 0.f;
     gload(0);
     sstore(0);
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
       const int buf = c & 1;
       if (c + 1 < nch) gload(c + 1);
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const float* tr = tile + ((size_t)buf * ROWS + tid + 256 * r) * LDR;
-#pragma unroll
-        for (int s4 = 0; s4 < KC / 4; ++s4) {
+      if (tid < cnt) {   // wave 0: one row per lane
+        const float* tr = tile + ((size_t)buf * ROWS + tid) * LDR;
+        const float* qb = qs + buf * KC;
+#pragma unroll 8
+        for (int s4 = 0; s4 < C4; ++s4) {
           const float4 rv = *reinterpret_cast<const float4*>(tr + s4 * 4);
-          const float4 qv = *reinterpret_cast<const float4*>(qs + buf * KC + s4 * 4);
-          acc[r] = fmaf(qv.x, rv.x, acc[r]);
-          acc[r] = fmaf(qv.y, rv.y, acc[r]);
-          acc[r] = fmaf(qv.z, rv.z, acc[r]);
-          acc[r] = fmaf(qv.w, rv.w, acc[r]);
+          const float4 qv = *reinterpret_cast<const float4*>(qb + s4 * 4);
+          acc = fmaf(qv.x, rv.x, acc);
+          acc = fmaf(qv.y, rv.y, acc);
+          acc = fmaf(qv.z, rv.z, acc);
+          acc = fmaf(qv.w, rv.w, acc);
         }
       }
       if (c + 1 < nch) sstore(buf ^ 1);
       __syncthreads();
     }
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      const int lr = tid + 256 * r;
-      if (lr < cnt) {
-        const uint32_t id = ids[lr];
-        a[base + lr] = ((uint64_t)f2key_(sv_d2(q2, rn[id], acc[r])) << 32) | id;
-      }
+    if (tid < cnt) {
+      const uint32_t id = ids[tid];
+      a[base + tid] = ((uint64_t)f2key_(sv_d2(q2, rn[id], acc)) << 32) | id;
     }
   }
   bitonic64(a, np2, tid);
@@ -1626,17 +1626,19 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
   if (lds <= 160 * 1024) {
     if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<true>), lds));
     hipLaunchKernelGGL(refine_exact_kernel<true>, SV_REFINE_ARGS);
-  } else if (d % 32 == 0) {
-    const bool two = rcap <= 512;   // a first-tier list: one pass of two rows per thread (150 KiB of LDS)
-    const int rows = two ? 512 : 256;
-    lds = (size_t)(2 * rows * 36 + 64 + rows) * 4 + (size_t)rpad * 8;
+  } else if (d % 128 == 0) {
+    // [2][64 rows][KC + 4] floats + [2][KC] query floats + [64] ids + the sort keys: KC = 256 (133 KiB + keys) unless the list is
+    // a second-tier one (up to 8192 keys = 64 KiB), which takes KC = 128
+    const bool big = d % 256 == 0 && (size_t)(2 * 64 * 260 + 2 * 256 + 64) * 4 + (size_t)rpad * 8 <= 160 * 1024;
+    const int kc = big ? 256 : 128;
+    lds = (size_t)(2 * 64 * (kc + 4) + 2 * kc + 64) * 4 + (size_t)rpad * 8;
     if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "refine: a %d-entry list of %d-d rows exceeds the LDS", rcap, d);
-    if (two) {
-      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<2>), lds));
-      hipLaunchKernelGGL(refine_exact_wide_kernel<2>, SV_REFINE_ARGS);
+    if (big) {
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<256>), lds));
+      hipLaunchKernelGGL(refine_exact_wide_kernel<256>, SV_REFINE_ARGS);
     } else {
-      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<1>), lds));
-      hipLaunchKernelGGL(refine_exact_wide_kernel<1>, SV_REFINE_ARGS);
+      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<128>), lds));
+      hipLaunchKernelGGL(refine_exact_wide_kernel<128>, SV_REFINE_ARGS);
     }
   } else {
     lds = (size_t)rpad * 8;

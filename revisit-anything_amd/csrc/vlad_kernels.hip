@@ -293,14 +293,18 @@ int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
 // So the edge exists iff max_{right} tau <= min_{left} tau, and a point strictly inside the segment
 // blocks it.  O(S) per pair, fp64.  Generic inputs give exactly Qhull's triangulation.  Non-generic inputs -- exactly
 // co-circular quadruples (max_right tau == min_left tau: the triangulation is not unique, both diagonals are kept here,
-// Qhull picks one) and duplicate centroids (Qhull drops the coplanar duplicate) -- are COUNTED: every image that holds
-// one adds 65536 to *n_bad, so that the caller can route the batch through the reference's own Qhull path.
+// Qhull picks one) and duplicate centroids (Qhull drops the coplanar duplicate) -- are REPORTED: every image that holds
+// one adds 65536 to *n_bad and sets bit 1 of img_flags[b] (bit 0: an empty mask, i.e. a NaN centroid), so that the caller
+// can route exactly those images through the reference's own Qhull path.  "Co-circular" includes quadruples whose two
+// bounds agree to within a few ulps: there the sign of tmax - tmin is rounding noise, and either answer could differ from
+// Qhull's (which decides such cases by its own perturbation rules).
 // S <= 3 reproduces the reference's special case: every row = e0 (+ e1).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict__ cent,
                                                         const int32_t* __restrict__ seg_off,
                                                         const int64_t* __restrict__ adj_off, int order, int S_max,
-                                                        uint8_t* __restrict__ adj, uint32_t* __restrict__ n_bad) {
+                                                        uint8_t* __restrict__ adj, uint32_t* __restrict__ n_bad,
+                                                        uint8_t* __restrict__ img_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
@@ -316,7 +320,10 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
   for (int s = tid; s < S; s += 256) {
     px[s] = cent[2 * (size_t)(s0 + s)];
     py[s] = cent[2 * (size_t)(s0 + s) + 1];
-    if (px[s] != px[s] && n_bad) atomicAdd(n_bad, 1u);  // NaN centroid = empty mask (reference: ValueError)
+    if (px[s] != px[s]) {  // NaN centroid = empty mask (reference: ValueError)
+      if (n_bad) atomicAdd(n_bad, 1u);
+      if (img_flags) img_flags[b] = (uint8_t)(img_flags[b] | 1u);   // (same value from every writer; bit 1 is set later, by one thread)
+    }
   }
   for (int j = tid; j < S * SW; j += 256) A1[j] = 0;
   __shared__ int degenerate;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
     const double ux = px[u], uy = py[u], vx = px[v], vy = py[v];
     const double ex = vx - ux, ey = vy - uy;
     if (ex == 0.0 && ey == 0.0) degenerate = 1;   // duplicate centroid
-    double tmin = INFINITY, tmax = -INFINITY;
+    double tmin = INFINITY, tmax = -INFINITY, emin = 0.0, emax = 0.0;   // e*: rounding-error bounds of the two extremes
     bool blocked = false;
     for (int p = 0; p < S; ++p) {
       if (p == u || p == v) continue;
@@ -347,22 +354,37 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
       const double bx = px[p] - vx, by = py[p] - vy;
       const double num = fma(ax, bx, ay * by);
       const double den = fma(ex, ay, -(ey * ax));
-      if (den > 0.0) {
-        tmin = fmin(tmin, num / den);
-      } else if (den < 0.0) {
-        tmax = fmax(tmax, num / den);
+      if (den != 0.0) {
+        const double t = num / den;
+        // |computed tau - exact tau| for THESE coordinates: the differences, the two sums of products and the quotient
+        // each carry a few 2^-53 relative to the magnitudes that entered them
+        const double err = 9e-16 * ((fabs(ax * bx) + fabs(ay * by)) + fabs(t) * (fabs(ex * ay) + fabs(ey * ax))) / fabs(den);
+        if (den > 0.0) {
+          if (t < tmin) {
+            tmin = t;
+            emin = err;
+          }
+        } else if (t > tmax) {
+          tmax = t;
+          emax = err;
+        }
       } else if (num < 0.0) {
         blocked = true;
       }
     }
-    if (!blocked && tmax == tmin) degenerate = 1;   // an empty circle through four points: either diagonal is Delaunay
+    // an empty circle through four points (either diagonal is Delaunay): exactly (lattice centroids: every quantity above is
+    // exact, equal taus compare equal), or so nearly that the sign of tmax - tmin is rounding noise
+    if (!blocked && tmax > -INFINITY && tmin < INFINITY && fabs(tmax - tmin) <= emin + emax) degenerate = 1;
     if (!blocked && tmax <= tmin) {
       atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (v >> 6)]), 1ull << (v & 63));
       atomicOr(reinterpret_cast<unsigned long long*>(&A1[v * SW + (u >> 6)]), 1ull << (u & 63));
     }
   }
   __syncthreads();
-  if (tid == 0 && degenerate && n_bad) atomicAdd(n_bad, 65536u);
+  if (tid == 0 && degenerate) {
+    if (n_bad) atomicAdd(n_bad, 65536u);
+    if (img_flags) img_flags[b] = (uint8_t)(img_flags[b] | 2u);
+  }
   for (int j = tid; j < S * SW; j += 256) P[j] = A1[j];
   __syncthreads();
   for (int it = 1; it < order; ++it) {  // P <- (P . A1) > 0
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
 }
 
 int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg_off_dev, const int64_t* adj_off_dev,
-                        int B, int S_max, int order, uint8_t* adj, uint32_t* n_bad) {
+                        int B, int S_max, int order, uint8_t* adj, uint32_t* n_bad, uint8_t* img_flags) {
   if (B <= 0 || S_max <= 0) return SEGVLAD_OK;
   const int SW = (S_max + 63) / 64;
   const size_t lds = (size_t)S_max * 16 + (size_t)3 * S_max * SW * 8;
@@ -399,7 +421,7 @@ int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(adjacency_kernel), (size_t)lds));
   hipLaunchKernelGGL(adjacency_kernel, dim3(B), dim3(256), lds, ctx->stream, cent, seg_off_dev, adj_off_dev, order, S_max,
-                     adj, n_bad);
+                     adj, n_bad, img_flags);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

@@ -67,17 +67,26 @@ class SegVLADPipeline:
             bits, cent = eng.incidence_centroids(masks, self.H, self.W, self.patch)   # one pass over the mask bytes
             if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)
                 adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
-            else:                     # device kernel: no host round trip
+            else:                     # device kernel: no host round trip (check_empty: one flag byte per image comes back)
                 try:
-                    adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
+                    if self.check_empty and hasattr(eng, "adjacency_flagged"):
+                        adj, flags = eng.adjacency_flagged(cent, seg_offsets, self.order)
+                        if (flags & 1).any():
+                            raise ValueError(f"{int((flags & 1).sum())} image(s) with an empty mask: centroid undefined")
+                        bad = np.nonzero(flags & 2)[0]
+                        if len(bad):
+                            # non-generic centroid configurations (duplicate / co-circular centroids: the triangulation is
+                            # Qhull's tie-breaking): the reference's own Qhull path for exactly these images
+                            adj = self._patch_with_qhull(adj, cent, np.asarray(seg_offsets), bad)
+                    else:
+                        adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
                 except SegVLADError as e:
                     # typed, not message-matched: a documented implementation limit (SEGVLAD_ERR_LIMIT) or the
                     # degenerate-configuration report are recoverable; anything else is not
                     if not isinstance(e, SegVLADDegenerateError) and e.code != SEGVLAD_ERR_LIMIT:
                         raise
-                    # an image with more segments (~620) than the in-LDS Delaunay holds, or a non-generic centroid
-                    # configuration (duplicate / exactly co-circular centroids, where the triangulation is Qhull's
-                    # tie-breaking): the reference's own Qhull path for this batch
+                    # an image with more segments (~620) than the in-LDS Delaunay holds (or a report from an engine
+                    # without per-image flags): the reference's own Qhull path for this batch
                     adj = adjacency_batch(cent.cpu().numpy(), seg_offsets, self.order, self.adj_workers)
         else:
             bits = eng.incidence(masks, self.H, self.W, self.patch)
@@ -89,6 +98,17 @@ class SegVLADPipeline:
         if self.use_pca:
             desc = eng.pca_apply(desc, l2norm=l2norm)
         return desc
+
+    def _patch_with_qhull(self, adj: torch.Tensor, cent: torch.Tensor, so: np.ndarray, images) -> torch.Tensor:
+        """Overwrite the [S_b, S_b] blocks of the listed images in the concatenated device adjacency with Qhull's."""
+        sizes = (so[1:] - so[:-1]).astype(np.int64)
+        adj_off = np.concatenate([[0], np.cumsum(sizes * sizes)])
+        lo, hi = int(so[min(images)]), int(so[max(images) + 1])
+        ch = cent[lo:hi].cpu().numpy()
+        for b in images:
+            blk = adjacency_from_centroids(ch[so[b] - lo:so[b + 1] - lo], self.order).numpy().astype(np.uint8).reshape(-1)
+            adj[int(adj_off[b]):int(adj_off[b + 1])] = torch.from_numpy(blk).to(adj.device)
+        return adj
 
     # ---- a10: index ------------------------------------------------------------------------------------
     def index_reset(self):

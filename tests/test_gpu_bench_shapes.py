@@ -122,50 +122,8 @@ def test_knn_f16_filter_d1024_bench_and_shard_sizes(eng, planted_1m, n_rows):
         assert np.abs(m[qq, ii[qq, rr]] - rd2[qq, rr]).max() < 1e-5
 
 
-def test_knn_one_overflowing_query_is_redone_alone(eng):
-    """300 queries against 200 k rows; ONE query has 600 exact duplicates of itself in the database, which overflow
-    its 512-entry refine list.  Only that row may take the exact matrix path (search_stats / stage counters), every
-    result must equal the oracle's (ties -> lower id)."""
-    import torch
-
-    dev = eng.device
-    g = torch.Generator(device=dev)
-    g.manual_seed(11)
-    n, d, nq, k = 200000, 256, 300, 50
-    R = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
-    star = torch.nn.functional.normalize(torch.randn(1, d, device=dev, generator=g), dim=1)
-    dup_rows = torch.arange(0, 600, device=dev) * 331 + 17          # 600 scattered rows
-    R[dup_rows] = star
-    src = torch.randint(0, n - 1, (nq,), device=dev, generator=g)
-    src = torch.where(src % 331 == 17, src + 1, src)               # never a duplicate row: only query 137 sees the 600-way tie
-    Q = torch.nn.functional.normalize(R[src] + (1.0 / d ** 0.5) * torch.randn(nq, d, device=dev, generator=g), dim=1)
-    Q[137] = star[0]
-    eng.db_reset()
-    eng.db_add(R)
-    eng.set_profiling(True)
-    eng.profile_reset()
-    d2, idx = eng.search(Q, k)
-    st = eng.search_stats()
-    ms, rows_redone = eng.stage_ms("knn_fallback")
-    eng.set_profiling(False)
-    assert st["levels"] >= 1 and st["filter"] == "f16"
-    assert st["n_fallback"] == 1 and rows_redone == 1, (st, rows_redone)
-    rd2, ridx = O().topk_from_d2(O().l2_matrix(R.cpu().numpy(), Q.cpu().numpy()), k)
-    dd, ii = d2.cpu().numpy(), idx.cpu().numpy()
-    assert np.abs(dd - rd2).max() < 1e-5
-    assert np.array_equal(ii[137], np.sort(dup_rows.cpu().numpy())[:k])    # 600-way tie: the k lowest ids
-    assert np.abs(dd[137]).max() < 1e-6
-    clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
-    clear[137] = False
-    assert np.array_equal(ii[clear], ridx[clear])
-    # with no overflow the stage does not exist / is not charged
-    eng.set_profiling(True)
-    eng.profile_reset()
-    eng.search(Q[:100], k)
-    assert eng.search_stats()["n_fallback"] == 0
-    with pytest.raises(Exception):
-        eng.stage_ms("knn_fallback")
-    eng.set_profiling(False)
+# (the per-query overflow paths -- second refinement tier, matrix-path fallback -- are forced in
+#  tests/test_gpu_config2_redundant.py::test_refine_band_overflow_takes_the_second_tier_and_list_overflow_the_matrix_path)
 
 
 # ------------------------------------------------------------------------------------------------

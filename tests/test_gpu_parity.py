@@ -605,6 +605,26 @@ def test_adjacency_flags_non_generic_centroids_and_the_pipeline_uses_qhull(eng):
     d_dev = SegVLADPipeline(eng, H, W, order=1, use_pca=False).describe(toks, masks, offs).cpu().numpy()
     d_host = SegVLADPipeline(eng, H, W, order=1, use_pca=False, host_adjacency=True).describe(toks, masks, offs).cpu().numpy()
     assert np.array_equal(d_dev, d_host)
+    # per-image flags (segvlad_adjacency_flagged): in a batch of [generic, rect, generic, dup] exactly images 1 and 3 are
+    # reported, and the pipeline patches exactly their blocks with Qhull's answer (the others keep the device kernel's)
+    cat = np.concatenate([generic, rect, generic + 1.5, dup])
+    offs4 = np.array([0, 5, 10, 15, 20], np.int32)
+    adj, flags = eng.adjacency_flagged(cat, offs4, 1)
+    assert flags.tolist() == [0, 2, 0, 2]
+    pipe = SegVLADPipeline(eng, H, W, order=1, use_pca=False)
+    patched = pipe._patch_with_qhull(adj.clone(), torch.from_numpy(cat).to(eng.device), offs4, [1, 3]).cpu().numpy()
+    for b_, c_ in enumerate((generic, rect, generic + 1.5, dup)):
+        want = O().adjacency_from_centroids(c_, 1).astype(np.uint8).reshape(-1)
+        assert np.array_equal(patched[25 * b_:25 * b_ + 25], want), b_
+    assert np.array_equal(adj.cpu().numpy()[:25], patched[:25])                                  # untouched
+    # a quadruple that is co-circular only up to rounding (the rectangle, rotated by an irrational angle) is reported too
+    th = 0.7312
+    rot = rect @ np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]).T + np.array([100.0, 50.0])
+    assert eng.adjacency_flagged(rot, offs, 1)[1].tolist() == [2]
+    # an empty mask sets bit 0 of ITS image only
+    cent_nan = np.concatenate([generic, generic + 2.0])
+    cent_nan[7] = np.nan
+    assert eng.adjacency_flagged(cent_nan, np.array([0, 5, 10], np.int32), 1)[1].tolist() == [0, 1]
 
 
 def test_pipeline_device_adjacency_equals_host_qhull(eng):

@@ -1,0 +1,38 @@
+"""One 50-segment query image per pass over a 1 M x 1024 index: per-stage times (HIP events) and -- under
+rocprofv3 --kernel-trace --stats -- the per-kernel durations of the pass.   python tools/probe_stream.py [reps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from revisit_anything_amd.engine import SegVLADEngine  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+dev = torch.device("cuda:0")
+eng = SegVLADEngine(0)
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+n, d, k = 1_000_000, 1024, 200
+R = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
+eng.db_add(R)
+Q = torch.nn.functional.normalize(R[torch.arange(50, device=dev) * 977] + 0.03 * torch.randn(50, d, device=dev, generator=g), dim=1)
+for _ in range(5):
+    eng.search(Q, k)
+torch.cuda.synchronize()
+eng.set_profiling(True)
+eng.profile_reset()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    eng.search(Q, k)
+e1.record()
+torch.cuda.synchronize()
+tot = 0.0
+for s in ("knn_level0", "knn_gemm", "knn_select"):
+    ms, nl = eng.stage_ms(s)
+    tot += ms / reps
+    print(f"{s}: {ms / reps * 1e3:.1f} us per pass, {nl / reps:.1f} launches")
+print(f"stages sum {tot * 1e3:.1f} us; wall per search {e0.elapsed_time(e1) / reps * 1e3:.1f} us; streamed 2.05 GB -> "
+      f"{2.048e9 / (tot * 1e-3) / 1e12:.2f} TB/s of the stage sum = {2.048e9 / (tot * 1e-3) / 8e12:.3f} of HBM peak")
+print(eng.search_stats())
