@@ -903,10 +903,9 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     if (n0 <= 1024 && pl.kind != 3) {
       // a short sample row: only its r0-th smallest distance is needed -- the wave-per-query register select of the
       // candidate lists (mode 0: thr[q] = rank-th smallest), the distance block standing in for a list of n0 entries
-      SV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->s_cand_cnt.p), (int)n0, (size_t)m, ctx->stream));
       SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_dist.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
                                      (int)ld0, r0, 0, 0, nullptr, 0, qn, pl.c_eps, pl.rn_max, thr, ctx->s_ref_cnt.as<uint32_t>(),
-                                     ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count));
+                                     ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count, nullptr, nullptr, nullptr, (int)n0));
     } else {
       SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, r0, thr, ctx->s_thr_idx.as<int64_t>(), r0, 0));
     }
@@ -924,7 +923,9 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     stride /= SV_RATIO;
     const int64_t ns = (n + stride - 1) / stride;
     const bool last = (lv == levels);
-    SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
+    // the candidate counters start every level at zero: the mode-0 selects of the approximate-domain filters leave them so;
+    // only the first filter level behind a select_topk level 0, and the fp32 filter's select, need the memset
+    if (pl.kind == 3 || (lv == 1 && !l0_small)) SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
     if (pl.kind != 3) {
       {
         StageScope sc(ctx, "knn_gemm");

@@ -265,11 +265,13 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
 // rank: which order statistic of the list is A (mode 0: the next level's threshold; mode 1: k).  check != 0 (heuristic
 // thresholds): mode 0 flags a list shorter than rank, mode 1 flags A > thr_in[row * thr_in_ld] (the threshold the list was
 // collected under).  Flagged rows (also: list overflow) are marked in fail_rows and counted once in *fail_count.
-int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
+// mode 0 also ZEROES cand_cnt[row] (the next level's filter appends from zero).  fixed_cnt >= 0: every row is a list of that
+// length (the sampled level's distance block) and cand_cnt is not read.
+int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
                             float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
                             uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows = nullptr, uint32_t* rovf_count = nullptr,
-                            float* ref_lim = nullptr);
+                            float* ref_lim = nullptr, int fixed_cnt = -1);
 // rovf_rows / rovf_count / ref_lim (mode 1): a refine band longer than rcap marks its row there (with the band's upper limit)
 // instead of in fail_rows: sv_launch_refine2_compact + sv_launch_refine_exact(..., rcap = cap, only_rows = rovf_rows)
 // then refine it straight from the candidate list.

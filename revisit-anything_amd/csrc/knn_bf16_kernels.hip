@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void hist_add_(uint32_t* hist, bool active, uint32_t 
 // yields A_k, the k-th smallest approximate distance (+inf if fewer than k candidates).
 //   mode 0: thr_out[q] = A_k
 //   mode 1: refine list = ids with d2~ <= A_k + 2 eps(q) (unordered; at most rcap, more -> the row is flagged in ovf_rows)
-__global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+__global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
                                                             const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
                                                             const float* __restrict__ thr_in, int64_t thr_in_ld,
                                                             const float* __restrict__ qn, float c_eps, float rn_max,
@@ -1181,7 +1181,13 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   if (todo && !todo[row]) return;   // already ranked by select_small_kernel
-  const uint32_t c = cnt[row];
+  __shared__ uint32_t s_c;
+  if (tid == 0) {
+    s_c = cnt[row];
+    if (mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero (no memset launch between the levels)
+  }
+  __syncthreads();
+  const uint32_t c = s_c;
   // the threshold this list was collected under (read before thr_out -- possibly the same word -- is overwritten)
   const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
   auto flag_row = [&]() {
@@ -1273,31 +1279,21 @@ __global__ __launch_bounds__(256) void select_approx_kernel(const uint32_t* __re
   }
 }
 
-// The same ranking for SHORT lists (<= 1024 candidates: every list of the low-rank level scheme), one WAVE per query
-// instead of one 256-thread workgroup: the keys live in registers (16 per lane), the rank-th smallest is found by a
-// binary MSB-first radix select whose per-bit counts are wave reductions, the refine list is compacted by ballots.
-// No LDS, no barriers: 0.19 ms -> ~0.03 ms per 4096 queries and level.  Longer lists are left to select_approx_kernel
-// (todo[row] = 1).
-__global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
-                                                           const uint32_t* __restrict__ cid, int nq, int cap, int k, int mode, int check,
-                                                           const float* __restrict__ thr_in, int64_t thr_in_ld,
-                                                           const float* __restrict__ qn, float c_eps, float rn_max,
-                                                           float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
-                                                           uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
-                                                           uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ todo,
-                                                           uint32_t* __restrict__ rovf_rows, uint32_t* __restrict__ rovf_count,
-                                                           float* __restrict__ ref_lim) {
-  constexpr int PER = 16;
-  const int l = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= nq) return;
-  const uint32_t c = cnt[row];
-  if (c > (uint32_t)(64 * PER) && c <= (uint32_t)cap && !ovf_rows[row]) {   // long list: the workgroup kernel ranks it
-    if (l == 0) todo[row] = 1u;
-    return;
-  }
-  if (l == 0) todo[row] = 0u;
-  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+// The same ranking for lists of up to 4096 candidates (every list of the low-rank level scheme, and nearly every list of
+// the rigorous one), one WAVE per query instead of one 256-thread workgroup: the keys live in registers (4, 16 or 64 per
+// lane, by the list's length), the rank-th smallest is found by a binary MSB-first radix select whose per-bit counts are
+// ballots + scalar population counts, the refine list is compacted by ballots.  No LDS, no barriers.  Longer lists are
+// left to select_approx_kernel (todo[row] = 1).
+// select_small_body: the ranking itself for lists of at most 64 * PER keys (PER register slots per lane, loops fully
+// unrolled: a run-time bound on the slot loops cost a scalar branch per slot and bit -- 40 us per launch).
+template <int PER>
+__device__ __forceinline__ void select_small_body(const float* __restrict__ cd2, const uint32_t* __restrict__ cid, int64_t row, int l,
+                                                  uint32_t c, int cap, int k, int mode, int check, float t_in,
+                                                  const float* __restrict__ qn, float c_eps, float rn_max,
+                                                  float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
+                                                  uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
+                                                  uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
+                                                  uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim) {
   auto flag_row = [&]() {
     if (l == 0) {
       if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
@@ -1305,25 +1301,24 @@ __global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __res
       else thr_out[row] = -INFINITY;
     }
   };
-  if (c > (uint32_t)cap || ovf_rows[row] || (check && (int)c < k)) {
-    flag_row();
-    return;
-  }
   uint32_t key[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int j = l + 64 * i;
-    key[i] = (j < (int)c) ? f2key_(cd2[row * cap + j]) : 0xffffffffu;   // padding sorts last (a real key is never all ones: NaN-free)
+    key[i] = 0xffffffffu;   // padding sorts last (a real key is never all ones: NaN-free)
+    if (j < (int)c) key[i] = f2key_(cd2[row * cap + j]);
   }
   float ak = INFINITY;
   if ((int)c >= k) {
     uint32_t prefix = 0, mask = 0, rem = (uint32_t)k;
     for (int bit = 31; bit >= 0; --bit) {
       const uint32_t b = 1u << bit;
-      uint32_t zeros = 0;   // keys that match the prefix so far and have this bit clear
+      // keys that match the prefix so far and have this bit clear, counted over the wave by ballots (a compare + a scalar
+      // population count per key slot: the butterfly of six cross-lane shuffles per bit it replaces was ~8 us of pure
+      // LDS-crossbar latency per launch)
+      uint32_t zeros = 0;
 #pragma unroll
-      for (int i = 0; i < PER; ++i) zeros += ((key[i] & (mask | b)) == prefix) ? 1u : 0u;
-      for (int o = 32; o > 0; o >>= 1) zeros += (uint32_t)__shfl_xor((int)zeros, o);
+      for (int i = 0; i < PER; ++i) zeros += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((key[i] & (mask | b)) == prefix));
       if (rem > zeros) {
         rem -= zeros;
         prefix |= b;
@@ -1370,16 +1365,66 @@ __global__ __launch_bounds__(256) void select_small_kernel(const uint32_t* __res
   }
 }
 
-int sv_launch_select_approx(segvlad_ctx* ctx, const uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
+__global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+                                                           const uint32_t* __restrict__ cid, int nq, int cap, int k, int mode, int check,
+                                                           const float* __restrict__ thr_in, int64_t thr_in_ld,
+                                                           const float* __restrict__ qn, float c_eps, float rn_max,
+                                                           float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
+                                                           uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
+                                                           uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ todo,
+                                                           uint32_t* __restrict__ rovf_rows, uint32_t* __restrict__ rovf_count,
+                                                           float* __restrict__ ref_lim, int fixed_cnt) {
+  constexpr int PER = 64;   // up to 4096 keys per wave, in registers
+  const int l = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nq) return;
+  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];   // fixed_cnt: every row is a list of that length
+  if (c > (uint32_t)(64 * PER) && c <= (uint32_t)cap && !ovf_rows[row]) {   // long list: the workgroup kernel ranks it
+    if (l == 0) todo[row] = 1u;
+    return;
+  }
+  if (l == 0) {
+    todo[row] = 0u;
+    if (mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero (no memset launch between the levels)
+  }
+  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  auto flag_row = [&]() {
+    if (l == 0) {
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      if (mode == 1) ref_cnt[row] = 0;
+      else thr_out[row] = -INFINITY;
+    }
+  };
+  if (c > (uint32_t)cap || ovf_rows[row] || (check && (int)c < k)) {
+    flag_row();
+    return;
+  }
+  if (c <= 256u)
+    select_small_body<4>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+                         ovf_count, rovf_rows, rovf_count, ref_lim);
+  else if (c <= 1024u)
+    select_small_body<16>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+                          ovf_count, rovf_rows, rovf_count, ref_lim);
+  else
+    select_small_body<64>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+                          ovf_count, rovf_rows, rovf_count, ref_lim);
+}
+
+int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
                             int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
                             float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
-                            uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, uint32_t* rovf_count, float* ref_lim) {
+                            uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, uint32_t* rovf_count, float* ref_lim,
+                            int fixed_cnt) {
   if (nq <= 0) return SEGVLAD_OK;
   SV_HIP(ctx->s_sel_todo.reserve((size_t)nq * 4));
   uint32_t* todo = ctx->s_sel_todo.as<uint32_t>();
   hipLaunchKernelGGL(select_small_kernel, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cand_cnt, cand_d2, cand_id, nq, cap, rank, mode,
                      check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo,
-                     rovf_rows, rovf_count, ref_lim);
+                     rovf_rows, rovf_count, ref_lim, fixed_cnt);
+  if (fixed_cnt >= 0 && fixed_cnt <= 4096) {   // every list is ranked by the wave kernel: nothing left for the workgroup kernel
+    SV_HIP(hipGetLastError());
+    return SEGVLAD_OK;
+  }
   const size_t lds = (size_t)cap * 4;
   hipLaunchKernelGGL(select_approx_kernel, dim3(nq), dim3(256), lds, ctx->stream, cand_cnt, cand_d2, cand_id, cap, rank, mode, check,
                      thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo,
@@ -1430,9 +1475,9 @@ int sv_launch_refine2_compact(segvlad_ctx* ctx, const uint32_t* rovf_rows, const
 
 // exact distances of the refine list: the sequential fp32 fma chain over k = 0..d-1 (bit-identical to the
 // v_mfma_f32_32x32x2_f32 chain of the matrix path), then (distance, id) sort and top-k.  One thread per candidate row; the
-// query row is cached in LDS (QLDS; d up to ~38k).  The row is walked with EIGHT 16-byte loads in flight per thread (a
-// register double buffer): a 50-query pass has fewer waves than the chip has SIMDs, so the loop is pure load latency --
-// one round trip per 8 x 16 B instead of one per 16 B.
+// query row is cached in LDS (QLDS; d up to ~38k).  The row is walked with THIRTY-TWO 16-byte loads in flight per thread:
+// a 50-query pass has fewer waves than the chip has SIMDs, so the loop is pure load latency -- one round trip per
+// 32 x 16 B (an 8-deep register double buffer still paid one round trip per 128 B: 78 us per pass).
 // only_rows != null: rows whose flag is clear are left untouched (second refinement tier).
 template <bool QLDS>
 __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
@@ -1462,31 +1507,21 @@ __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restri
     const float4* rp = reinterpret_cast<const float4*>(R + (size_t)id * d);
     float acc = 0.f;
     int t = 0;
-    if ((n4 & 7) == 0 && n4 >= 16) {
-      float4 cur[8], nxt[8];
+    if ((n4 & 31) == 0) {
+      for (; t < n4; t += 32) {   // 512 B of the row in flight per lane: 8 round trips for a 1024-d row
+        float4 buf[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) cur[u] = rp[u];
-      for (; t + 8 < n4; t += 8) {
+        for (int u = 0; u < 32; ++u) buf[u] = rp[t + u];
+        __builtin_amdgcn_sched_barrier(0);   // all 32 loads are issued before the first fma (the scheduler otherwise
+                                             // sinks them next to their uses to save registers -- and pays the latency 32 times)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = rp[t + 8 + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 32; ++u) {
           const float4 qv = qp[t + u];
-          acc = fmaf(qv.x, cur[u].x, acc);
-          acc = fmaf(qv.y, cur[u].y, acc);
-          acc = fmaf(qv.z, cur[u].z, acc);
-          acc = fmaf(qv.w, cur[u].w, acc);
+          acc = fmaf(qv.x, buf[u].x, acc);
+          acc = fmaf(qv.y, buf[u].y, acc);
+          acc = fmaf(qv.z, buf[u].z, acc);
+          acc = fmaf(qv.w, buf[u].w, acc);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float4 qv = qp[t + u];
-        acc = fmaf(qv.x, cur[u].x, acc);
-        acc = fmaf(qv.y, cur[u].y, acc);
-        acc = fmaf(qv.z, cur[u].z, acc);
-        acc = fmaf(qv.w, cur[u].w, acc);
       }
     } else {
       for (; t < n4; ++t) {
@@ -1515,22 +1550,24 @@ __global__ __launch_bounds__(256) void refine_exact_kernel(const float* __restri
 }
 
 // Deep rows (raw K*D descriptors: d = 98 304 is 384 KiB per row, far beyond the LDS and -- one row per lane -- beyond what
-// L1 can keep of 256 private streams): the same sequential chain, but the candidate rows are fetched COALESCED and in LONG
-// runs: a pass takes 64 candidate rows, every k-chunk of KC floats (1 KiB of each row at KC = 256: one wave-wide 16-B load
-// per row -- DRAM pages are used whole; with 128-byte pieces of 200+ rows 384 KiB apart every access opened a new page and
-// the kernel ran at 1.4 TB/s) lands in an LDS tile [64 rows][KC (+4 pad)], double buffered, and the 64 lanes of wave 0 then
-// walk ONE ROW EACH with conflict-free ds_read_b128 (row stride = 4 banks mod 64).  The chain of a chunk (KC dependent fmas
-// per lane, ~0.45 us) is shorter than the chunk's fetch (64 KiB per CU at the CU's share of HBM: ~2 us), so one computing
-// wave per workgroup suffices; all four waves load.  d % KC == 0.
-template <int KC>
+// L1 can keep of 256 private streams): the same sequential chain, with the candidate rows fetched COALESCED (KC * 4 bytes
+// of a row per step: C4 lanes x 16 B) into an LDS tile [64 rows][KC (+4 pad)], double buffered, which the 64 lanes of wave 0
+// then walk ONE ROW EACH (conflict-free ds_read_b128: the row stride is 4 banks mod 64); all four waves load.
+// What bounds it is bytes in flight: one workgroup per CU (the tile) with one step of 32 KiB outstanding ran at 1.4-1.8 TB/s
+// -- piece size, a time skew between the rows and the 3 * 2^17-byte row pitch made no difference, and
+// tools/ubench/gather_bw.hip reaches 7 TB/s on the same addresses with 256 KiB per CU in flight.  So the loads run DEPTH
+// steps ahead in a register ring (DEPTH x NP float4 per thread: 128 KiB per CU at DEPTH = 4), and only the step that is due
+// is written to the LDS tile.  d % KC == 0.
+template <int KC, int DEPTH>
 __global__ __launch_bounds__(256) void refine_exact_wide_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
                                                                 const float* __restrict__ qn, const float* __restrict__ rn,
                                                                 const uint32_t* __restrict__ ref_cnt,
                                                                 const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
                                                                 float* __restrict__ d2_out, int64_t* __restrict__ idx_out,
                                                                 const uint32_t* __restrict__ only_rows) {
-  constexpr int ROWS = 64, LDR = KC + 4, C4 = KC / 4;    // C4 16-byte pieces per row and chunk
-  constexpr int NP = ROWS * C4 / 256;                    // pieces per thread and chunk
+  constexpr int ROWS = 64, LDR = KC + 4, C4 = KC / 4;    // C4 16-byte pieces per row and step
+  constexpr int NP = ROWS * C4 / 256;                    // pieces per thread and step
+  constexpr int RSTEP = 256 / C4;                        // tile rows between two pieces of a thread
   static_assert(C4 <= 64 && 64 % C4 == 0 && NP * 256 == ROWS * C4, "a wave covers whole rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);                                 // [2][ROWS][LDR]
@@ -1545,58 +1582,133 @@ __global__ __launch_bounds__(256) void refine_exact_wide_kernel(const float* __r
   while (np2 < n) np2 <<= 1;
   for (int j = tid; j < np2; j += 256) a[j] = ~0ull;
   const float q2 = qn[row];
-  const float* qrow = Q + row * d;
+  const float* qrow = Q + row * d + (tid < C4 ? tid * 4 : 0);
   const int nch = d / KC;
-  // piece u of this thread: tile row (tid + 256 u) / C4, 16-byte segment (tid + 256 u) % C4
-  const int seg = tid % C4, lrow0 = tid / C4;
-  constexpr int RSTEP = 256 / C4;
+  const int seg = tid % C4, lrow0 = tid / C4;   // piece u of this thread: tile row lrow0 + RSTEP u, 16-byte segment seg
   for (int base = 0; base < n; base += ROWS) {
     const int cnt = (n - base < ROWS) ? (n - base) : ROWS;
     __syncthreads();   // the previous pass is done with ids[] and the tile
     if (tid < cnt) ids[tid] = ref_id[row * rcap + base + tid];
     __syncthreads();
+    // (no per-piece predication: a branch around every load makes the compiler wait for each one.  Tile rows beyond the
+    //  list re-read candidate 0 -- L2 hits -- and are never looked at; every thread carries a query piece, lanes >= C4 a
+    //  duplicate of piece 0 that is never stored)
     const float* src[NP];
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int lr = lrow0 + RSTEP * u;
       src[u] = R + (size_t)ids[lr < cnt ? lr : 0] * d + seg * 4;
     }
-    float4 g[NP], gq = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto gload = [&](int c) {
-#pragma unroll
-      for (int u = 0; u < NP; ++u)
-        if (lrow0 + RSTEP * u < cnt) g[u] = *reinterpret_cast<const float4*>(src[u] + (size_t)c * KC);
-      if (tid < C4) gq = *reinterpret_cast<const float4*>(qrow + (size_t)c * KC + tid * 4);
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-      for (int u = 0; u < NP; ++u)
-        if (lrow0 + RSTEP * u < cnt) *reinterpret_cast<float4*>(tile + ((size_t)buf * ROWS + lrow0 + RSTEP * u) * LDR + seg * 4) = g[u];
-      if (tid < C4) *reinterpret_cast<float4*>(qs + buf * KC + tid * 4) = gq;
-    };
-    float acc = 0.f;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-      const int buf = c & 1;
-      if (c + 1 < nch) gload(c + 1);
-      if (tid < cnt) {   // wave 0: one row per lane
-        const float* tr = tile + ((size_t)buf * ROWS + tid) * LDR;
-        const float* qb = qs + buf * KC;
-#pragma unroll 8
-        for (int s4 = 0; s4 < C4; ++s4) {
-          const float4 rv = *reinterpret_cast<const float4*>(tr + s4 * 4);
-          const float4 qv = *reinterpret_cast<const float4*>(qb + s4 * 4);
-          acc = fmaf(qv.x, rv.x, acc);
-          acc = fmaf(qv.y, rv.y, acc);
-          acc = fmaf(qv.z, rv.z, acc);
-          acc = fmaf(qv.w, rv.w, acc);
-        }
-      }
-      if (c + 1 < nch) sstore(buf ^ 1);
-      __syncthreads();
+    // The ring is four NAMED register sets and the step is a macro instantiated once per set: hipcc 7.2 sends a
+    // [DEPTH][NP] array that is indexed through a lambda parameter to scratch memory (seen in the ISA: scratch_load/_store
+    // around every piece, vmcnt(0) after every load).
+    static_assert(DEPTH == 4 && NP == 8, "four named ring sets of eight named pieces");
+#define SV_WG_DECL(X) float4 g##X##0, g##X##1, g##X##2, g##X##3, g##X##4, g##X##5, g##X##6, g##X##7, q##X
+    SV_WG_DECL(A);
+    SV_WG_DECL(B);
+    SV_WG_DECL(C);
+    SV_WG_DECL(D);
+#define SV_WG_LOAD(X, c_)                                                          \
+    do {                                                                           \
+      const size_t o_ = (size_t)(c_) * KC;                                         \
+      g##X##0 = *reinterpret_cast<const float4*>(src[0] + o_);                     \
+      g##X##1 = *reinterpret_cast<const float4*>(src[1] + o_);                     \
+      g##X##2 = *reinterpret_cast<const float4*>(src[2] + o_);                     \
+      g##X##3 = *reinterpret_cast<const float4*>(src[3] + o_);                     \
+      g##X##4 = *reinterpret_cast<const float4*>(src[4] + o_);                     \
+      g##X##5 = *reinterpret_cast<const float4*>(src[5] + o_);                     \
+      g##X##6 = *reinterpret_cast<const float4*>(src[6] + o_);                     \
+      g##X##7 = *reinterpret_cast<const float4*>(src[7] + o_);                     \
+      q##X = *reinterpret_cast<const float4*>(qrow + o_);                          \
+    } while (0)
+#define SV_WG_STORE(X, buf_)                                                       \
+    do {                                                                           \
+      float* t_ = tile + ((size_t)(buf_) * ROWS + lrow0) * LDR + seg * 4;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 0 * LDR) = g##X##0;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 1 * LDR) = g##X##1;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 2 * LDR) = g##X##2;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 3 * LDR) = g##X##3;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 4 * LDR) = g##X##4;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 5 * LDR) = g##X##5;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 6 * LDR) = g##X##6;          \
+      *reinterpret_cast<float4*>(t_ + (size_t)RSTEP * 7 * LDR) = g##X##7;          \
+      if (tid < C4) *reinterpret_cast<float4*>(qs + (buf_) * KC + tid * 4) = q##X; \
+    } while (0)
+    // one step: multiply step c out of tile buffer c & 1, move step c + 1 (ring set XN) into the other buffer, request
+    // step c + 1 + DEPTH into the set that just became free
+#define SV_WG_MUL(c)                                                                                       \
+    if (tid < cnt) {                                                                                       \
+      const float* tr = tile + ((size_t)((c) & 1) * ROWS + tid) * LDR;                                     \
+      const float* qb = qs + ((c) & 1) * KC;                                                               \
+      _Pragma("unroll 8") for (int s4 = 0; s4 < C4; ++s4) {                                                \
+        const float4 rv = *reinterpret_cast<const float4*>(tr + s4 * 4);                                   \
+        const float4 qv = *reinterpret_cast<const float4*>(qb + s4 * 4);                                   \
+        acc = fmaf(qv.x, rv.x, acc);                                                                       \
+        acc = fmaf(qv.y, rv.y, acc);                                                                       \
+        acc = fmaf(qv.z, rv.z, acc);                                                                       \
+        acc = fmaf(qv.w, rv.w, acc);                                                                       \
+      }                                                                                                    \
     }
+    // steady state (no conditions on the loads: the compiler's wait counts then leave the three younger steps in flight)
+#define SV_WG_STEP_FULL(c_, XN)                                                                            \
+    do {                                                                                                   \
+      const int c = (c_);                                                                                  \
+      SV_WG_MUL(c)                                                                                         \
+      SV_WG_STORE(XN, (c + 1) & 1);                                                                        \
+      SV_WG_LOAD(XN, c + 1 + DEPTH);                                                                       \
+      __syncthreads();                                                                                     \
+    } while (0)
+#define SV_WG_STEP(c_, XN)                                                                                 \
+    do {                                                                                                   \
+      const int c = (c_);                                                                                  \
+      if (c < nch) {                                                                                       \
+        if (tid < cnt) {                                                                                   \
+          const float* tr = tile + ((size_t)(c & 1) * ROWS + tid) * LDR;                                   \
+          const float* qb = qs + (c & 1) * KC;                                                             \
+          _Pragma("unroll 8") for (int s4 = 0; s4 < C4; ++s4) {                                            \
+            const float4 rv = *reinterpret_cast<const float4*>(tr + s4 * 4);                               \
+            const float4 qv = *reinterpret_cast<const float4*>(qb + s4 * 4);                               \
+            acc = fmaf(qv.x, rv.x, acc);                                                                   \
+            acc = fmaf(qv.y, rv.y, acc);                                                                   \
+            acc = fmaf(qv.z, rv.z, acc);                                                                   \
+            acc = fmaf(qv.w, rv.w, acc);                                                                   \
+          }                                                                                                \
+        }                                                                                                  \
+        if (c + 1 < nch) {                                                                                 \
+          SV_WG_STORE(XN, (c + 1) & 1);   /* waits for the loads of step c + 1 only */                     \
+          if (c + 1 + DEPTH < nch) SV_WG_LOAD(XN, c + 1 + DEPTH);                                          \
+        }                                                                                                  \
+        __syncthreads();                                                                                   \
+      }                                                                                                    \
+    } while (0)
+    float acc = 0.f;
+    // set A holds steps 0, 4, 8, ...; B 1, 5, ...; C 2, 6, ...; D 3, 7, ...
+    SV_WG_LOAD(A, 0);
+    if (1 < nch) SV_WG_LOAD(B, 1);
+    if (2 < nch) SV_WG_LOAD(C, 2);
+    if (3 < nch) SV_WG_LOAD(D, 3);
+    SV_WG_STORE(A, 0);
+    if (4 < nch) SV_WG_LOAD(A, 4);
+    __syncthreads();
+    int c0 = 0;
+    for (; c0 + 3 + 1 + DEPTH < nch; c0 += 4) {   // every load of these four steps exists
+      SV_WG_STEP_FULL(c0, B);
+      SV_WG_STEP_FULL(c0 + 1, C);
+      SV_WG_STEP_FULL(c0 + 2, D);
+      SV_WG_STEP_FULL(c0 + 3, A);
+    }
+    for (; c0 < nch; c0 += 4) {                    // the last steps: nothing (or not everything) left to request
+      SV_WG_STEP(c0, B);
+      SV_WG_STEP(c0 + 1, C);
+      SV_WG_STEP(c0 + 2, D);
+      SV_WG_STEP(c0 + 3, A);
+    }
+#undef SV_WG_STEP
+#undef SV_WG_STEP_FULL
+#undef SV_WG_MUL
+#undef SV_WG_STORE
+#undef SV_WG_LOAD
+#undef SV_WG_DECL
     if (tid < cnt) {
       const uint32_t id = ids[tid];
       a[base + tid] = ((uint64_t)f2key_(sv_d2(q2, rn[id], acc)) << 32) | id;
@@ -1627,19 +1739,12 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
     if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<true>), lds));
     hipLaunchKernelGGL(refine_exact_kernel<true>, SV_REFINE_ARGS);
   } else if (d % 128 == 0) {
-    // [2][64 rows][KC + 4] floats + [2][KC] query floats + [64] ids + the sort keys: KC = 256 (133 KiB + keys) unless the list is
-    // a second-tier one (up to 8192 keys = 64 KiB), which takes KC = 128
-    const bool big = d % 256 == 0 && (size_t)(2 * 64 * 260 + 2 * 256 + 64) * 4 + (size_t)rpad * 8 <= 160 * 1024;
-    const int kc = big ? 256 : 128;
-    lds = (size_t)(2 * 64 * (kc + 4) + 2 * kc + 64) * 4 + (size_t)rpad * 8;
+    // [2][64 rows][132] floats + [2][128] query floats + [64] ids + the sort keys (<= 64 KiB for a second-tier list)
+    lds = (size_t)(2 * 64 * 132 + 2 * 128 + 64) * 4 + (size_t)rpad * 8;
     if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "refine: a %d-entry list of %d-d rows exceeds the LDS", rcap, d);
-    if (big) {
-      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<256>), lds));
-      hipLaunchKernelGGL(refine_exact_wide_kernel<256>, SV_REFINE_ARGS);
-    } else {
-      SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_wide_kernel<128>), lds));
-      hipLaunchKernelGGL(refine_exact_wide_kernel<128>, SV_REFINE_ARGS);
-    }
+    auto kern = refine_exact_wide_kernel<128, 4>;
+    if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, SV_REFINE_ARGS);
   } else {
     lds = (size_t)rpad * 8;
     if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<false>), lds));
