@@ -1279,10 +1279,22 @@ __global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict
   }
 }
 
+// sum over the 64 lanes, returned wave-uniform: quad swaps, half-row and row mirrors (DPP: no LDS crossbar), then the four
+// row sums through readlane
+__device__ __forceinline__ uint32_t wave_sum_u32_(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);   // row_mirror
+  return (uint32_t)(__builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+                    __builtin_amdgcn_readlane(x, 48));
+}
+
 // The same ranking for lists of up to 4096 candidates (every list of the low-rank level scheme, and nearly every list of
 // the rigorous one), one WAVE per query instead of one 256-thread workgroup: the keys live in registers (4, 16 or 64 per
 // lane, by the list's length), the rank-th smallest is found by a binary MSB-first radix select whose per-bit counts are
-// ballots + scalar population counts, the refine list is compacted by ballots.  No LDS, no barriers.  Longer lists are
+// per-lane sums + one DPP wave reduction, the refine list is compacted by ballots.  No LDS, no barriers.  Longer lists are
 // left to select_approx_kernel (todo[row] = 1).
 // select_small_body: the ranking itself for lists of at most 64 * PER keys (PER register slots per lane, loops fully
 // unrolled: a run-time bound on the slot loops cost a scalar branch per slot and bit -- 40 us per launch).
@@ -1313,12 +1325,14 @@ __device__ __forceinline__ void select_small_body(const float* __restrict__ cd2,
     uint32_t prefix = 0, mask = 0, rem = (uint32_t)k;
     for (int bit = 31; bit >= 0; --bit) {
       const uint32_t b = 1u << bit;
-      // keys that match the prefix so far and have this bit clear, counted over the wave by ballots (a compare + a scalar
-      // population count per key slot: the butterfly of six cross-lane shuffles per bit it replaces was ~8 us of pure
-      // LDS-crossbar latency per launch)
-      uint32_t zeros = 0;
+      // keys that match the prefix so far and have this bit clear: counted per lane (a compare + an add per key slot), then
+      // ONE wave sum per bit by DPP row reductions + four readlanes.  (The butterfly of six ds_bpermute shuffles it replaces
+      // was ~8 us of LDS-crossbar latency per launch; a ballot + scalar popcount per slot stalls on the VALU -> SALU
+      // hand-over of every compare: 42 us for 64 slots.)
+      uint32_t zl = 0;
 #pragma unroll
-      for (int i = 0; i < PER; ++i) zeros += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((key[i] & (mask | b)) == prefix));
+      for (int i = 0; i < PER; ++i) zl += ((key[i] & (mask | b)) == prefix) ? 1u : 0u;
+      const uint32_t zeros = wave_sum_u32_(zl);
       if (rem > zeros) {
         rem -= zeros;
         prefix |= b;
@@ -1379,12 +1393,12 @@ __global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict_
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nq) return;
   const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];   // fixed_cnt: every row is a list of that length
-  if (c > (uint32_t)(64 * PER) && c <= (uint32_t)cap && !ovf_rows[row]) {   // long list: the workgroup kernel ranks it
+  if (todo && c > (uint32_t)(64 * PER) && c <= (uint32_t)cap && !ovf_rows[row]) {   // long list: the workgroup kernel ranks it
     if (l == 0) todo[row] = 1u;
     return;
   }
   if (l == 0) {
-    todo[row] = 0u;
+    if (todo) todo[row] = 0u;
     if (mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero (no memset launch between the levels)
   }
   const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
@@ -1395,7 +1409,9 @@ __global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict_
       else thr_out[row] = -INFINITY;
     }
   };
-  if (c > (uint32_t)cap || ovf_rows[row] || (check && (int)c < k)) {
+  // todo == null (a handful of queries: the workgroup kernel is not even launched): a list beyond the wave's 4096 keys is
+  // treated like an overflowing one -- the query is redone on the exact path
+  if (c > (uint32_t)cap || (!todo && c > (uint32_t)(64 * PER)) || ovf_rows[row] || (check && (int)c < k)) {
     flag_row();
     return;
   }
@@ -1404,6 +1420,9 @@ __global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict_
                          ovf_count, rovf_rows, rovf_count, ref_lim);
   else if (c <= 1024u)
     select_small_body<16>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+                          ovf_count, rovf_rows, rovf_count, ref_lim);
+  else if (c <= 2048u)
+    select_small_body<32>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
                           ovf_count, rovf_rows, rovf_count, ref_lim);
   else
     select_small_body<64>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
@@ -1416,12 +1435,18 @@ int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, const float* c
                             uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, uint32_t* rovf_count, float* ref_lim,
                             int fixed_cnt) {
   if (nq <= 0) return SEGVLAD_OK;
-  SV_HIP(ctx->s_sel_todo.reserve((size_t)nq * 4));
-  uint32_t* todo = ctx->s_sel_todo.as<uint32_t>();
+  // a single query image (<= 128 rows): lists beyond 4096 entries are as good as unheard of there, and every launch of a
+  // streaming pass is ~10 us of its ~500: the workgroup kernel is left out (select_small flags such a row for the exact path)
+  const bool wave_only = nq <= 128 || (fixed_cnt >= 0 && fixed_cnt <= 4096);
+  uint32_t* todo = nullptr;
+  if (!wave_only) {
+    SV_HIP(ctx->s_sel_todo.reserve((size_t)nq * 4));
+    todo = ctx->s_sel_todo.as<uint32_t>();
+  }
   hipLaunchKernelGGL(select_small_kernel, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cand_cnt, cand_d2, cand_id, nq, cap, rank, mode,
                      check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, todo,
                      rovf_rows, rovf_count, ref_lim, fixed_cnt);
-  if (fixed_cnt >= 0 && fixed_cnt <= 4096) {   // every list is ranked by the wave kernel: nothing left for the workgroup kernel
+  if (wave_only) {   // every list is ranked (or flagged) by the wave kernel
     SV_HIP(hipGetLastError());
     return SEGVLAD_OK;
   }

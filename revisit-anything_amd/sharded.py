@@ -91,6 +91,10 @@ class ShardedSegmentIndex:
             return local_rows
         mx = max(rows_per_rank)
         x = local_rows.contiguous()
+        if min(rows_per_rank) == mx:   # equal slices (the usual case): ONE all_gather_into_tensor, no padding, no trimming
+            out = torch.empty((self.world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(out, x, group=self.group)
+            return out
         if x.shape[0] < mx:
             x = torch.cat([x, x.new_zeros((mx - x.shape[0],) + tuple(x.shape[1:]))])
         parts = [torch.empty_like(x) for _ in range(self.world)]
@@ -137,8 +141,11 @@ class ShardedSegmentIndex:
         """search -> keep k_vote, 2-d^2 -> vote with the global segment->image map.  The global min/max of the
         vote (func_vpr.py:212-213) is taken over the merged (global) similarities, so it needs no extra collective."""
         if self.world > 1:
-            # the reference searches 200 and keeps 50 (place_rec_main.py:56,78): only the kept columns are exchanged
-            d2, idx = self.search(Q, k_vote, k_local=k_search)
+            # The reference searches 200 and keeps 50 (place_rec_main.py:56,78).  The global top-50 is contained in the union
+            # of the per-shard top-50 lists, and an exact search returns the same first 50 rows whatever depth it is asked
+            # for (ascending by (distance, id)): every shard searches -- and refines -- k_vote deep, not k_search, and only
+            # those columns travel.  (k_search only matters to a single index, which mirrors the reference's call.)
+            d2, idx = self.search(Q, k_vote)
         else:
             d2, idx = self.search(Q, k_search)
         sims, m = self.be.sims_from_d2(d2, idx, k_vote)

@@ -115,3 +115,62 @@ def test_rccl_backend_smoke_world_size_1(tmp_path):
     s.close()
     mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     assert open(tmp_path / "ok0").read() == "True"
+
+
+def _nccl2_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device(f"cuda:{rank}")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from revisit_anything_amd.engine import SegVLADEngine
+    from revisit_anything_amd.sharded import ShardedSegmentIndex, shard_images
+
+    R, img, Q, tau, off, n_img, S = _problem()
+    eng = SegVLADEngine(rank)
+    ib = shard_images(n_img, world)
+    rows = slice(int(ib[rank]) * S, int(ib[rank + 1]) * S)
+    idx = ShardedSegmentIndex(eng, device=dev)
+    idx.build(torch.from_numpy(R[rows]).to(dev), img[rows])
+    Qd = torch.from_numpy(Q).to(dev)
+    # every rank describes nothing here; the query rows are split and gathered like bench.py's descriptors
+    qb = [(r * Q.shape[0]) // world for r in range(world + 1)]
+    Qg = idx.gather_rows(Qd[qb[rank]:qb[rank + 1]].contiguous(), [qb[r + 1] - qb[r] for r in range(world)])
+    d2, ids = idx.search(Qg, 60)
+    pred, sc, m, sims = idx.retrieve(Qg, off, k_search=60, k_vote=50, n_top=5, want_scores=True)
+    np.savez(os.path.join(out_dir, f"n{rank}.npz"), d2=d2.cpu().numpy(), ids=ids.cpu().numpy(), pred=pred.cpu().numpy(),
+             sc=sc.cpu().numpy(), q=Qg.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_two_gpus_equal_single_index(tmp_path):
+    """RCCL with world size 2 on two DEVICES (skipped on a 1-GPU box: RCCL refuses two ranks on one GPU): the sharded
+    search / retrieve over xGMI must equal the single index bit for bit -- so that the driver's multi-GPU bench is not the
+    first time more than one rank runs."""
+    import torch
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_nccl2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    R, img, Q, tau, off, n_img, S = _problem()
+    eng = SegVLADEngine(0)
+    eng.db_add(R, img)
+    d2, ids = eng.search(Q, 60)
+    sims, m = eng.sims_from_d2(d2, ids, 50)
+    pred, sc = eng.vote(m, sims, off, n_top=5)
+    for r in range(2):
+        z = np.load(tmp_path / f"n{r}.npz")
+        assert np.array_equal(z["q"], Q)
+        assert np.array_equal(z["ids"], ids.cpu().numpy()) and np.array_equal(z["d2"], d2.cpu().numpy())
+        assert np.array_equal(z["pred"], pred.cpu().numpy()) and np.array_equal(z["sc"], sc.cpu().numpy())
