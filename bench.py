@@ -182,6 +182,8 @@ def parse():
     p.add_argument("--no-sub-records", action="store_true", help="skip the 'config2' (raw K*D search, BASELINE configs[1]) and "
                    "'redundant_db' (sibling groups of 31) sub-records of the N=1 line")
     p.add_argument("--search-stats", action="store_true", help="record candidate / refine list occupancies (one extra read-back per search)")
+    p.add_argument("--native-comm", action="store_true", help="N>1: exchange through the C-ABI's own RCCL communicator "
+                   "(segvlad_search_sharded / segvlad_allgather_rows) instead of torch.distributed collectives")
     p.add_argument("--no-ubench", action="store_true", help="skip the live MFMA ceiling micro-benchmark (tools/ubench/mfma_peak)")
     return p.parse_args()
 
@@ -336,7 +338,7 @@ def run(a, top=True):
         rows[(b0 - r_lo) * S:(b0 - r_lo + nb) * S] = d
     del tok, msk
     img_of_seg = torch.arange(r_lo, r_hi, device=dev, dtype=torch.int32).repeat_interleave(S)
-    index = ShardedSegmentIndex(eng, rank=rank, world=world, device=dev)
+    index = ShardedSegmentIndex(eng, rank=rank, world=world, device=dev, native_comm=a.native_comm and world > 1)
     index.build(rows, img_of_seg)
     rows_keep = rows if (world == 1 and not a.no_cpu_baseline) else None   # host copy source for the CPU-baseline leg
     del rows
@@ -628,7 +630,7 @@ def run(a, top=True):
         "config": {"workload": f"{nQ} query images x {S} seg vs {nR * S}-segment DB ({nR} ref images), {W}x{H} -> {N} tokens, "
                                f"D={D}, K={K}, {'PCA ' + str(P) if use_pca else 'raw K*D'}, order {a.order}, search 200 / vote 50",
                    "query_images": nQ, "db_segments": nR * S, "segments_per_image": S, "clusters": K, "desc_dim": D,
-                   "tokens": N, "pca_dim": P if use_pca else None, "order": a.order, "parallelism": f"db-row-shard x{world}",
+                   "tokens": N, "pca_dim": P if use_pca else None, "order": a.order, "parallelism": f"db-row-shard x{world}" + (" (C-ABI RCCL communicator)" if a.native_comm and world > 1 else ""),
                    "query_own": a.query_own},
         "recall_at_1": recalls[0], "recall_at_5": recalls[4], "db_build_s": t_build,
         "sibling_group": a.group, "recall_at_1_within_sibling_group": recalls_group[0],

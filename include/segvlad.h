@@ -37,7 +37,8 @@ enum {
   SEGVLAD_ERR_HIP = -2,    /* a HIP runtime call failed                                        */
   SEGVLAD_ERR_STATE = -3,  /* call order (e.g. segvlad_images before segvlad_set_vocab)        */
   SEGVLAD_ERR_LIMIT = -4,  /* documented implementation limit exceeded                        */
-  SEGVLAD_ERR_NOMEM = -5
+  SEGVLAD_ERR_NOMEM = -5,
+  SEGVLAD_ERR_COMM = -6    /* RCCL: library not found, or a collective / communicator call failed */
 };
 
 #define SEGVLAD_VOTE_WT_BORDA_IM 0 /* get_matches(method="max_seg_topk_wt_borda_Im"), func_vpr.py:207-224 */
@@ -218,6 +219,32 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
  *      [9] query rows whose refine band held more rows than the first-tier list (512) and that were refined
  *          from their whole candidate list instead (second tier; temporally redundant databases)            */
 int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n);
+
+/* ---- row-sharded index over the GPUs of a node: one process (and one context) per GPU.
+ *      No reference counterpart -- the reference is single-process (place_rec_main.py:53-60 builds ONE faiss index);
+ *      this is SURVEY 8b/8e's own layer: rank r adds the rows [base_r, base_r + n_r) of the reference-segment matrix to
+ *      ITS context (segvlad_db_add), every rank searches the full query batch against its shard, the per-shard top-k
+ *      lists travel in ONE all-gather of packed 12-byte records {fp32 distance bits, int64 global id} over RCCL (xGMI
+ *      inside a node), and every rank merges them -- by distance, ties by lower global id: bit for bit what one index
+ *      over all rows returns.  RCCL is bound at run time (dlopen; a copy already in the process -- PyTorch-ROCm's -- is
+ *      shared): without it these calls return SEGVLAD_ERR_COMM and everything else keeps working.
+ *
+ *      segvlad_comm_unique_id   rank 0 draws the 128-byte id (HOST); it reaches the other ranks by any host channel
+ *                               (MPI, a file, torch.distributed's store ...)
+ *      segvlad_comm_init        collective over all ranks: binds an RCCL communicator to the context (its stream carries
+ *                               the collectives); world = 1 is valid
+ *      segvlad_comm_info        rank / world of the context's communicator (world 0 = none) and which RCCL was bound
+ *      segvlad_allgather_rows   [n_local][d] fp32 of every rank -> [world * n_local][d], rank order (equal slices): the
+ *                               query descriptors when every rank describes a slice of the query images
+ *      segvlad_search_sharded   global exact top-k (ascending (d2, id); (inf, -1) beyond the total row count), identical
+ *                               on every rank.  id_base = global index of this shard's first row.  Collective. */
+#define SEGVLAD_COMM_ID_BYTES 128
+int segvlad_comm_unique_id(void* id_out);
+int segvlad_comm_init(segvlad_ctx* ctx, const void* id, int rank, int world);
+int segvlad_comm_destroy(segvlad_ctx* ctx);
+int segvlad_comm_info(segvlad_ctx* ctx, int* rank_out, int* world_out, char* origin_out, int origin_len);
+int segvlad_allgather_rows(segvlad_ctx* ctx, const float* local_rows, int n_local, int d, float* all_rows);
+int segvlad_search_sharded(segvlad_ctx* ctx, const float* Q, int nq, int k, int64_t id_base, float* d2_out, int64_t* idx_out);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,8 @@ _f32p = C.c_void_p  # all bulk pointers are passed as raw addresses (host or dev
 
 SEGVLAD_OK = 0
 # error codes of include/segvlad.h (SegVLADError.code)
-SEGVLAD_ERR_ARG, SEGVLAD_ERR_HIP, SEGVLAD_ERR_STATE, SEGVLAD_ERR_LIMIT, SEGVLAD_ERR_NOMEM = -1, -2, -3, -4, -5
+SEGVLAD_ERR_ARG, SEGVLAD_ERR_HIP, SEGVLAD_ERR_STATE, SEGVLAD_ERR_LIMIT, SEGVLAD_ERR_NOMEM, SEGVLAD_ERR_COMM = -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 VOTE_WT_BORDA_IM = 0
 VOTE_COUNT = 1
 
@@ -54,6 +55,12 @@ SIGNATURES = {
     "segvlad_stage_ms": (C.c_int, [c_ctx_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "segvlad_set_option": (C.c_int, [c_ctx_p, C.c_char_p, C.c_char_p]),
     "segvlad_search_stats": (C.c_int, [c_ctx_p, C.POINTER(C.c_int64), C.c_int]),
+    "segvlad_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "segvlad_comm_init": (C.c_int, [c_ctx_p, C.c_void_p, C.c_int, C.c_int]),
+    "segvlad_comm_destroy": (C.c_int, [c_ctx_p]),
+    "segvlad_comm_info": (C.c_int, [c_ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "segvlad_allgather_rows": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, _f32p]),
+    "segvlad_search_sharded": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_int64, _f32p, C.c_void_p]),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsegvlad_hip.so")
 SOURCES = ["api.hip", "vlad_kernels.hip", "gemm_kernels.hip", "select_kernels.hip", "vote_kernels.hip",
-           "knn_bf16_kernels.hip", "gemm_f16x3_kernels.hip", "project_kernels.hip"]
+           "knn_bf16_kernels.hip", "gemm_f16x3_kernels.hip", "project_kernels.hip", "comm.hip"]
 
 
 def _hipcc() -> str:
@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))

@@ -136,6 +136,7 @@ int segvlad_create(segvlad_ctx** out, int device_id) {
                                             {"SEGVLAD_KNN_HEURISTIC", "knn_heuristic"}, {"SEGVLAD_PCA_PATH", "pca_path"}};
   for (auto& kv : env_keys)
     if (const char* v = getenv(kv[0])) (void)segvlad_set_option(c, kv[1], v);
+  if (const char* v = getenv("SEGVLAD_RCCL_LIB")) snprintf(sv_rccl_lib_override, sizeof(sv_rccl_lib_override), "%s", v);
   if (getenv("SEGVLAD_KNN_FP32")) (void)segvlad_set_option(c, "knn_filter", "fp32");
   if (getenv("SEGVLAD_PCA_FP32")) (void)segvlad_set_option(c, "pca_arith", "fp32");
   c->err[0] = 0;
@@ -200,6 +201,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
   if (!ctx) return SEGVLAD_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  sv_comm_release(ctx);
   DevBuf* bufs[] = {&ctx->vocab,    &ctx->vocab_bt, &ctx->pca_mean, &ctx->pca_comps, &ctx->pca_scale, &ctx->db_rows,
                     &ctx->db_norms, &ctx->db_img,   &ctx->s_xt,     &ctx->s_labels,  &ctx->s_rnorm,   &ctx->s_gap,
                     &ctx->s_colmask, &ctx->s_gscale, &ctx->s_segimg, &ctx->s_segoff, &ctx->s_adjoff,  &ctx->s_dist,
@@ -210,7 +212,8 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_laboff,  &ctx->s_rnsorted, &ctx->s_ovf,   &ctx->s_fb_q,   &ctx->s_fb_d2,  &ctx->s_fb_idx,
                     &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
                     &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys, &ctx->s_pz, &ctx->s_rowbase,
-                    &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part, &ctx->s_rovf,   &ctx->s_ref_lim};
+                    &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part, &ctx->s_rovf,   &ctx->s_ref_lim,
+                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)

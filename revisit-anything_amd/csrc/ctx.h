@@ -181,6 +181,10 @@ struct segvlad_ctx {
       s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
       s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part,
       s_rovf, s_ref_lim;
+  // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time, the exchange buffers
+  void* comm = nullptr;   // ncclComm_t
+  int comm_rank = 0, comm_world = 1;
+  DevBuf s_sh_d2, s_sh_idx, s_sh_rec, s_sh_all, s_sh_d2c, s_sh_idc;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -193,6 +197,10 @@ struct segvlad_ctx {
 // hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes), remembered per (device, kernel): the driver call takes a
 // lock and tens of microseconds; a launcher that repeats it before every launch leaves the GPU idle between kernels
 hipError_t sv_max_dyn_lds(const void* fn, size_t bytes);
+
+extern char sv_rccl_lib_override[256];   // comm.hip; filled by segvlad_create from SEGVLAD_RCCL_LIB
+// comm.hip: destroys the context's communicator, if any (segvlad_destroy / segvlad_comm_destroy)
+void sv_comm_release(segvlad_ctx* ctx);
 
 // ---- pointer staging ---------------------------------------------------------------------------
 bool sv_is_device_ptr(const void* p);

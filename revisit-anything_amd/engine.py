@@ -112,6 +112,52 @@ class SegVLADEngine:
         self._check(self.lib.segvlad_stage_ms(self._h, stage.encode(), C.byref(ms), C.byref(n)), f"stage_ms({stage})")
         return ms.value, n.value
 
+    # ---- row-sharded index over several GPUs (segvlad_comm_* / segvlad_search_sharded: RCCL bound at run time) ----------
+    def comm_unique_id(self) -> bytes:
+        """128-byte RCCL id drawn by ONE rank; hand it to every rank's comm_init over any host channel."""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = self.lib.segvlad_comm_unique_id(buf)
+        if rc != 0:
+            raise SegVLADError(f"comm_unique_id failed ({rc}): RCCL could not be bound (librccl.so; SEGVLAD_RCCL_LIB)", code=int(rc))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        """Collective: bind an RCCL communicator (world ranks, one GPU each) to this context."""
+        if len(uid) != _lib.COMM_ID_BYTES:
+            raise ValueError("uid must be the 128 bytes of comm_unique_id()")
+        self._stream()
+        self._check(self.lib.segvlad_comm_init(self._h, C.c_char_p(uid), int(rank), int(world)), "comm_init")
+
+    def comm_destroy(self):
+        self._check(self.lib.segvlad_comm_destroy(self._h), "comm_destroy")
+
+    def comm_info(self) -> dict:
+        r, w = C.c_int(), C.c_int()
+        o = C.create_string_buffer(256)
+        self._check(self.lib.segvlad_comm_info(self._h, C.byref(r), C.byref(w), o, 256), "comm_info")
+        return {"rank": r.value, "world": w.value, "rccl": o.value.decode(errors="replace")}
+
+    def allgather_rows(self, x) -> torch.Tensor:
+        """[n_local, d] of every rank -> [world * n_local, d] in rank order (equal slices), one RCCL all-gather."""
+        t = _as(x, np.float32, torch.float32)
+        n, d = int(t.shape[0]), int(t.shape[1])
+        out = self._empty((self.comm_info()["world"] * n, d), torch.float32)
+        self._stream()
+        self._check(self.lib.segvlad_allgather_rows(self._h, _ptr(t), n, d, _ptr(out)), "allgather_rows")
+        self._keep = [t]
+        return out
+
+    def search_sharded(self, Q, k: int, id_base: int):
+        """Collective: global exact top-k over all ranks' shards, identical on every rank (d2 [nq,k], GLOBAL ids [nq,k])."""
+        q = _as(Q, np.float32, torch.float32)
+        nq = int(q.shape[0])
+        d2 = self._empty((nq, k), torch.float32)
+        idx = self._empty((nq, k), torch.int64)
+        self._stream()
+        self._check(self.lib.segvlad_search_sharded(self._h, _ptr(q), nq, int(k), int(id_base), _ptr(d2), _ptr(idx)), "search_sharded")
+        self._keep = [q]
+        return d2, idx
+
     # ---- vocabulary -------------------------------------------------------------------------------
     def set_vocab(self, c_centers):
         c = _as(c_centers, np.float32, torch.float32)

@@ -35,8 +35,13 @@ def shard_images(n_images: int, world: int) -> np.ndarray:
 
 class ShardedSegmentIndex:
     def __init__(self, backend, rank: Optional[int] = None, world: Optional[int] = None, group=None,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, native_comm: bool = False):
+        """native_comm: exchange through the C-ABI's own RCCL communicator (segvlad_comm_init / segvlad_search_sharded /
+        segvlad_allgather_rows: pack, all-gather, unpack and merge on the context's stream, no torch collective on the data
+        path) instead of torch.distributed; the 128-byte communicator id still travels over torch.distributed's host
+        channel.  What a C caller of include/segvlad.h gets."""
         self.be = backend
+        self.native = bool(native_comm)
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = rank if rank is not None else (dist.get_rank(group) if self.distributed else 0)
@@ -72,6 +77,11 @@ class ShardedSegmentIndex:
         self.img_of_seg_global = img.contiguous()
         if n_local:
             self.be.db_add(local_rows, None)
+        if self.native:
+            uid = [self.be.comm_unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(uid, src=0, group=self.group)
+            self.be.comm_init(uid[0], self.rank, self.world)
 
     @property
     def n_total(self) -> int:
@@ -91,6 +101,8 @@ class ShardedSegmentIndex:
             return local_rows
         mx = max(rows_per_rank)
         x = local_rows.contiguous()
+        if self.native and min(rows_per_rank) == mx and x.dim() == 2:
+            return self.be.allgather_rows(x)
         if min(rows_per_rank) == mx:   # equal slices (the usual case): ONE all_gather_into_tensor, no padding, no trimming
             out = torch.empty((self.world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             dist.all_gather_into_tensor(out, x, group=self.group)
@@ -107,6 +119,8 @@ class ShardedSegmentIndex:
         k_local >= k: search depth used on each shard before the exchange (only the first k columns travel:
         the global top-k is contained in the union of the per-shard top-k lists)."""
         nq = int(Q.shape[0])
+        if self.native:   # local search, packed all-gather, merge: one C-ABI call on the context's stream
+            return self.be.search_sharded(Q, k, int(self.row_start[self.rank]))
         if self.n_local:
             d2, idx = self.be.search(Q, max(k, k_local or k))
             d2 = torch.as_tensor(d2).to(self.device)[:, :k].contiguous()

@@ -133,7 +133,7 @@ def _nccl2_worker(rank, world, port, out_dir):
     eng = SegVLADEngine(rank)
     ib = shard_images(n_img, world)
     rows = slice(int(ib[rank]) * S, int(ib[rank + 1]) * S)
-    idx = ShardedSegmentIndex(eng, device=dev)
+    idx = ShardedSegmentIndex(eng, device=dev, native_comm=bool(int(os.environ.get("SEGVLAD_TEST_NATIVE_COMM", "0"))))
     idx.build(torch.from_numpy(R[rows]).to(dev), img[rows])
     Qd = torch.from_numpy(Q).to(dev)
     # every rank describes nothing here; the query rows are split and gathered like bench.py's descriptors
@@ -160,7 +160,6 @@ def test_rccl_two_gpus_equal_single_index(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_nccl2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     from revisit_anything_amd.engine import SegVLADEngine
 
     R, img, Q, tau, off, n_img, S = _problem()
@@ -169,8 +168,60 @@ def test_rccl_two_gpus_equal_single_index(tmp_path):
     d2, ids = eng.search(Q, 60)
     sims, m = eng.sims_from_d2(d2, ids, 50)
     pred, sc = eng.vote(m, sims, off, n_top=5)
+    for native in ("0", "1"):          # torch.distributed collectives, then the C-ABI's own RCCL communicator
+        os.environ["SEGVLAD_TEST_NATIVE_COMM"] = native
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_nccl2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+        _check_two(tmp_path, Q, ids, d2, pred, sc)
+
+
+def _check_two(tmp_path, Q, ids, d2, pred, sc):
     for r in range(2):
         z = np.load(tmp_path / f"n{r}.npz")
         assert np.array_equal(z["q"], Q)
         assert np.array_equal(z["ids"], ids.cpu().numpy()) and np.array_equal(z["d2"], d2.cpu().numpy())
         assert np.array_equal(z["pred"], pred.cpu().numpy()) and np.array_equal(z["sc"], sc.cpu().numpy())
+
+
+def test_cabi_sharded_entry_world_1(tmp_path):
+    """segvlad_comm_* / segvlad_search_sharded / segvlad_allgather_rows (RCCL bound at run time by the library itself, no
+    torch.distributed anywhere) at world size 1 on the one GPU of this box: the sharded search equals the plain search
+    with ids shifted by id_base, the row gather is the identity, the communicator reports what it is."""
+    import torch
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    R, img, Q, tau, off, n_img, S = _problem()
+    eng = SegVLADEngine(0)
+    eng.db_add(R[:20000])
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(uid, 0, 1)
+    info = eng.comm_info()
+    assert info["rank"] == 0 and info["world"] == 1 and "rccl" in info["rccl"].lower()
+    d2, ids = eng.search(Q, 60)
+    sd2, sids = eng.search_sharded(Q, 60, id_base=123456789012)
+    assert torch.equal(sd2, d2) and torch.equal(sids, ids + 123456789012)          # 64-bit ids survive the 12-byte records
+    x = torch.rand(37, 64, device=eng.device)
+    assert torch.equal(eng.allgather_rows(x), x)
+    # k beyond the shard's rows: (inf, -1) padding stays (-1 is not shifted)
+    e2 = SegVLADEngine(0)
+    e2.db_add(R[:5])
+    e2.comm_init(e2.comm_unique_id(), 0, 1)
+    pd2, pids = e2.search_sharded(Q[:3], 8, id_base=1000)
+    assert bool((pids[:, 5:] == -1).all()) and bool(torch.isinf(pd2[:, 5:]).all()) and bool((pids[:, :5] >= 1000).all())
+    e2.comm_destroy()
+    assert e2.comm_info()["world"] == 0
+    eng.comm_destroy()
+    # the sharded index with native_comm (single rank): same results as without
+    from revisit_anything_amd.sharded import ShardedSegmentIndex
+
+    a = ShardedSegmentIndex(SegVLADEngine(0), rank=0, world=1, device=eng.device, native_comm=True)
+    a.build(torch.from_numpy(R).to(eng.device), img)
+    b = ShardedSegmentIndex(SegVLADEngine(0), rank=0, world=1, device=eng.device)
+    b.build(torch.from_numpy(R).to(eng.device), img)
+    pa = a.retrieve(torch.from_numpy(Q).to(eng.device), off, k_search=60, k_vote=50, n_top=5)
+    pb = b.retrieve(torch.from_numpy(Q).to(eng.device), off, k_search=60, k_vote=50, n_top=5)
+    assert torch.equal(pa[0], pb[0]) and torch.equal(pa[2], pb[2]) and torch.equal(pa[3], pb[3])
