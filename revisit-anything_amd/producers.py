@@ -149,12 +149,11 @@ SAM_PIXEL_STD = (58.395, 57.12, 57.375)
 
 
 def build_point_grid(n_per_side: int) -> np.ndarray:
-    """utils/amg.py build_point_grid: an n x n grid of (x, y) in [0, 1], cell centres, x fastest."""
-    offset = 1.0 / (2 * n_per_side)
-    pts = np.linspace(offset, 1 - offset, n_per_side)
-    xs = np.tile(pts[None, :], (n_per_side, 1))
-    ys = np.tile(pts[:, None], (1, n_per_side))
-    return np.stack([xs, ys], axis=-1).reshape(-1, 2)
+    """The prompt grid of SamAutomaticMaskGenerator (utils/amg.py:179-186): the n x n cell centres of the unit square as
+    (x, y) rows, x running fastest.  Pinned bit for bit against the vendored function (tests/golden/producers.npz)."""
+    centres = np.linspace(0.5 / n_per_side, 1.0 - 0.5 / n_per_side, n_per_side)
+    gx, gy = np.meshgrid(centres, centres)             # 'xy' indexing: gx varies along the last axis
+    return np.column_stack([gx.ravel(), gy.ravel()])
 
 
 def stability_score(mask_logits: torch.Tensor, mask_threshold: float, offset: float) -> torch.Tensor:
@@ -166,21 +165,22 @@ def stability_score(mask_logits: torch.Tensor, mask_threshold: float, offset: fl
 
 
 def mask_boxes(masks: torch.Tensor) -> torch.Tensor:
-    """utils/amg.py batched_mask_to_box: XYXY boxes of bool masks [n, H, W]; an empty mask gives [0, 0, 0, 0]."""
+    """Tight XYXY boxes (inclusive pixel coordinates) of bool masks [..., H, W]; an empty mask gives [0, 0, 0, 0] -- the
+    output of utils/amg.py:303-338 (batched_mask_to_box), pinned against it in tests/golden/producers.npz.  Found from the
+    first / last occupied row and column (argmax of the occupancy profile and of its mirror image)."""
+    lead = masks.shape[:-2]
     if masks.numel() == 0:
-        return torch.zeros((*masks.shape[:-2], 4), dtype=torch.int64, device=masks.device)
+        return torch.zeros((*lead, 4), dtype=torch.int64, device=masks.device)
     h, w = masks.shape[-2:]
-    in_h = masks.any(dim=-1)
-    hc = in_h * torch.arange(h, device=masks.device)[None, :]
-    bottom = hc.max(dim=-1).values
-    top = (hc + h * (~in_h)).min(dim=-1).values
-    in_w = masks.any(dim=-2)
-    wc = in_w * torch.arange(w, device=masks.device)[None, :]
-    right = wc.max(dim=-1).values
-    left = (wc + w * (~in_w)).min(dim=-1).values
-    empty = (right < left) | (bottom < top)
-    out = torch.stack([left, top, right, bottom], dim=-1)
-    return out * (~empty).unsqueeze(-1)
+    rows = masks.any(dim=-1).to(torch.uint8)            # [..., H]: which rows hold a pixel
+    cols = masks.any(dim=-2).to(torch.uint8)            # [..., W]
+    top = rows.argmax(dim=-1)
+    bottom = (h - 1) - rows.flip(-1).argmax(dim=-1)
+    left = cols.argmax(dim=-1)
+    right = (w - 1) - cols.flip(-1).argmax(dim=-1)
+    box = torch.stack([left, top, right, bottom], dim=-1)
+    occupied = rows.amax(dim=-1).to(torch.bool)
+    return box * occupied.unsqueeze(-1)
 
 
 def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:

@@ -2,6 +2,8 @@
 reference's extractor returns (value facet of layer L, CLS dropped, utilities.py:219-288), the pre-processing follows
 getAnyLocFt / process_single_DINO (func_vpr.py:489-506, 549-562), and the output has the ``ift_dino`` layout the hot
 path consumes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -144,6 +146,61 @@ def test_sam_helpers_match_their_definitions():
         if all(iou(boxes[i].tolist(), boxes[j].tolist()) <= 0.3 for j in want):
             want.append(int(i))
     assert keep == want
+
+
+def _stub_extractor(seed: int, D: int):
+    """The stand-in extractor the DINO fixtures were generated with (tools/make_golden.py::stub_extractor)."""
+    g = torch.Generator().manual_seed(seed)
+    Wm = torch.randn(6, D, generator=g)
+
+    def f(x):
+        p = torch.nn.functional.avg_pool2d(x, 14)
+        p2 = torch.nn.functional.avg_pool2d(x * x, 14)
+        t = torch.cat([p, p2], 1).flatten(2).transpose(1, 2)
+        return torch.tanh(t @ Wm) + 0.25 * (t @ Wm)
+
+    return f
+
+
+def test_sam_helpers_equal_the_vendored_amg_utilities(golden_dir):
+    """The reference's OWN utilities (sam/segment_anything/utils/amg.py: build_point_grid :179-186,
+    calculate_stability_score :156-176, batched_mask_to_box :303-338, box_xyxy_to_xywh :91-96), executed by
+    tools/make_golden.py where they lie -- not expectations written by hand."""
+    z = np.load(os.path.join(golden_dir, "producers.npz"))
+    for n in (1, 3, 16, 32):
+        assert np.array_equal(pr.build_point_grid(n), z[f"grid_{n}"])                          # bit-identical float64
+    for j in range(3):
+        thr, off = (float(v) for v in z[f"stab_{j}_args"])
+        got = pr.stability_score(torch.from_numpy(z[f"stab_{j}_logits"]), thr, off).numpy()
+        assert got.shape == z[f"stab_{j}_out"].shape and np.array_equal(got, z[f"stab_{j}_out"])
+    shape = tuple(int(v) for v in z["box_masks_shape"])
+    m = torch.from_numpy(np.unpackbits(z["box_masks"], axis=-1)[..., :shape[-1]].astype(bool))
+    b = pr.mask_boxes(m)
+    assert np.array_equal(b.numpy(), z["box_out"].astype(np.int64))                            # empty -> zeros, full, 1 pixel
+    assert np.array_equal(pr.mask_boxes(m.reshape(3, 3, *shape[1:])).numpy(), z["box_out_nd"].astype(np.int64))
+    assert np.array_equal(pr.mask_boxes(m[0][None]).numpy()[0], z["box_out_2d"].astype(np.int64))
+    # the record's XYWH box (automatic_mask_generator.py:157: box_xyxy_to_xywh) as generate() forms it
+    xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], dim=1).numpy()
+    assert np.array_equal(xywh, z["box_xywh"].astype(np.int64))
+
+
+def test_dino_tokens_equal_getAnyLocFt_and_process_single_DINO(golden_dir):
+    """func_vpr.py:489-506 (getAnyLocFt) and :549-562 (process_single_DINO) executed with a seeded stub extractor on
+    three image sizes (two of them not multiples of 14: CenterCrop offsets), against image_to_tokens / process_single_DINO
+    here fed with the same extractor."""
+    z = np.load(os.path.join(golden_dir, "producers.npz"))
+    for j in range(3):
+        _, H, W, D, seed = (int(v) for v in z[f"dino_{j}_args"])
+        img_bgr = z[f"dino_{j}_img"]
+        assert img_bgr.shape == (H, W, 3)
+        ext = _stub_extractor(seed, D)
+        img_p, tok = pr.process_single_DINO({"resize": False}, img_bgr, ext)
+        assert np.array_equal(img_p, img_bgr[:, :, ::-1])
+        assert tok.shape == z[f"dino_{j}_feat_norm"].shape == (1, D, H // 14, W // 14)
+        assert np.abs(tok.numpy() - z[f"dino_{j}_feat_norm"]).max() < 2e-6                     # same ops; fp32 reduction orders
+        raw = pr.image_to_tokens(np.ascontiguousarray(img_bgr[:, :, ::-1]), ext, None, normalize=False)
+        assert np.abs(raw.numpy() - z[f"dino_{j}_raw"]).max() < 2e-5
+        assert np.abs(np.linalg.norm(tok.numpy(), axis=1) - 1.0).max() < 1e-5
 
 
 def test_sam_auto_masks_records_and_half_resolution(tiny_sam, tmp_path):

@@ -384,5 +384,121 @@ def main():
     print("golden bytes:", tot)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# producers: the vendored SAM utilities and the reference's DINO token extraction, executed where they lie
+# ---------------------------------------------------------------------------------------------------------------------
+def stub_extractor(seed: int, D: int):
+    """Deterministic stand-in for the DINOv2 value-facet extractor (weights are not available): [1, 3, h, w] normalised
+    image -> [1, (h/14)(w/14), D]: per-patch channel means and mean squares through a seeded linear map + tanh.  The tests
+    rebuild the same function from the seed (tests/test_producers.py::_stub_extractor)."""
+    g = torch.Generator().manual_seed(seed)
+    Wm = torch.randn(6, D, generator=g)
+
+    def f(x):
+        p = torch.nn.functional.avg_pool2d(x, 14)                                  # [1, 3, h/14, w/14]
+        p2 = torch.nn.functional.avg_pool2d(x * x, 14)
+        t = torch.cat([p, p2], 1).flatten(2).transpose(1, 2)                       # [1, n, 6]
+        return torch.tanh(t @ Wm) + 0.25 * (t @ Wm)
+
+    return f
+
+
+def gen_producers():
+    """tests/golden/producers.npz:
+    * sam/segment_anything/utils/amg.py: build_point_grid, calculate_stability_score, batched_mask_to_box,
+      box_xyxy_to_xywh -- pure torch / numpy, executed unmodified;
+    * func_vpr.py: getAnyLocFt + process_single_DINO, executed with (a) the stub extractor above, (b) cv2.cvtColor as the
+      BGR->RGB channel flip it is (cfg['resize'] = False: cv2.resize is not restated here), (c) the three torchvision
+      transforms getAnyLocFt composes (ToTensor, Normalize, CenterCrop), restated from torchvision's documented semantics
+      because torchvision is not installable in this image -- so the DINO fixtures pin the reference's own flow (crop to
+      patch multiples, extractor call, reshape / permute, channel L2 normalisation), not torchvision itself."""
+    out = {}
+    amg = types.ModuleType("amg")
+    amg.__dict__.update(np=np, torch=torch, math=__import__("math"), deepcopy=__import__("copy").deepcopy)
+    from typing import Any, Dict, Generator, ItemsView, List, Tuple
+    amg.__dict__.update(Any=Any, Dict=Dict, Generator=Generator, ItemsView=ItemsView, List=List, Tuple=Tuple)
+    extract(f"{REF}/sam/segment_anything/utils/amg.py",
+            {"build_point_grid", "calculate_stability_score", "batched_mask_to_box", "box_xyxy_to_xywh"}, amg.__dict__)
+    for n in (1, 3, 16, 32):
+        out[f"grid_{n}"] = amg.build_point_grid(n)
+    g = torch.Generator().manual_seed(910)
+    for j, (shape, thr, off) in enumerate([((7, 24, 31), 0.0, 1.0), ((4, 3, 17, 20), 0.0, 1.0), ((5, 40, 40), 0.3, 0.7)]):
+        logits = torch.randn(shape, generator=g) * 2.0
+        out[f"stab_{j}_seed"] = np.array([910, j])
+        out[f"stab_{j}_logits"] = logits.numpy()
+        out[f"stab_{j}_args"] = np.array([thr, off])
+        out[f"stab_{j}_out"] = amg.calculate_stability_score(logits, thr, off).numpy()
+    # boxes: blobs, an empty mask, a full mask, a single pixel, extra leading dimensions
+    m = torch.rand((9, 30, 44), generator=g) > 0.93
+    m[2] = False
+    m[3] = True
+    m[4] = False
+    m[4, 17, 5] = True
+    m[5, :, :10] = False
+    m[6, :12, :] = False
+    out["box_masks"] = np.packbits(m.numpy(), axis=-1)
+    out["box_masks_shape"] = np.array(m.shape)
+    out["box_out"] = amg.batched_mask_to_box(m).numpy()
+    out["box_out_nd"] = amg.batched_mask_to_box(m.reshape(3, 3, 30, 44)).numpy()
+    out["box_out_2d"] = amg.batched_mask_to_box(m[0]).numpy()
+    # (per box, as automatic_mask_generator.py:157 calls it: the function indexes [2] / [3] of a single box)
+    out["box_xywh"] = np.stack([amg.box_xyxy_to_xywh(bx).numpy() for bx in torch.from_numpy(out["box_out"])])
+
+    # ---- getAnyLocFt / process_single_DINO ------------------------------------------------------------------------
+    class _Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    def _to_tensor():
+        return lambda img: torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0)
+
+    def _normalize(mean, std):
+        m_, s_ = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+        return lambda x: (x - m_) / s_
+
+    def _center_crop(size):
+        def f(x):
+            h, w = x.shape[-2:]
+            th, tw = size
+            top, left = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))
+            return x[..., top:top + th, left:left + tw]
+        return f
+
+    tvf = types.SimpleNamespace(Compose=_Compose, ToTensor=_to_tensor, Normalize=_normalize, CenterCrop=_center_crop)
+    cv2 = types.SimpleNamespace(COLOR_BGR2RGB=4, cvtColor=lambda img, code: np.ascontiguousarray(img[:, :, ::-1]),
+                                resize=None)
+    fv = types.ModuleType("func_vpr_dino")
+    fv.__dict__.update(np=np, torch=torch, tvf=tvf, cv2=cv2)
+    extract(f"{REF}/func_vpr.py", {"getAnyLocFt", "process_single_DINO"}, fv.__dict__)
+    rng = np.random.Generator(np.random.PCG64(920))
+    for j, (H, W, D) in enumerate([(233, 317, 48), (480, 640, 32), (300, 400, 24)]):
+        img_bgr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        ext = stub_extractor(930 + j, D)
+        cfg = {"resize": False, "dinov2": True}
+        img_p, feat_norm = fv.process_single_DINO(cfg, img_bgr, ext, "cpu")
+        raw = fv.getAnyLocFt(np.ascontiguousarray(img_bgr[:, :, ::-1]), ext, "cpu", upsample=False)
+        up = fv.getAnyLocFt(np.ascontiguousarray(img_bgr[:, :, ::-1]), ext, "cpu", upsample=True) if j == 0 else None
+        out[f"dino_{j}_args"] = np.array([920, H, W, D, 930 + j])
+        out[f"dino_{j}_img"] = img_bgr
+        out[f"dino_{j}_feat_norm"] = feat_norm.numpy()
+        out[f"dino_{j}_raw"] = raw.numpy()
+        assert np.array_equal(img_p, img_bgr[:, :, ::-1])
+        if up is not None:
+            out[f"dino_{j}_up_sample"] = up.numpy()[0, :4, ::37, ::41]                 # a thin slice of the up-sampled map
+    np.savez_compressed(f"{OUT}/producers.npz", **out)
+    print("producers.npz", {k: np.asarray(v).shape for k, v in out.items() if not k.endswith("_img")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "producers":
+        os.makedirs(OUT, exist_ok=True)
+        patch_cuda_to_cpu()
+        gen_producers()
+    else:
+        main()
+        gen_producers()
