@@ -281,6 +281,15 @@ def run(a, top=True):
         var = torch.logspace(-3, -6, P, device=dev)
         eng.pca_set(mean, comps, var, whiten=True)
         del comps
+    # The fused VLAD -> PCA call picks its form ("project" / "planes") per call from the batch size; the two agree to ~1e-5
+    # relative, not bit for bit.  Every describe of this run -- DB build, timed steps, the oracle check's 4-image batch --
+    # uses the form the TIMED batch would get, so that the check covers the measured path.
+    pca_path = None
+    if use_pca:
+        nql = int(shard_images(nQ, world)[rank + 1] - shard_images(nQ, world)[rank])
+        pca_path = "project" if (eng_pca_products(K * D, P) == 3 and D % 32 == 0 and P % 4 == 0 and S * K >= 1.25 * N
+                                 and nql * N >= 128 * K) else "planes"
+        eng.set_option("pca_path", pca_path)
     pipe = SegVLADPipeline(eng, H, W, 14, order=a.order, use_pca=use_pca)
     fac = ImageFactory(dev, C, N, S, Hm, Wm, a.query_own, a.group)
     # --pipeline: the describe stage gets its own context (vocabulary + PCA model) and its own stream, so that batch
@@ -288,6 +297,8 @@ def run(a, top=True):
     eng_d, pipe_d, s_desc = eng, pipe, None
     if a.pipeline:
         eng_d = SegVLADEngine(local)
+        if pca_path:
+            eng_d.set_option("pca_path", pca_path)
         eng_d.set_vocab(C_np)
         if use_pca:
             g = torch.Generator(device=dev)
@@ -541,10 +552,7 @@ def run(a, top=True):
     # never reaches HBM.  In its "planes" form the stage writes two fp16 planes of the same size instead (4 S K D bytes
     # either way); in its "project" form (see roofline_pca) it writes the fp16 planes of the token residuals (4 N D) and
     # the block norms (4 S K).
-    pca_form = None
-    if use_pca:
-        pca_form = "project" if (eng_pca_products(K * D, P) == 3 and D % 32 == 0 and P % 4 == 0 and S * K >= 1.25 * N
-                                 and nq_local * N >= 128 * K) else "planes"
+    pca_form = pca_path
     vlad_ms = sum(stages[s]["ms_per_step"] for s in ("incidence", "assign", "prep", "aggregate") if s in stages)
     out_bytes = 4 * N * D + 4 * S * K if pca_form == "project" else 4 * S * K * D
     bytes_img = 4 * D * N + out_bytes + S * N / 8 + S * S + S * Hm * Wm
@@ -633,7 +641,7 @@ def run(a, top=True):
                    "tokens": N, "pca_dim": P if use_pca else None, "order": a.order, "parallelism": f"db-row-shard x{world}" + (" (C-ABI RCCL communicator)" if a.native_comm and world > 1 else ""),
                    "query_own": a.query_own},
         "recall_at_1": recalls[0], "recall_at_5": recalls[4], "db_build_s": t_build,
-        "sibling_group": a.group, "recall_at_1_within_sibling_group": recalls_group[0],
+        "pca_path": pca_path, "sibling_group": a.group, "recall_at_1_within_sibling_group": recalls_group[0],
         "search_stats": sstats, "per_rank_stages_ms": per_rank,
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in stages.items()},
         "roofline": roof, "roofline_vlad": vlad_roof, "roofline_pca": pca_roof, "roofline_knn_stream": stream_roof,

@@ -190,8 +190,9 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
 /* ---- switches (no reference counterpart: the reference has one arithmetic, fp32/fp64 torch + faiss).
  *      Read ONCE: the environment variables SEGVLAD_KNN_FILTER / SEGVLAD_KNN_FP32 / SEGVLAD_PCA_FP32 /
  *      SEGVLAD_F16_CFG / ... give a context its defaults at segvlad_create; this call overrides them.
- *      None of them changes a result: every kNN filter is followed by the exact fp32 refinement and
- *      the PCA variants are both fp32-class (tests assert bit-equality / tolerance between them).
+ *      No kNN switch changes a result (every filter is followed by the exact fp32 refinement: tests assert
+ *      bit-equality); the PCA variants are all fp32-class and agree to ~1e-5 relative (tests hold each to the same
+ *      oracle tolerance), not bit for bit.
  *        "knn_filter"   auto | f16 | bf16x3 | fp32     arithmetic of the candidate filter GEMM
  *        "pca_arith"    auto | f16x3 | fp32            projection GEMM arithmetic
  *        "search_stats" 0 | 1                          record list occupancies (segvlad_search_stats)
@@ -202,7 +203,11 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *                                                      "project" projects every token's residual with its cluster's
  *                                                      slice of the components and aggregates the segments in the
  *                                                      P-dimensional space (same fp32-class result, N*D*P instead of
- *                                                      S*K*D*P flops per image); auto = the smaller product
+ *                                                      S*K*D*P flops per image); auto = the smaller product, decided PER
+ *                                                      CALL from the batch (tokens per cluster, segments): the same
+ *                                                      image can therefore come out ~1e-5 relative apart in two batches
+ *                                                      of different size -- fix the form when runs must be comparable
+ *                                                      digit for digit (bench.py does)
  *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning   */
 int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
 

@@ -288,6 +288,8 @@ int segvlad_set_vocab(segvlad_ctx* ctx, const float* C, int K, int D) {
   ctx->D = D;
   ctx->Kpad = Kpad;
   SV_TRY(sv_launch_vocab_prepare(ctx));
+  // largest centre component: bounds the token residuals x^ - C_k whose fp16 planes the "project" form builds (images_impl)
+  SV_TRY(sv_maxabs(ctx, ctx->vocab.as<float>(), (int64_t)K * D, &ctx->vocab_maxabs));
   return sv_finish(ctx);
 }
 
@@ -434,7 +436,16 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
                         ((double)S_tot * K >= 1.25 * (double)B * N && (double)B * N >= 128.0 * K));
   int64_t rows_pad = 0;   // grouped token rows: every cluster's rows padded to whole 256-row GEMM tiles
   if (fused && project) {
-    xscale = ldexpf(1.f, 13);   // residuals of unit tokens against the centres (means of unit tokens): |r| <= 2
+    // residuals of unit tokens against the centres: |r| <= 1 + max|C|.  Centres that are means of unit tokens (every
+    // k-means vocabulary) give 2^13, like the planes form's data-derived scale; arbitrary centres (segvlad_set_vocab takes
+    // any) get the scale their magnitude needs instead of overflowing fp16 silently
+    {
+      int e;
+      const float bound = 1.f + ctx->vocab_maxabs;
+      if (!std::isfinite(bound)) return ctx->fail(SEGVLAD_ERR_ARG, "images_pca: the vocabulary holds a non-finite centre");
+      frexpf(bound, &e);
+      xscale = ldexpf(1.f, 14 - e);
+    }
     rows_pad = (((int64_t)B * N + 255) & ~255ll) + 256ll * K;
     SV_HIP(ctx->s_xh1.reserve((size_t)(rows_pad + 256) * D * 2));   // + one tile: the dummy row of sv_launch_token_norms
     SV_HIP(ctx->s_xh2.reserve((size_t)(rows_pad + 256) * D * 2));

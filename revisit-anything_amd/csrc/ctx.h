@@ -148,6 +148,7 @@ struct segvlad_ctx {
 
   // vocabulary
   int K = 0, D = 0, Kpad = 0;
+  float vocab_maxabs = 0.f;   // max |C_kd| (set_vocab): scale of the residual planes of the "project" form
   DevBuf vocab;      // [K][D] raw centres
   DevBuf vocab_bt;   // normalised centres in MFMA-B order [D/2][Kpad/32][64]
 

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import os
 import pickle
+import itertools
 import re
 import time
 from typing import List
@@ -62,9 +63,8 @@ def _set_vocab(c_centers):
 # small host helpers with the reference's exact behaviour
 # --------------------------------------------------------------------------------------------------
 def first_k_unique_indices(ranked_indices, K):
-    """func_vpr.py:50-59."""
-    seen = set()
-    return [x for x in ranked_indices if x not in seen and (seen.add(x) or True)][:K]
+    """func_vpr.py:50-59: the first K distinct entries of a ranked list, in order of first appearance."""
+    return list(dict.fromkeys(ranked_indices))[:K]      # a dict keeps insertion order: de-duplication that preserves rank
 
 
 def _natural_key(s):
@@ -80,16 +80,11 @@ def preload_masks(masks_in, image_key):
 
 
 def getIdxSingleFast(img_idx, masks_seg, minArea=400, returnMask=True):
-    """func_vpr.py:762-786.  ``minArea`` is ignored, exactly as in the reference (:779 is commented out)."""
-    imInds, regIndsIm, segmask = [], [], []
-    count = 0
-    for mask in masks_seg:
-        if returnMask:
-            segmask.append(mask)
-        regIndsIm.append(count)
-        imInds.append(img_idx)
-        count += 1
-    return np.array(imInds), regIndsIm, segmask
+    """func_vpr.py:762-786: (image index repeated once per mask, the masks' running numbers, the masks themselves).
+    ``minArea`` is ignored, exactly as in the reference (its area test, :779, is commented out); an image without masks
+    gives ``np.array([])`` -- float64, like the reference's."""
+    segs = list(masks_seg)
+    return np.array([img_idx] * len(segs)), list(range(len(segs))), (segs if returnMask else [])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -258,15 +253,13 @@ def normalizeFeat(rfts):
 # a12  image vote
 # --------------------------------------------------------------------------------------------------
 def weighted_borda_count(*ranked_lists_with_scores):
-    """func_vpr.py:61-77 (host helper kept for API completeness; get_matches runs the device kernel)."""
-    scores = {}
-    for ranked_list in ranked_lists_with_scores:
-        for index, score in ranked_list:
-            if index in scores:
-                scores[index] += score
-            else:
-                scores[index] = score
-    return sorted(scores.keys(), key=lambda index: scores[index], reverse=True)
+    """func_vpr.py:61-77 (host helper kept for API completeness; get_matches runs the device kernel): every index collects
+    the scores it is listed with, in listing order; indices come back by decreasing total, ties in order of first
+    appearance (a stable sort over the insertion-ordered totals)."""
+    totals = {}
+    for index, score in itertools.chain.from_iterable(ranked_lists_with_scores):
+        totals[index] = totals[index] + score if index in totals else score
+    return [index for index, _ in sorted(totals.items(), key=lambda kv: kv[1], reverse=True)]
 
 
 def _offsets_from_ranges(segRangeQuery, n_query):
@@ -311,28 +304,27 @@ def get_matches(matches, gt, sims, segRangeQuery, imIndsRef, n=1, method="max_si
 # a13  recall (host Python, as in the reference)
 # --------------------------------------------------------------------------------------------------
 def calc_recall(pred, gt, n, analysis=False):
-    """func_vpr.py:396-422 (prints the same line)."""
-    recall = [0] * n
-    recall_per_query = [0] * len(gt)
-    num_eval = 0
-    for i in range(len(gt)):
-        if len(gt[i]) == 0:
+    """func_vpr.py:396-422 (prints the same line): recall@1..n over the queries that have ground truth -- a query counts
+    at the rank of its first correct prediction.  With n == 1 the reference tests the WHOLE prediction ``pred[i]`` for
+    membership in ``gt[i]`` (not its first entry); that is kept."""
+    first_hit = np.full(len(gt), -1, dtype=np.int64)        # rank of the first correct prediction, -1 = none
+    evaluated = np.zeros(len(gt), dtype=bool)
+    for i, truth in enumerate(gt):
+        if len(truth) == 0:
             continue
-        num_eval += 1
-        for j in range(len(pred[i])):
-            if n == 1:
-                if pred[i] in gt[i]:
-                    recall[j] += 1
-                    recall_per_query[i] = 1
-                    break
-            else:
-                if pred[i][j] in gt[i]:
-                    recall[j] += 1
-                    break
-    recalls = np.cumsum(recall) / float(num_eval)
-    print("POSITIVES/TOTAL segVLAD for this dataset: ", np.cumsum(recall), "/", num_eval)
+        evaluated[i] = True
+        ranks = range(len(pred[i]))
+        hit = next((j for j in ranks if (pred[i] if n == 1 else pred[i][j]) in truth), None)
+        if hit is not None:
+            first_hit[i] = hit
+    num_eval = int(evaluated.sum())
+    positives = np.cumsum(np.bincount(first_hit[first_hit >= 0], minlength=n)[:n] if n > 0 else np.zeros(0, np.int64))
+    if (first_hit >= n).any():                              # a hit beyond rank n: the reference's recall[j] would raise
+        raise IndexError("list index out of range")
+    recalls = positives / float(num_eval)
+    print("POSITIVES/TOTAL segVLAD for this dataset: ", positives, "/", num_eval)
     if analysis:
-        return recalls.tolist(), recall_per_query
+        return recalls.tolist(), [int(n == 1 and h >= 0) for h in first_hit]
     return recalls.tolist()
 
 

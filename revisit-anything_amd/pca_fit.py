@@ -127,3 +127,186 @@ def fit_pca(X=None, n_components: int = 1024, *, backend=None, n_oversamples: in
     comps *= signs[:, None]
     var = (s ** 2) / (n - 1)
     return mean.astype(np.float32), comps.astype(np.float32), var.astype(np.float32)
+
+
+# ---- the fit, resident on the device (the reference's scale: 50 000 x 49 152 .. 98 304 -> 1024) ------------------------------
+def _chol_qr2_cols(Y, shift_tries: int = 3):
+    """Orthonormalise the COLUMNS of a tall device matrix Y [m, q] (fp32) by CholeskyQR2: G = Y^T Y in fp64 on the device,
+    its q x q Cholesky factor on the host (q ~ 1000: milliseconds), Y <- Y R^-1 on the device; twice (the second pass removes
+    the kappa^2 loss of the first).  Returns fp32 [m, q].  A Gram matrix that is not positive definite in fp64 (numerically
+    rank-deficient block) is regularised by a relative shift and the pass repeated."""
+    import torch
+
+    for _ in range(2):
+        Yd = Y.double()
+        G = (Yd.t() @ Yd).cpu().numpy()
+        scale = float(np.trace(G)) / G.shape[0]
+        R = None
+        for t in range(shift_tries + 1):
+            try:
+                R = np.linalg.cholesky(G + (0.0 if t == 0 else scale * 10.0 ** (-14 + 2 * t)) * np.eye(G.shape[0])).T   # G = R^T R
+                break
+            except np.linalg.LinAlgError:
+                continue
+        if R is None:   # hopeless block: Householder QR on the host (never seen on descriptor data)
+            return torch.as_tensor(np.linalg.qr(Yd.cpu().numpy())[0].astype(np.float32)).to(Y.device)
+        Rinv = np.linalg.solve(R, np.eye(R.shape[0]))
+        Y = (Yd @ torch.as_tensor(Rinv).to(Y.device)).float()
+        del Yd
+    return Y
+
+
+def fit_pca_device(engine, X, n_components: int = 1024, *, n_oversamples: int = 32, n_iter: int = 8, seed: int = 0,
+                   timings: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """``fit_pca`` with everything but two q x q factorisations on the device: X [n, KD] fp32 stays in HBM (50 000 x 98 304 =
+    19.7 GB, + its transpose), the two tall products of every half step run on the C-ABI's projection GEMM
+    (segvlad_pca_apply: three fp16 MFMA products of a two-term split, fp32-class) in TWO contexts -- one keeps ``X^T`` as
+    its "components" for the whole fit, the other receives the current basis -- and the re-orthonormalisation is
+    CholeskyQR2 (Gram matrices in fp64 on the device, q x q Cholesky on the host).  The Rayleigh-Ritz step diagonalises the
+    q x q Gram matrix of X_c V instead of taking an SVD of the [n, q] block.  Same conventions / return value as fit_pca.
+    (Host QR of the [98 304, 1056] and [50 000, 1056] blocks was > 90 % of the round-2 fit.)"""
+    import time
+
+    import torch
+
+    from .engine import SegVLADEngine
+
+    t_start = time.perf_counter()
+    dev = engine.device
+    X = X if isinstance(X, torch.Tensor) else torch.as_tensor(np.asarray(X, dtype=np.float32))
+    X = X.to(dev, dtype=torch.float32).contiguous()
+    n, kd = int(X.shape[0]), int(X.shape[1])
+    p = int(n_components)
+    if not 0 < p <= min(n - 1, kd):
+        raise ValueError(f"n_components={p} must be in 1..min(n-1, KD) = {min(n - 1, kd)}")
+    q = min(p + int(n_oversamples), min(n, kd))
+    q = (q + 3) & ~3 if ((q + 3) & ~3) <= min(n, kd) else q
+    mean64 = X.mean(dim=0, dtype=torch.float64)                                     # [KD]
+    # the transposed product's inner dimension is n: padded with zero columns to a multiple of 32 so that it stays on the
+    # split fp16 GEMM (api.hip: KD % 32), which changes no sum
+    n_pad = (n + 31) // 32 * 32
+    Xt = torch.zeros((kd, n_pad), dtype=torch.float32, device=dev)
+    Xt[:, :n] = X.t()
+    eng_t = SegVLADEngine(dev)                                                      # comps = X^T, set once
+    eng_t.pca_set(None, Xt, None, whiten=False)
+    del Xt
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    Vt = _chol_qr2_cols(torch.randn(kd, q, device=dev, generator=g)).t().contiguous()          # [q, KD], orthonormal rows
+
+    def xc_v(Vt_):       # X_c V = X V - 1 (mean^T V): [n, q]
+        engine.pca_set(None, Vt_, None, whiten=False)
+        Y = engine.pca_apply(X, l2norm=False)
+        return Y - (Vt_.double() @ mean64).float()[None, :]
+
+    def xct_u_t(U):      # (X_c^T U)^T = U^T X - (U^T 1) mean^T: [q, KD]
+        Ut = torch.zeros((q, n_pad), dtype=torch.float32, device=dev)
+        Ut[:, :n] = U.t()
+        Z = eng_t.pca_apply(Ut, l2norm=False)
+        return Z - torch.outer(U.double().sum(dim=0), mean64).float()
+
+    t_setup = time.perf_counter()
+    for _ in range(max(int(n_iter), 1)):
+        U = _chol_qr2_cols(xc_v(Vt))                                               # [n, q]
+        Vt = _chol_qr2_cols(xct_u_t(U).t().contiguous()).t().contiguous()          # [q, KD]
+    t_iter = time.perf_counter()
+    B = xc_v(Vt)                                                                   # [n, q] = X_c V
+    Bd = B.double()
+    M = (Bd.t() @ Bd).cpu().numpy()                                                # q x q, = W diag(s^2) W^T
+    w, Wm = np.linalg.eigh(M)
+    order = np.argsort(w)[::-1][:p]
+    s2 = np.maximum(w[order], 0.0)
+    Wp = torch.as_tensor(np.ascontiguousarray(Wm[:, order])).to(dev)               # [q, p]
+    comps = (Wp.t() @ Vt.double())                                                 # [p, KD] = (V W)^T, orthonormal rows
+    # sklearn's svd_flip (u-based): u_j = B w_j / s_j; the entry of largest magnitude of every u_j is made positive
+    Uj = Bd @ Wp                                                                   # [n, p] (= u_j s_j: the sign is that of u_j)
+    rows = Uj.abs().argmax(dim=0)
+    signs = torch.sign(Uj[rows, torch.arange(p, device=dev)])
+    signs[signs == 0] = 1.0
+    comps = (comps * signs[:, None]).float().cpu().numpy()
+    var = (s2 / (n - 1)).astype(np.float32)
+    eng_t.close()
+    if timings is not None:
+        torch.cuda.synchronize()
+        t_end = time.perf_counter()
+        timings.update(setup_s=t_setup - t_start, iterations_s=t_iter - t_setup, rayleigh_ritz_s=t_end - t_iter,
+                       total_s=t_end - t_start, n=n, kd=kd, p=p, q=q, n_iter=int(n_iter))
+    return mean64.float().cpu().numpy(), comps, var
+
+
+def to_sklearn_pca(mean, components, explained_variance, n_samples: int, whiten: bool = True):
+    """A ``sklearn.decomposition.PCA`` carrying the fitted model -- what the reference pickles (place_rec_pca.py:403-411) and
+    what its ``apply_pca_transform_from_pkl`` (func_vpr.py:1419-1443) unpickles and calls ``.transform`` on."""
+    from sklearn.decomposition import PCA
+
+    comps = np.asarray(components, dtype=np.float32)
+    var = np.asarray(explained_variance, dtype=np.float32)
+    m = PCA(n_components=int(comps.shape[0]), whiten=bool(whiten), svd_solver="arpack")
+    m.mean_ = np.asarray(mean, dtype=np.float32)
+    m.components_ = comps
+    m.explained_variance_ = var
+    m.singular_values_ = np.sqrt(var.astype(np.float64) * max(int(n_samples) - 1, 1)).astype(np.float32)
+    m.explained_variance_ratio_ = var / max(float(var.sum()), 1e-30)    # (relative to the RETAINED variance: the total is not formed)
+    m.n_components_ = int(comps.shape[0])
+    m.n_features_in_ = int(comps.shape[1])
+    m.n_samples_ = int(n_samples)
+    m.noise_variance_ = 0.0
+    return m
+
+
+def fit_from_store(dino_in, masks_in, image_keys, pipeline, out_pkl: Optional[str] = None, n_components: int = 1024,
+                   max_segments: int = 50000, num_segments_total: Optional[int] = None, batch_size: int = 100,
+                   n_iter: int = 8, seed: int = 0, rng: Optional[np.random.Generator] = None, timings: Optional[dict] = None):
+    """The reference's PCA-fitting run (place_rec_pca.py:320-411) as one call: count the reference split's segments, walk its
+    images, describe each batch WITHOUT PCA on the device (raw K*D segment descriptors), keep ``int(S_img * ratio)`` randomly
+    chosen rows of every image (ratio = min(1, max_segments / total); stop at ``max_segments``), fit on the device, and --
+    with ``out_pkl`` -- pickle a ``sklearn.decomposition.PCA`` that ``apply_pca_transform_from_pkl`` (here or in the
+    reference) loads.  ``pipeline``: a SegVLADPipeline with use_pca=False whose engine holds the vocabulary.
+    Returns (mean, components, explained_variance)."""
+    import pickle
+
+    import torch
+
+    from .driver import load_image_inputs
+    from .func_vpr import getIdxSingleFast
+
+    if getattr(pipeline, "use_pca", False):
+        raise ValueError("fit_from_store needs a pipeline with use_pca=False (the fit sees the raw K*D descriptors)")
+    rng = rng or np.random.default_rng()
+    dev = pipeline.eng.device
+    if num_segments_total is None:   # countNumMasksInDataset (func_vpr.py)
+        num_segments_total = sum(len(getIdxSingleFast(i, list(load_image_inputs(dino_in, masks_in, k)[1]))[2])
+                                 for i, k in enumerate(image_keys))
+    ratio = min(1.0, max_segments / max(int(num_segments_total), 1))
+    kept, acc = [], 0
+    for b0 in range(0, len(image_keys), batch_size):
+        keys = image_keys[b0:b0 + batch_size]
+        toks, msks, offs = [], [], [0]
+        for key in keys:
+            t, m = load_image_inputs(dino_in, masks_in, key)
+            toks.append(t)
+            msks.append(m)
+            offs.append(offs[-1] + m.shape[0])
+        masks = np.concatenate([m for m in msks if m.shape[0]]) if any(m.shape[0] for m in msks) else np.zeros((0, 1, 1), np.uint8)
+        gd = pipeline.describe(torch.from_numpy(np.stack(toks)).to(dev), torch.from_numpy(masks).to(dev),
+                               np.asarray(offs, dtype=np.int32), l2norm=False)                    # [S_batch, K*D] on the device
+        for j in range(len(keys)):                                                                  # per image, as :385-398
+            s_img = offs[j + 1] - offs[j]
+            k = int(s_img * ratio)
+            if k > 0:
+                pick = torch.as_tensor(rng.permutation(s_img)[:k] + offs[j], device=dev)
+                kept.append(gd[pick])
+                acc += k
+            if acc >= max_segments:
+                break
+        if acc >= max_segments:
+            break
+    if not kept:
+        raise ValueError("no segments sampled")
+    X = torch.cat(kept)
+    del kept
+    mean, comps, var = fit_pca_device(pipeline.eng, X, n_components=n_components, n_iter=n_iter, seed=seed, timings=timings)
+    if out_pkl:
+        with open(out_pkl, "wb") as f:
+            pickle.dump(to_sklearn_pca(mean, comps, var, n_samples=int(X.shape[0]), whiten=True), f)
+    return mean, comps, var

@@ -74,6 +74,59 @@ def test_pca_fit_device_backend_matches_sklearn_exact_solver(eng):
     assert np.abs(np.abs(yd) - np.abs(y_ref)).max() < 2e-3 * np.abs(y_ref).max()
 
 
+def test_pca_fit_on_the_device_at_a_reduced_real_shape_and_the_pickle_flow(eng, tmp_path):
+    """fit_pca_device (CholeskyQR2 + Gram Rayleigh-Ritz on the device, no host QR) at descriptor width: n = 1024 rows of
+    K*D = 49 152 columns -> 64 components, against sklearn's exact solver (the full 50 000 x 49 152 / 98 304 -> 1024 fit is
+    timed by tools/probe_pca_fit.py: profiles/r03_pca_fit.json); then the place_rec_pca.py flow: the pickle
+    written by to_sklearn_pca is a real sklearn PCA whose transform equals the engine's projection of the same model, and
+    apply_pca_transform_from_pkl loads it."""
+    import pickle
+
+    import torch
+    from sklearn.decomposition import PCA
+
+    from revisit_anything_amd import func_vpr, pca_fit
+
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    n, kd, p, r = 1024, 49152, 64, 96        # (sklearn's exact SVD of this block is ~15 s of host time; the device fit < 1 s)
+    spec = torch.logspace(0, -1.5, r, device=dev)
+    X = (torch.randn(n, r, device=dev, generator=g) * spec) @ (torch.randn(r, kd, device=dev, generator=g) / kd ** 0.5)
+    X = X + 0.003 * torch.randn(n, kd, device=dev, generator=g) + 0.02 * torch.randn(kd, device=dev, generator=g) / kd ** 0.5
+    tm = {}
+    mean, comps, var = pca_fit.fit_pca_device(eng, X, n_components=p, n_iter=6, seed=3, timings=tm)
+    Xh = X.cpu().numpy()
+    ref = PCA(n_components=p, whiten=True, svd_solver="full").fit(Xh.astype(np.float64))
+    assert np.abs(mean - ref.mean_).max() < 1e-6
+    assert np.allclose(var, ref.explained_variance_, rtol=5e-4)
+    sv = np.linalg.svd(comps.astype(np.float64) @ ref.components_.T, compute_uv=False)
+    assert (1 - sv).max() < 1e-5                                                  # the same 128-dimensional subspace
+    assert np.abs(np.abs((comps.astype(np.float64) * ref.components_).sum(1)) - 1).max() < 1e-3   # and the same vectors
+    assert tm["q"] % 4 == 0 and tm["total_s"] < 60
+    # n not a multiple of 32 (the transposed product pads its inner dimension): checked against the exact spectrum / row
+    # space from the n x n Gram matrix of the centred rows (fp64 on the host)
+    n2 = 999
+    mean2, comps2, var2 = pca_fit.fit_pca_device(eng, X[:n2], n_components=16, n_iter=6, seed=3)
+    Xc = Xh[:n2].astype(np.float64) - Xh[:n2].astype(np.float64).mean(0)
+    w, Uu = np.linalg.eigh(Xc @ Xc.T)
+    w, Uu = w[::-1][:16], Uu[:, ::-1][:, :16]
+    assert np.allclose(var2, w / (n2 - 1), rtol=5e-4)
+    exact_rows = (Xc.T @ Uu / np.sqrt(w)).T                                          # right singular vectors
+    assert (1 - np.linalg.svd(comps2.astype(np.float64) @ exact_rows.T, compute_uv=False)).max() < 1e-5
+    # the pickle of the reference's flow
+    path = str(tmp_path / "pca_model.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(pca_fit.to_sklearn_pca(mean, comps, var, n_samples=n, whiten=True), f)
+    with open(path, "rb") as f:
+        model = pickle.load(f)
+    y_sk = model.transform(Xh[:40].astype(np.float64))                            # what the reference's loader computes
+    y_ref = ref.transform(Xh[:40].astype(np.float64))
+    assert np.abs(np.abs(y_sk) - np.abs(y_ref)).max() < 5e-3 * np.abs(y_ref).max()
+    y_dev = func_vpr.apply_pca_transform_from_pkl(torch.from_numpy(Xh[:40]), path).numpy()
+    assert np.abs(y_dev - y_sk).max() < 2e-3 * np.abs(y_sk).max()
+
+
 # ------------------------------------------------------------------------------------------------
 # f4: vocabulary k-means (utilities.py:766-787) -- Lloyd half-step from the segment-VLAD kernels
 # ------------------------------------------------------------------------------------------------
