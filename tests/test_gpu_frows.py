@@ -157,6 +157,58 @@ def test_vocabulary_device_half_step_equals_numpy(eng):
 # ------------------------------------------------------------------------------------------------
 # f1: the experiment loop over stored inputs (place_rec_main.py:244-373)
 # ------------------------------------------------------------------------------------------------
+def test_fit_from_store_is_the_reference_pca_run_in_one_call(eng, tmp_path):
+    """place_rec_pca.py:320-411 as one call: walk a reference split in the on-disk layout, describe without PCA, keep
+    int(S_img * ratio) random rows per image up to max_segments, fit on the device, pickle a sklearn PCA -- which
+    recall_segloc's loader (apply_pca_transform_from_pkl) then applies.  Checked against an fp64 fit of exactly the
+    sampled rows (the sampling is seeded here; the reference's is not)."""
+    import pickle
+
+    import torch
+
+    from revisit_anything_amd import func_vpr, pca_fit, store as st
+    from revisit_anything_amd.pipeline import SegVLADPipeline
+
+    K, D, H, W = 8, 64, 112, 140
+    N = (H // 14) * (W // 14)
+    C = synth().make_vocab(K, D, seed=41)
+    droot, mroot = str(tmp_path / "dino"), str(tmp_path / "masks")
+    keys, n_seg = [], 0
+    for i in range(30):
+        key = f"img_{i}.jpg"
+        S = 5 + i % 4
+        st.write_dino(droot, key, synth().make_tokens(C, N, seed=7000 + i, noise=0.3).reshape(1, D, H // 14, W // 14))
+        st.write_masks(mroot, key, synth().make_masks(S, H // 2, W // 2, seed=8000 + i, hmin=6, hmax=30, wmin=6, wmax=40)[:S])
+        keys.append(key)
+        n_seg += S
+    eng.set_vocab(C)
+    pipe = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=False)
+    path = str(tmp_path / "pca.pkl")
+    max_seg = 120                                                # < 192 segments in the split: ratio 0.62, stops early
+    mean, comps, var = pca_fit.fit_from_store(st.FeatureStore(droot, "dino"), st.FeatureStore(mroot, "masks"), keys, pipe, out_pkl=path,
+                                              n_components=12, max_segments=max_seg, batch_size=7, n_iter=6, seed=2,
+                                              rng=np.random.default_rng(5))
+    # the same sampling rule on the host (sample_segments) over the same descriptors and the same random stream
+    blocks = []
+    for i, key in enumerate(keys):
+        t = np.asarray(st.FeatureStore(droot, "dino")[key]["ift_dino"][()]).reshape(D, N)
+        m = np.stack(func_vpr.preload_masks(st.FeatureStore(mroot, "masks"), key)).astype(np.uint8)
+        blocks.append(pipe.describe(torch.from_numpy(t[None]).to(eng.device), torch.from_numpy(m).to(eng.device),
+                                    np.array([0, len(m)], np.int32), l2norm=False).cpu().numpy())
+    Xs = pca_fit.sample_segments(blocks, n_seg, max_segments=max_seg, rng=np.random.default_rng(5))
+    ratio = max_seg / n_seg
+    assert Xs.shape[0] == sum(int((5 + i % 4) * ratio) for i in range(30)) < max_seg     # int() truncates per image (:384)
+    mean_h, comps_h, var_h = pca_fit.fit_pca(Xs, n_components=12, n_iter=6, seed=2)
+    assert np.abs(mean - mean_h).max() < 1e-6 and np.allclose(var, var_h, rtol=1e-3)
+    assert (1 - np.linalg.svd(comps.astype(np.float64) @ comps_h.astype(np.float64).T, compute_uv=False)).max() < 1e-5
+    model = pickle.load(open(path, "rb"))
+    assert type(model).__name__ == "PCA" and model.whiten and model.n_components_ == 12 and model.n_features_in_ == K * D
+    y_dev = func_vpr.apply_pca_transform_from_pkl(torch.from_numpy(Xs[:20]), path).numpy()
+    assert np.abs(y_dev - model.transform(Xs[:20].astype(np.float64))).max() < 2e-3 * np.abs(y_dev).max()
+    with pytest.raises(ValueError):
+        pca_fit.fit_from_store(None, None, [], SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True))
+
+
 def test_driver_run_segloc_over_a_feature_store_equals_oracle(eng, tmp_path):
     from revisit_anything_amd import driver, store as st
     from revisit_anything_amd.pipeline import SegVLADPipeline
