@@ -421,3 +421,20 @@ def get_recall_anyloc(db, q, gt, k=5):
                 recall[j] += 1
                 break
     return np.cumsum(recall) / float(n_eval) * 100, ids
+
+
+# --------------------------------------------------------------------------------------------------
+# f4: vocabulary k-means (vlad_c_centers_pt_gen.py:86-158 -> utilities.py:749-791 VLAD.fit ->
+# fast_pytorch_kmeans.KMeans(mode='cosine')).  fast-pytorch-kmeans 0.2.0.1 is a third-party dependency with no source in
+# the reference tree: its published Lloyd iteration is restated here -- PARITY UNPINNED for this function; the cosine
+# assignment it uses is the pinned ``assign_labels`` above.
+# --------------------------------------------------------------------------------------------------
+def kmeans_cosine_step(X_unit: np.ndarray, C: np.ndarray):
+    """One Lloyd half-step on unit rows ``X_unit [n, D]`` with centres ``C [K, D]``: cosine arg-max labels (first maximum),
+    per-cluster sums of the assigned rows (fp64) and counts.  Returns (labels, gap, sums, counts)."""
+    X32 = np.ascontiguousarray(X_unit, dtype=np.float32)
+    labels, gap = assign_labels(X32, np.asarray(C, dtype=np.float32))
+    K = C.shape[0]
+    sums = np.zeros((K, X32.shape[1]), dtype=np.float64)
+    np.add.at(sums, labels, X32.astype(np.float64))
+    return labels, gap, sums, np.bincount(labels, minlength=K)

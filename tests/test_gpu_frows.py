@@ -154,6 +154,37 @@ def test_vocabulary_device_half_step_equals_numpy(eng):
     assert np.all(np.linalg.norm(cen_d, axis=1) < 1.0)
 
 
+def test_vocabulary_half_step_at_the_reference_shape_against_the_oracle(eng):
+    """K = 32 clusters of D = 1536 (the shipped vocabularies' shape: cache/vocabulary/dinov2_vitg14/l31_value_c32) over
+    48 images x 1530 tokens = 73 440 unit rows: the device half-step (segment-VLAD kernels, one all-token pseudo-segment
+    per image) against the ORACLE's pinned cosine assignment + fp64 sums -- labels identical wherever the oracle's top-2
+    gap exceeds 1e-6, counts consistent, per-cluster sums within 1e-6 per accumulated token."""
+    from revisit_anything_amd import vocabulary as vq
+
+    K, D, B, N = 32, 1536, 48, 1530
+    C0 = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocab_indoor_k32_d1536.npy"))   # a shipped vocabulary
+    toks = np.stack([synth().make_tokens(C0, N, seed=3300 + b, noise=0.08) for b in range(B)])     # [B, D, N]
+    X = np.concatenate([t.T for t in toks])
+    db = vq.DeviceBackend(eng, toks, batch=16)
+    rng = np.random.Generator(np.random.PCG64(8))
+    C = db.init_points(rng.choice(B * N, size=K, replace=False))                                     # random initial points
+    for _ in range(2):
+        ld, sd, cd = db.step(C)
+        lo, gap, so, co = O().kmeans_cosine_step(X, C.astype(np.float32))
+        clear = gap > 1e-6
+        assert clear.mean() > 0.999 and np.array_equal(ld[clear], lo[clear])
+        assert cd.sum() == B * N and np.abs(cd - co).sum() <= 2 * int((~clear).sum())
+        same = ld == lo
+        if not same.all():                       # move the few near-tie rows to the device's side before comparing sums
+            so = so.copy()
+            for t in np.nonzero(~same)[0]:
+                so[lo[t]] -= X[t].astype(np.float64)
+                so[ld[t]] += X[t].astype(np.float64)
+        assert np.abs(sd - so).max() < 1e-6 * max(1.0, float(cd.max()))
+        C = np.where(cd[:, None] > 0, sd / np.maximum(cd, 1)[:, None], C)
+    assert np.all(np.linalg.norm(C, axis=1) < 1.0 + 1e-6)
+
+
 # ------------------------------------------------------------------------------------------------
 # f1: the experiment loop over stored inputs (place_rec_main.py:244-373)
 # ------------------------------------------------------------------------------------------------
