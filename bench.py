@@ -295,7 +295,9 @@ def run(a, top=True):
     # --pipeline: the describe stage gets its own context (vocabulary + PCA model) and its own stream, so that batch
     # i+1 is described (HBM side) under the search of batch i (matrix pipe side); `eng` keeps the index
     eng_d, pipe_d, s_desc = eng, pipe, None
-    if a.pipeline:
+    # (also created for the "pipelined" sub-measurement of the default N=1 line, which times both modes on one index)
+    also_pipelined = top and world == 1 and not a.pipeline and not a.no_sub_records and not a.sweep_own
+    if a.pipeline or also_pipelined:
         eng_d = SegVLADEngine(local)
         if pca_path:
             eng_d.set_option("pca_path", pca_path)
@@ -415,7 +417,7 @@ def run(a, top=True):
     if a.pipeline and a.warmup:
         out = steps_pipelined(min(2, a.warmup))
     FILTER_KIND = eng.search_stats()["filter"]
-    for e_ in {eng, eng_d}:
+    for e_ in ({eng, eng_d} if a.pipeline else {eng}):
         e_.set_profiling(True)
         e_.profile_reset()
     # HIP events on the stream the steps are issued on (hipEvent-timed steps, median), beside the wall clock
@@ -434,6 +436,19 @@ def run(a, top=True):
     for e_ in {eng, eng_d}:
         e_.set_profiling(False)
     step_ms_events = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    pipelined = None
+    if also_pipelined:   # the same K steps with describe(i+1) issued under search(i): same index, same inputs, same fences
+        out_p = steps_pipelined(2)
+        fence()
+        tp0 = time.perf_counter()
+        out_p = steps_pipelined(a.steps)
+        fence()
+        dtp = time.perf_counter() - tp0
+        pipelined = {"value": nQ * a.steps / dtp, "ms_per_step": dtp / a.steps * 1e3, "vs_serial": dt / dtp,
+                     "predictions_identical": bool(torch.equal(out_p[0], out[0])),
+                     "note": "describe of batch i+1 on its own context + stream under the search of batch i (bench.py --pipeline "
+                             "makes this the timed mode); the search's persistent filter kernel leaves the describe kernels few "
+                             "CUs, and both draw on the same power budget"}
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -465,7 +480,7 @@ def run(a, top=True):
     stages = {}
     for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "knn_redo",
               "knn_fallback", "vote"):
-        for e_ in {eng, eng_d}:
+        for e_ in ({eng, eng_d} if a.pipeline else {eng}):
             try:
                 ms, n = e_.stage_ms(s)
                 stages[s] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps}
@@ -629,6 +644,7 @@ def run(a, top=True):
         "timing_note": "value / ms_per_step: wall clock over the K steps between two barrier + synchronize fences (the contract); "
                        "the hip_event figures are per-step HIP events on the issuing stream (SURVEY 8d)",
         "mode": "pipelined (describe i+1 on its own context/stream under search i)" if a.pipeline else "serial",
+        "pipelined": pipelined,
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "filter_dtype": FILTER_KIND, "pca_gemm_dtype": "f16x3" if eng_pca_products(K * D, P) == 3 else "f32",
         "dtype_note": "every reported distance / similarity / descriptor is fp32-class: the fp16 MFMA product of the kNN stage only "
@@ -787,7 +803,9 @@ def cpu_baseline(a, db_rows, fac, tau, C_np, use_pca, P, N, S, K, D, H, W, pipe,
     qq, rr = np.nonzero(m_dev != oidx[:, :50])
     near_tie = True
     if len(qq):   # an id mismatch is legitimate only as a near-tie: the device's row is as close as the oracle's
-        near_tie = bool(np.abs(dmat[qq, m_dev[qq, rr]] - od2[qq, rr]).max() < 1e-5)
+        # (fp32 fma chain over d terms against fp64: ~sqrt(d) ulps of a unit dot product -- 1e-5 at d = 1024; raw 98 304-d
+        #  rows get north_star's 1e-4)
+        near_tie = bool(np.abs(dmat[qq, m_dev[qq, rr]] - od2[qq, rr]).max() < (1e-5 if d <= 4096 else 1e-4))
     gt = [[int(t)] for t in tau[:n_v]]
     from revisit_anything_amd.pipeline import recall_at
 

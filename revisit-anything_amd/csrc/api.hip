@@ -914,7 +914,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
       sc.count();
     }
     StageScope sc(ctx, "knn_select");
-    if (n0 <= 1024 && pl.kind != 3) {
+    if (n0 <= 4096 && pl.kind != 3) {
       // a short sample row: only its r0-th smallest distance is needed -- the wave-per-query register select of the
       // candidate lists (mode 0: thr[q] = rank-th smallest), the distance block standing in for a list of n0 entries
       SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_dist.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
@@ -925,7 +925,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     }
     sc.count();
   }
-  const bool l0_small = n0 <= 1024 && pl.kind != 3;
+  const bool l0_small = n0 <= 4096 && pl.kind != 3;
   const float* thr_ptr = l0_small ? thr : thr + (r0 - 1);
   int64_t thr_ld = l0_small ? 1 : r0;
   // rigorous: level-0 thresholds are exact distances, one margin covers the filter's error.  heuristic: the final
@@ -1138,8 +1138,11 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // shard: 256, 16, 1 instead of 16, 1 (1.35 -> 0.1 ms).  The rigorous redo keeps the plan above.
   const bool heuristic = pl.kind != 3 && ctx->opt.knn_heuristic && !ctx->db_heur_off && heur_rank(k) < k;
   SearchPlan plh = pl;
+  // (a single query image -- <= 128 rows -- keeps a sample of >= 2048 rows: the exact level of 50 x 3906 x 1024 is free,
+  //  and every level less is a filter launch + a select launch = ~40 us of a ~500 us pass)
+  const int64_t min_sample = nq <= 128 ? 2048 : 192;
   if (heuristic)
-    while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
+    while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= min_sample) {
       plh.stride0 *= SV_RATIO;
       ++plh.levels;
     }

@@ -37,6 +37,17 @@ def test_bench_step_predictions_equal_oracle_on_20_images():
     assert j["filter_dtype"] == "f16" and j["dtype"] == "f32"
     assert j["search_stats"]["n_fallback"] == 0 and j["search_stats"]["levels"] == 3
     assert j["roofline"]["bound"] == "mfma" and j["cpu_baseline"]["kind"] == "port"
+    # the sub-records of the N=1 line: both timing modes give the same predictions; BASELINE
+    # configs[1] in its literal raw-descriptor form and the 31-near-duplicates database run the fp16 filter with nobody on
+    # the distance-matrix path
+    assert j["mode"] == "serial" and j["pipelined"]["predictions_identical"] is True
+    c2, rd = j["config2"], j["redundant_db"]
+    assert "error" not in c2 and "error" not in rd, (c2, rd)
+    assert c2["search_stats"]["filter"] == "f16" and c2["search_stats"]["n_fallback"] == 0 and "raw K*D" in c2["workload"]
+    assert c2["search_stats"]["refine_sum"] / c2["search_stats"]["n_queries"] < 400
+    assert rd["sibling_group"] == 31 and rd["search_stats"]["n_fallback"] == 0 and rd["search_stats"]["n_redo"] <= 100
+    assert rd["recall_at_1_within_sibling_group"] >= 0.95
+    assert j["roofline"].get("ubench", {}).get("mfma_only_random_tflops", 0) > 500
 
 
 def test_bench_two_ranks_one_gpu_equal_single_rank(tmp_path):
@@ -52,3 +63,17 @@ def test_bench_two_ranks_one_gpu_equal_single_rank(tmp_path):
     assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
     assert np.array_equal(np.load(p1), np.load(p2))
     assert j1["recall_at_1"] == j2["recall_at_1"]
+
+
+def test_bench_config2_raw_descriptors_end_to_end_equals_oracle():
+    """BASELINE configs[1] literally (place_rec_main.py:49-60 with pca off): 1000 reference images x 50 segments of raw
+    K*D = 98 304-d descriptors, 200 query images, search 200 / vote 50 -- one image's 50 query segments re-computed by the
+    fp64 oracle against all 50 000 rows: identical top-1 image, sims within 1e-4, every id mismatch a near-tie."""
+    j = _run([sys.executable, "bench.py", "--no-pca", "--db-images", "1000", "--steps", "1", "--warmup", "1", "--verify-images", "1",
+              "--no-sub-records", "--no-ubench", "--search-stats"], 1500)
+    oc = j["oracle_check"]
+    assert oc["images"] == 1 and oc["top1_identical"] == 1 and oc["ok"], oc
+    assert oc["sims_max_abs_diff"] < 1e-4 and oc["neighbour_id_mismatches_are_near_ties"], oc
+    st = j["search_stats"]
+    assert j["filter_dtype"] == "f16" and st["n_fallback"] == 0 and st["levels"] >= 1, st
+    assert j["config"]["pca_dim"] is None and j["config"]["db_segments"] == 50000
