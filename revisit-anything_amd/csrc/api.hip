@@ -116,7 +116,7 @@ hipError_t sv_max_dyn_lds(const void* fn, size_t bytes) {
 
 extern "C" {
 
-int segvlad_version(void) { return 200; }
+int segvlad_version(void) { return 300; }
 
 int segvlad_create(segvlad_ctx** out, int device_id) {
   if (!out) return SEGVLAD_ERR_ARG;
@@ -1138,11 +1138,10 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // shard: 256, 16, 1 instead of 16, 1 (1.35 -> 0.1 ms).  The rigorous redo keeps the plan above.
   const bool heuristic = pl.kind != 3 && ctx->opt.knn_heuristic && !ctx->db_heur_off && heur_rank(k) < k;
   SearchPlan plh = pl;
-  // (a single query image -- <= 128 rows -- keeps a sample of >= 2048 rows: the exact level of 50 x 3906 x 1024 is free,
-  //  and every level less is a filter launch + a select launch = ~40 us of a ~500 us pass)
-  const int64_t min_sample = nq <= 128 ? 2048 : 192;
+  // (tried for single query images: stopping at a >= 2048-row sample -- one filter level less -- moves the time into the
+  //  64-keys-per-lane select of the 3906-entry sample row: 554 vs 553 us per pass, not kept)
   if (heuristic)
-    while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= min_sample) {
+    while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
       plh.stride0 *= SV_RATIO;
       ++plh.levels;
     }

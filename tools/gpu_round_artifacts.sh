@@ -56,5 +56,12 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python $REPO/bench.py --no-cpu-baseline \
      > $OUT/${TAG}_bench_n1_under_rocprof.json 2> /tmp/prof_kt.err
   f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_n1_kernel_stats.csv
+  # the single-image streaming pass (roofline_knn_stream): per-kernel durations of 50 passes
+  rm -rf /tmp/prof_st
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_st -- python $REPO/tools/probe_stream.py 50 \
+     > $OUT/${TAG}_stream_pass.txt 2> /tmp/prof_st.err
+  f=$(find /tmp/prof_st -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_stream_pass_kernel_stats.csv
   cd $REPO
+  # micro-benchmarks behind the ceilings quoted in DESIGN.md (MFMA rate under the power cap; gather bandwidth vs bytes in flight)
+  { timeout 120 ./tools/ubench/mfma_peak 20000; timeout 120 ./tools/ubench/gather_bw; } > $OUT/${TAG}_ubench.txt 2>&1
 fi
