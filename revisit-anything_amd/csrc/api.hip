@@ -184,6 +184,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "knn_heuristic")) return as_int(&o.knn_heuristic);
   if (!strcmp(key, "assign_narrow")) return as_int(&o.assign_narrow);
   if (!strcmp(key, "agg_kpb")) return as_int(&o.agg_kpb);
+  if (!strcmp(key, "pj_nw")) return as_int(&o.pj_nw);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
   return ctx->fail(SEGVLAD_ERR_ARG, "set_option: unknown key '%s'", key);
 }

@@ -99,6 +99,8 @@ struct SvOptions {
   int agg_kpb = 4;        // clusters per aggregation workgroup
   int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises); 7: token_norms_kernel waits for every
                           //    outstanding memory operation at every step (verification of its counted waits: same bits)
+  int pj_nw = 8;          // waves (32-column slices) per workgroup of the P-space aggregation: 8, or 4 (three workgroups per
+                          // CU instead of one: measured SLOWER, 3.72 vs 3.40 ms for the PCA stage of 200 images)
   int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
 };
 

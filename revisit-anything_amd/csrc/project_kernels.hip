@@ -112,7 +112,10 @@ int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* 
 // where its column-mask bit is set, else 0, B = z.  The mean term W mu and the whitening scale are applied in the epilogue.
 constexpr int PJ_T = 32;   // rows per tile (an image has at most K + N / 32 tiles: `maxt`)
 
-__global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __restrict__ Z, const float* __restrict__ wmu,
+template <int NW>   // waves per workgroup = 32-column slices: 8 (256 columns, 82 KiB of LDS: one workgroup per CU; default) or
+                    // 4 (128 columns, 49 KiB: three per CU; option pj_nw = 4 -- measured slower: every workgroup repeats the
+                    // per-tile mask loads, barriers and the weight table)
+__global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float* __restrict__ Z, const float* __restrict__ wmu,
                                                                 const float* __restrict__ bn, const float* __restrict__ gscale,
                                                                 const uint64_t* __restrict__ colmask,
                                                                 const int32_t* __restrict__ lab_off,
@@ -123,31 +126,50 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int KS = K + 1 + (K & 1);                                  // row stride of ag, always odd: conflict-free column reads
   float* ag = reinterpret_cast<float*>(smem);                      // [64][KS]  a_sk = g_s / ||V_sk||   (0 for empty blocks)
-  float* zt = ag + 64 * KS;                                        // [2][PJ_T][256] staged rows
-  uint64_t* mk = reinterpret_cast<uint64_t*>(zt + 2 * PJ_T * 256); // [2][PJ_T] column masks of the staged tokens
+  constexpr int NC = 32 * NW, NT_ = 64 * NW, C4W = NC / 4;         // columns, threads, float4 per staged row
+  float* zt = ag + 64 * KS;                                        // [2][PJ_T][NC] staged rows
+  uint64_t* mk = reinterpret_cast<uint64_t*>(zt + 2 * PJ_T * NC);  // [2][PJ_T] column masks of the staged tokens
   int32_t* tl_k = reinterpret_cast<int32_t*>(mk + 2 * PJ_T);       // [maxt] cluster of tile t
   int32_t* tl_j = tl_k + maxt;                                     // [maxt] first token (label-grouped order) of tile t
   int32_t* tl_z = tl_j + maxt;                                     // [maxt] first row of Z of tile t
   int32_t* tl_n = tl_z + maxt;                                     // [maxt] rows in tile t
   __shared__ int s_tiles;
-  const int b = blockIdx.y, p0 = blockIdx.x * 256;
+  const int b = blockIdx.y, p0 = blockIdx.x * NC;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
   const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
   const int SCb = (S + 63) >> 6;
   const int32_t* lo = lab_off + (size_t)b * (K + 1);
   const int pcol = p0 + 32 * w + i;
-  if (tid == 0) {   // tile list: K small serial steps, once per workgroup
-    int t = 0;
+  // tile list, built by K threads at once: thread k fetches its cluster's extent (three independent global loads -- the
+  // one-thread loop this replaces paid K dependent round trips, ~60 us per workgroup, a quarter of the kernel), thread 0
+  // turns the per-cluster tile counts into offsets (LDS only), thread k writes its cluster's tiles
+  int32_t* tl_pre = tl_n + maxt;                                   // [K + 1] first tile of cluster k
+  int my_o0 = 0, my_n = 0, my_g0 = 0;
+  if (tid < K) {
+    my_o0 = lo[tid];
+    my_n = lo[tid + 1] - my_o0;
+    my_g0 = rowbase[(size_t)b * K + tid];
+    tl_pre[tid + 1] = (my_n + PJ_T - 1) / PJ_T;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    tl_pre[0] = 0;
     for (int k = 0; k < K; ++k) {
-      const int o0 = lo[k], n = lo[k + 1] - o0, g0 = rowbase[(size_t)b * K + k];
-      for (int j0 = 0; j0 < n && t < maxt; j0 += PJ_T, ++t) {
-        tl_k[t] = k;
-        tl_j[t] = o0 + j0;
-        tl_z[t] = g0 + j0;
-        tl_n[t] = min(PJ_T, n - j0);
-      }
+      run += tl_pre[k + 1];
+      tl_pre[k + 1] = run;
     }
-    s_tiles = t;
+    s_tiles = run < maxt ? run : maxt;
+  }
+  __syncthreads();
+  if (tid < K) {
+    int t = tl_pre[tid];
+    for (int j0 = 0; j0 < my_n && t < maxt; j0 += PJ_T, ++t) {
+      tl_k[t] = tid;
+      tl_j[t] = my_o0 + j0;
+      tl_z[t] = my_g0 + j0;
+      tl_n[t] = min(PJ_T, my_n - j0);
+    }
   }
   __syncthreads();
   const int tiles = s_tiles;
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
   for (int sc = 0; sc < SCb; ++sc) {
     const int Sc = min(64, S - 64 * sc);
     __syncthreads();   // the previous chunk's readers of ag / zt are done
-    for (int idx = tid; idx < 64 * K; idx += 512) {
+    for (int idx = tid; idx < 64 * K; idx += NT_) {
       const int s = idx / K, k = idx - s * K;
       float a = 0.f;
       if (s < Sc) {
@@ -171,53 +193,71 @@ __global__ __launch_bounds__(512) void project_aggregate_kernel(const float* __r
       for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     const bool two = Sc > 32;
 
-    float4 v[4];
-    uint64_t mreg = 0ull;
-    auto fetch = [&](int t) {   // global loads of tile t into registers
-      const int nt = tl_n[t];
-      const float* src = Z + (size_t)tl_z[t] * P;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx4 = tid + 512 * q, row = idx4 >> 6, c4 = idx4 & 63;
-        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nt && p0 + 4 * c4 < P) v[q] = *reinterpret_cast<const float4*>(src + (size_t)row * P + p0 + 4 * c4);
-      }
-      if (tid < PJ_T) mreg = tid < nt ? colmask[((size_t)b * N + tl_j[t] + tid) * SC + sc] : 0ull;
-    };
-    auto stash = [&](int buf) {   // registers -> LDS tile `buf`
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx4 = tid + 512 * q, row = idx4 >> 6, c4 = idx4 & 63;
-        *reinterpret_cast<float4*>(zt + (size_t)buf * PJ_T * 256 + row * 256 + 4 * c4) = v[q];
-      }
-      if (tid < PJ_T) mk[buf * PJ_T + tid] = mreg;
-    };
+    // Two register sets: the rows of tile t+1 AND t+2 are in flight while tile t is multiplied (a tile is ~24 rows = 0.6 us
+    // of MFMA work; with one tile in flight every tile waited out most of a ~1.5 us load round trip).  The sets are named
+    // and the loop is unrolled by two (an array indexed by t & 1 would go to scratch memory).
+    float4 va[4], vb[4];
+    uint64_t ma = 0ull, mb = 0ull;
+#define SV_PJ_FETCH(V, M, t_)                                                                                   \
+    do {                                                                                                        \
+      const int nt_ = tl_n[t_];                                                                                 \
+      const float* src_ = Z + (size_t)tl_z[t_] * P;                                                             \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+        const int idx4 = tid + NT_ * q, row = idx4 / C4W, c4 = idx4 % C4W;                                      \
+        V[q] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                 \
+        if (row < nt_ && p0 + 4 * c4 < P) V[q] = *reinterpret_cast<const float4*>(src_ + (size_t)row * P + p0 + 4 * c4); \
+      }                                                                                                         \
+      if (tid < PJ_T) M = tid < nt_ ? colmask[((size_t)b * N + tl_j[t_] + tid) * SC + sc] : 0ull;               \
+    } while (0)
+#define SV_PJ_STASH(V, M, buf_)                                                                                 \
+    do {                                                                                                        \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+        const int idx4 = tid + NT_ * q, row = idx4 / C4W, c4 = idx4 % C4W;                                      \
+        *reinterpret_cast<float4*>(zt + (size_t)(buf_) * PJ_T * NC + row * NC + 4 * c4) = V[q];                 \
+      }                                                                                                         \
+      if (tid < PJ_T) mk[(buf_) * PJ_T + tid] = M;                                                              \
+    } while (0)
+#define SV_PJ_MUL(t_)                                                                                           \
+    do {                                                                                                        \
+      const int cur_ = (t_) & 1, k_ = tl_k[t_], nt_ = tl_n[t_];                                                 \
+      const float a0k = ag[i * KS + k_], a1k = ag[(32 + i) * KS + k_];                                          \
+      const float* ztc = zt + (size_t)cur_ * PJ_T * NC + 32 * w + i;                                            \
+      const uint64_t* mkc = mk + cur_ * PJ_T;                                                                   \
+      for (int pr = 0; 2 * pr < nt_; ++pr) {                                                                    \
+        const int j = 2 * pr + kk;                                                                              \
+        const uint64_t m = mkc[j];                                                                              \
+        const float bv = ztc[j * NC];                                                                           \
+        const float a0 = ((m >> i) & 1ull) ? a0k : 0.f;                                                         \
+        acc[0] = MFMA32(a0, bv, acc[0]);                                                                        \
+        if (two) {                                                                                              \
+          const float a1 = ((m >> (32 + i)) & 1ull) ? a1k : 0.f;                                                \
+          acc[1] = MFMA32(a1, bv, acc[1]);                                                                      \
+        }                                                                                                       \
+      }                                                                                                         \
+    } while (0)
+    // set A carries the odd tiles' predecessors: tile 0 -> LDS directly, then A = tile 1, B = tile 2, A = tile 3, ...
     if (tiles > 0) {
-      fetch(0);
-      stash(0);
+      SV_PJ_FETCH(va, ma, 0);
+      SV_PJ_STASH(va, ma, 0);
     }
+    if (tiles > 1) SV_PJ_FETCH(va, ma, 1);
     __syncthreads();   // ag and tile 0 visible
-    for (int t = 0; t < tiles; ++t) {
-      const int cur = t & 1;
-      if (t + 1 < tiles) fetch(t + 1);   // in flight under this tile's MFMAs
-      const int k = tl_k[t], nt = tl_n[t];
-      const float a0k = ag[i * KS + k], a1k = ag[(32 + i) * KS + k];
-      const float* ztc = zt + (size_t)cur * PJ_T * 256 + 32 * w + i;
-      const uint64_t* mkc = mk + cur * PJ_T;
-      for (int pr = 0; 2 * pr < nt; ++pr) {
-        const int j = 2 * pr + kk;
-        const uint64_t m = mkc[j];
-        const float bv = ztc[j * 256];
-        const float a0 = ((m >> i) & 1ull) ? a0k : 0.f;
-        acc[0] = MFMA32(a0, bv, acc[0]);
-        if (two) {
-          const float a1 = ((m >> (32 + i)) & 1ull) ? a1k : 0.f;
-          acc[1] = MFMA32(a1, bv, acc[1]);
-        }
-      }
-      if (t + 1 < tiles) stash(cur ^ 1);   // (the readers of that buffer -- tile t-1 -- passed the previous barrier)
+    for (int t = 0; t < tiles; t += 2) {
+      // even tile t: tile t+1 waits in A, tile t+2 is requested into B
+      if (t + 2 < tiles) SV_PJ_FETCH(vb, mb, t + 2);
+      SV_PJ_MUL(t);
+      if (t + 1 < tiles) SV_PJ_STASH(va, ma, 1);   // (the readers of that buffer -- tile t-1 -- passed the previous barrier)
+      __syncthreads();
+      if (t + 1 >= tiles) break;
+      // odd tile t+1: tile t+2 waits in B, tile t+3 is requested into A
+      if (t + 3 < tiles) SV_PJ_FETCH(va, ma, t + 3);
+      SV_PJ_MUL(t + 1);
+      if (t + 2 < tiles) SV_PJ_STASH(vb, mb, 0);
       __syncthreads();
     }
+#undef SV_PJ_MUL
+#undef SV_PJ_STASH
+#undef SV_PJ_FETCH
     if (pcol < P) {
       const float cs = col_scale ? col_scale[pcol] : 1.f, mu = wmu[pcol];
 #pragma unroll
@@ -239,13 +279,21 @@ int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* w
   if (B <= 0 || S_max <= 0) return SEGVLAD_OK;
   if (P % 4) return ctx->fail(SEGVLAD_ERR_ARG, "project_aggregate: P=%d must be a multiple of 4", P);
   const int maxt = K + (N + PJ_T - 1) / PJ_T;   // every cluster may end in a partial tile
-  const size_t lds = (size_t)64 * (K + 1 + (K & 1)) * 4 + (size_t)2 * PJ_T * 256 * 4 + (size_t)2 * PJ_T * 8 + (size_t)4 * maxt * 4;
+  const int nw = ctx->opt.pj_nw == 4 ? 4 : 8;
+  if (K > 64 * nw) return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d clusters need %d threads", K, K);
+  const size_t lds = (size_t)64 * (K + 1 + (K & 1)) * 4 + (size_t)2 * PJ_T * 32 * nw * 4 + (size_t)2 * PJ_T * 8 + (size_t)4 * maxt * 4 +
+                     (size_t)(K + 1) * 4;
   if (lds > 160 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d, N=%d need %zu B of LDS", K, N, lds);
-  if (lds > 64 * 1024)
-    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(project_aggregate_kernel), (size_t)lds));
-  hipLaunchKernelGGL(project_aggregate_kernel, dim3((P + 255) / 256, B), dim3(512), lds, ctx->stream, Z, wmu, block_norms, gscale,
-                     colmask, lab_off, rowbase, seg_off_dev, N, K, P, SC, maxt, col_scale, Y);
+  const void* fn = nw == 8 ? reinterpret_cast<const void*>(project_aggregate_kernel<8>) : reinterpret_cast<const void*>(project_aggregate_kernel<4>);
+  if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(fn, (size_t)lds));
+  const dim3 grid((P + 32 * nw - 1) / (32 * nw), B), block(64 * nw);
+  if (nw == 8)
+    hipLaunchKernelGGL(project_aggregate_kernel<8>, grid, block, lds, ctx->stream, Z, wmu, block_norms, gscale, colmask, lab_off, rowbase,
+                       seg_off_dev, N, K, P, SC, maxt, col_scale, Y);
+  else
+    hipLaunchKernelGGL(project_aggregate_kernel<4>, grid, block, lds, ctx->stream, Z, wmu, block_norms, gscale, colmask, lab_off, rowbase,
+                       seg_off_dev, N, K, P, SC, maxt, col_scale, Y);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
