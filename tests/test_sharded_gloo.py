@@ -131,3 +131,70 @@ def test_single_process_fallback_has_no_collective():
     from oracle import segvlad_oracle as O
 
     assert np.array_equal(ids.numpy(), O.knn_l2(R, Q, 5)[1])
+
+
+class NativeCommBackend(OracleBackend):
+    """OracleBackend + the C-ABI's communicator surface (comm_unique_id / comm_init / allgather_rows / search_sharded),
+    realised with gloo collectives: what ShardedSegmentIndex(native_comm=True) drives on a GPU node, minus RCCL."""
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world):
+        assert uid == bytes(range(128)) and 0 <= rank < world      # every rank received rank 0's id
+        self.rank, self.world = rank, world
+
+    def allgather_rows(self, x):
+        out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        return out
+
+    def search_sharded(self, Q, k, id_base):
+        d2, idx = self.search(Q, k)
+        idx = torch.where(idx >= 0, idx + id_base, idx)
+        dl, il = [torch.empty_like(d2) for _ in range(self.world)], [torch.empty_like(idx) for _ in range(self.world)]
+        dist.all_gather(dl, d2.contiguous())
+        dist.all_gather(il, idx.contiguous())
+        return self.merge_topk(torch.cat(dl, 1), torch.cat(il, 1), self.world, k)
+
+
+def native_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from revisit_anything_amd.sharded import ShardedSegmentIndex, shard_images
+
+    R, img, Q, tau, off = make_problem()
+    ib = shard_images(61, world)
+    rows = slice(ib[rank] * 7, ib[rank + 1] * 7)
+    idx = ShardedSegmentIndex(NativeCommBackend(), native_comm=True)
+    idx.build(R[rows], img[rows])                                   # broadcasts rank 0's communicator id, binds it
+    assert idx.be.world == world and idx.be.rank == rank
+    qb = (shard_images(Q.shape[0] // 21, world) * 21) if world == 3 else shard_images(Q.shape[0], world)
+    Qg = idx.gather_rows(torch.from_numpy(Q[qb[rank]:qb[rank + 1]]), [int(qb[r + 1] - qb[r]) for r in range(world)])
+    assert np.array_equal(Qg.numpy(), Q)
+    d2, ids = idx.search(Qg, 20)
+    pred, sc, m, sims = idx.retrieve(Qg, off, k_search=20, k_vote=10, n_top=3, want_scores=True)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), d2=d2.numpy(), ids=ids.numpy(), pred=pred.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_comm_surface_equals_single_index(tmp_path, world):
+    """The control flow of ShardedSegmentIndex(native_comm=True) -- id broadcast, comm_init, one-call sharded search with
+    id_base = first row of the shard, equal-slice row gather through the backend (world 3) and the padded torch path
+    (world 2: ragged slices) -- against a single index, bit for bit."""
+    mp.spawn(native_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle import segvlad_oracle as O
+
+    R, img, Q, tau, off = make_problem()
+    d2, ids = O.knn_l2(R, Q, 20)
+    sims = (2 - d2[:, :10]).astype(np.float32)
+    rng = [np.arange(off[i], off[i + 1]) for i in range(len(off) - 1)]
+    preds = O.get_matches_wt_borda_im(ids[:, :10], len(rng), sims, rng, img.astype(np.int64), n=3)
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["ids"], ids) and np.array_equal(z["d2"], d2)
+        for i, p in enumerate(preds):
+            assert z["pred"][i][:len(p)].tolist() == [int(x) for x in p]
