@@ -53,9 +53,11 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   tail -c 600 $OUT/${TAG}_bench_n1.json
   cd /tmp && export TMPDIR=/tmp
   # same command under the kernel trace (the CPU-baseline leg launches no kernels)
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python $REPO/bench.py --no-cpu-baseline \
+  # (--no-ubench: the micro-benchmark is a child process, rocprofv3 would trace it into a second set of files)
+  rm -rf /tmp/prof_kt
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python $REPO/bench.py --no-cpu-baseline --no-ubench \
      > $OUT/${TAG}_bench_n1_under_rocprof.json 2> /tmp/prof_kt.err
-  f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_n1_kernel_stats.csv
+  f=$(ls -S $(find /tmp/prof_kt -name '*kernel_stats.csv') 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_n1_kernel_stats.csv
   # the single-image streaming pass (roofline_knn_stream): per-kernel durations of 50 passes
   rm -rf /tmp/prof_st
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_st -- python $REPO/tools/probe_stream.py 50 \
