@@ -280,3 +280,44 @@ def test_refine_band_overflow_takes_the_second_tier_and_list_overflow_the_matrix
         eng.stage_ms("knn_fallback")
     eng.set_profiling(False)
     eng.db_reset()
+
+
+def test_second_tier_runs_per_chunk_of_queries(eng):
+    """More queries than one chunk of the search (16 384): a query of the FIRST chunk whose refine band overflows must be
+    refined from its candidate list before the second chunk overwrites the lists."""
+    import torch
+
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    n, d, nq, k = 120000, 128, 20000, 20
+    R = torch.randn(n, d, device=dev, generator=g)
+    R[:, d - 1] = 0.0
+    R = torch.nn.functional.normalize(R, dim=1)
+    star = 0.2 * torch.nn.functional.normalize(torch.randn(1, d, device=dev, generator=g) * (torch.arange(d, device=dev) < d - 1), dim=1)
+    star[0, d - 1] = 1.0
+    star = torch.nn.functional.normalize(star, dim=1)
+    dup = torch.arange(0, 700, device=dev) * 151 + 9
+    R[dup] = star[0]
+    src = torch.randint(0, n - 1, (nq,), device=dev, generator=g)
+    for _ in range(4):
+        src = torch.where(torch.isin(src, dup), src + 1, src)
+    Q = R[src] + (1.0 / d ** 0.5) * torch.randn(nq, d, device=dev, generator=g)
+    Q[:, d - 1] = 0.0
+    Q = torch.nn.functional.normalize(Q, dim=1)
+    Q[77] = star[0]                      # chunk 0
+    Q[19000] = star[0]                   # chunk 1
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = eng.search(Q, k)
+    st = eng.search_stats()
+    assert st["n_refine2"] == 2 and st["n_fallback"] == 0, st
+    want = np.sort(dup.cpu().numpy())[:k]
+    assert np.array_equal(idx[77].cpu().numpy(), want) and np.array_equal(idx[19000].cpu().numpy(), want)
+    assert float(d2[[77, 19000]].abs().max()) < 1e-6
+    sel = torch.tensor([0, 1, 76, 78, 16383, 16384, 18999, 19999], device=dev)
+    rd2, ridx = O().knn_l2(R.cpu().numpy(), Q[sel].cpu().numpy(), k)
+    assert np.abs(d2[sel].cpu().numpy() - rd2).max() < 1e-5
+    clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
+    assert np.array_equal(idx[sel].cpu().numpy()[clear], ridx[clear])
+    eng.db_reset()
