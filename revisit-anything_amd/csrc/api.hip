@@ -1204,8 +1204,23 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_HIP(ctx->s_qf16.reserve((size_t)nq * d * 2));
     SV_TRY(sv_launch_to_f16(ctx, (const float*)dq, (int64_t)nq * d, qscale, ctx->s_qf16.as<uint16_t>()));
     pl.inv_scale = 1.f / (qscale * ctx->db_f16_scale);
-    // |d2~ - d2| <= c_eps ||q|| ||r||: ctx.h, sv_f16_c_eps (the constant of the kernel variant that will run)
-    pl.c_eps = sv_f16_c_eps(d, sv_f16_kblock(ctx->opt, d));
+    // |d2~ - d2| <= c_eps ||q|| ||r||: ctx.h, sv_f16_c_eps (the constant of the kernel variant that will run).  Batches
+    // (> 128 queries, default configuration) take the biased-accumulator kernel when the norms are balanced enough for
+    // its margin: bias_mult = 1 + max||r|| / (2 min||q||), 1.5 for unit vectors
+    float bias_mult = 1.f;
+    ctx->f16_bias_ok = false;
+    if (nq > 128 && (ctx->opt.f16_cfg < 0 || ctx->opt.f16_cfg == 250) && !sv_f16_kblock(ctx->opt, d)) {
+      float q2min = 0.f;
+      SV_TRY(sv_row_norm_min(ctx, qn, nq, &q2min));
+      if (q2min > 0.f && pl.rn_max > 0.f) {
+        const float bm = 1.f + std::sqrt(pl.rn_max) / (2.f * std::sqrt(q2min));
+        if (std::isfinite(bm) && bm <= 5.f) {
+          bias_mult = bm;
+          ctx->f16_bias_ok = true;
+        }
+      }
+    }
+    pl.c_eps = sv_f16_c_eps(d, sv_f16_kblock(ctx->opt, d), bias_mult);
   } else if (bf16_path) {
     // lazily extend the bf16 planes to the rows added since the last search
     if (ctx->db_split_rows < n) {

@@ -118,10 +118,14 @@ inline int sv_f16_kblock(const SvOptions& o, int d) {
 //   accumulation one running accumulator: <= 2 roundings per product, 2 d 2^-24;
 //                blocked (kb > 0): 2 kb 2^-24 inside a block -- whatever order the matrix pipe sums a k-step in -- plus
 //                (d / kb + 1) 2^-24 for the fp32 additions of the block sums,
-// all relative to sum_i |q_i r_i| <= ||q|| ||r||; the factor 2 turns the error of the dot product into that of d2.
-inline float sv_f16_c_eps(int d, int kb) {
+//                relative to the largest running magnitude: sum_i |q_i r_i| <= ||q|| ||r||.  The batch kernels' BIAS starts
+//                the accumulators at -||r||^2 / 2, so the running magnitude is <= ||q|| ||r|| + ||r||^2 / 2
+//                <= bias_mult ||q|| max||r|| with bias_mult = 1 + max||r|| / (2 min||q||) over the query batch (1.5 for unit
+//                vectors; segvlad_search measures it and keeps the unbiased kernel when it exceeds 5); bias_mult = 1 without;
+// the factor 2 turns the error of the dot product into that of d2.
+inline float sv_f16_c_eps(int d, int kb, float bias_mult) {
   const float acc = kb > 0 ? (2.f * (float)kb + (float)((d + kb - 1) / kb) + 1.f) / 16777216.f : 2.f * (float)d / 16777216.f;
-  return 2.5f * (1.f / 1024.f + 1.f / 4194304.f + acc);
+  return 2.5f * (1.f / 1024.f + 1.f / 4194304.f + bias_mult * acc);
 }
 
 // statistics of the last segvlad_search (segvlad_search_stats)
@@ -176,6 +180,7 @@ struct segvlad_ctx {
   float db_f16_scale = 0.f, db_maxabs = 0.f;
   float db_rn_max = 0.f;
   int64_t db_rn_max_rows = 0;
+  bool f16_bias_ok = false;   // this search's batch filter launches may use the biased-accumulator kernel (segvlad_search)
   bool db_heur_off = false;   // set when > 25 % of a search's queries needed the rigorous redo (until the index changes)
 
   // scratch (grow-only, reused across calls)
@@ -293,6 +298,7 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
                            const uint32_t* only_rows = nullptr);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
+int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);
 // gemm_f16x3_kernels.hip
 int sv_launch_split_f16x2(segvlad_ctx* ctx, const float* X, int64_t n_rows, int d, const float* sub, float scale, uint16_t* h1,

@@ -389,7 +389,13 @@ __device__ __forceinline__ float acc_elem(const f32x16& v, int r) {
 //      are added into a second register set and cleared, so that the fp32 accumulation error of a dot product is bounded
 //      by (2 KBT HBK + d / (KBT HBK)) 2^-24 sum|q_i r_i| instead of 2 d 2^-24 sum|q_i r_i| -- whatever the matrix pipe's
 //      internal summation order is (see sv_f16_c_eps).  Needs the plain loop (PP == 0) and 2 x TM x TN x 16 accumulators.
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0>
+// BIAS: the accumulators START at -||r||^2 / 2 (in the scaled domain) instead of 0, so that at the end of the k-loop they
+//      hold dot - ||r||^2 / 2 -- the quantity the epilogue screens -- and the per-element subtraction of pass 1 (four of its
+//      seven VALU instructions per four elements) disappears; d2~ = ||q||^2 - 2 acc / scale.  The column norms are fetched
+//      ahead of the tile (before the head DMA; PERSIST: before the previous tile's epilogue).  The running sums are up to
+//      1.5 x larger in magnitude, which sv_f16_c_eps accounts for.
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
+          bool BIAS = false>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total,
@@ -475,6 +481,16 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       }
     }
   };
+  // BIAS: this lane's column norms of the (next) tile, requested BEFORE the tile's head so that the head's wait covers them
+  float cnn[TN];
+  auto load_cn = [&](int tn_) {
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int64_t colj = (int64_t)tn_ * BN + wn * (32 * TN) + nt * 32 + (threadIdx.x & 31);
+      cnn[nt] = (colj < N) ? rn[colj * b_stride] : INFINITY;  // +inf: columns beyond N never pass
+    }
+  };
+  if (BIAS) load_cn(tn);
   issue_head(tm, tn);
   if (NB == 3 && ntiles > 1)
     wait_vm_lgkm0<JB>();
@@ -491,13 +507,20 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   const int tid = lane_opaque, l = tid & 63, i = l & 31, kk = l >> 5;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
+  float cn[TN];
+  if (BIAS) {
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) cn[nt] = cnn[nt];
+  }
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int b = 0; b < TN; ++b) {
+      const float a0_ = BIAS ? -(cn[b] * (0.5f / inv_scale)) : 0.f;   // (the same product the epilogue forms: cnh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = a0_;
+    }
   f32x16 accb[KBT > 0 ? TM : 1][KBT > 0 ? TN : 1];   // blocked accumulation: the sum of the finished k-blocks
   if (KBT > 0) {
 #pragma unroll
@@ -516,11 +539,12 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     pre_q2 = qn[m0 + tid];
     pre_thr = thr[(m0 + tid) * thr_ld];
   }
-  float cn[TN];
+  if (!BIAS) {
 #pragma unroll
-  for (int nt = 0; nt < TN; ++nt) {
-    const int64_t colj = n0 + wn * (32 * TN) + nt * 32 + i;
-    cn[nt] = (colj < N) ? rn[colj * b_stride] : INFINITY;  // +inf: columns beyond N never pass
+    for (int nt = 0; nt < TN; ++nt) {
+      const int64_t colj = n0 + wn * (32 * TN) + nt * 32 + i;
+      cn[nt] = (colj < N) ? rn[colj * b_stride] : INFINITY;  // +inf: columns beyond N never pass
+    }
   }
 
   // per-lane source rows of this wave's DMA pieces (clamped: edge rows are never emitted)
@@ -796,7 +820,10 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   if (PERSIST) {
     seq_next = seq + 32;
     while (seq_next < seq_total && !tile_of(seq_next, tm_next, tn_next)) seq_next += 32;
-    if (seq_next < seq_total) issue_head(tm_next, tn_next);
+    if (seq_next < seq_total) {
+      if (BIAS) load_cn(tn_next);
+      issue_head(tm_next, tn_next);
+    }
   }
   // ---- epilogue: keep d2~ <= thr + eps_mult * eps(q) -----------------------------------------------------------
   // The epilogue is VALU-issue bound (s_memtime phase timing, SEGVLAD_F16_CFG=90: every instruction of the sparse
@@ -844,8 +871,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   float cnh[TN];
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
-    cnh[nt] = cn[nt] * half_scale;
-    if (wm == 0) cnl[wn * (32 * TN) + nt * 32 + i] = cn[nt];   // both half-waves hold the same value
+    cnh[nt] = BIAS ? 0.f : cn[nt] * half_scale;                  // BIAS: already inside the accumulators
+    if (!BIAS && wm == 0) cnl[wn * (32 * TN) + nt * 32 + i] = cn[nt];   // both half-waves hold the same value
   }
   __syncthreads();
   SV_PHASE(2)  // row records staged
@@ -881,7 +908,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
         av[nt] = acc_elem<ACC_A>(acc[mt][nt], r);
-        dd[nt] = av[nt] - cnh[nt];
+        dd[nt] = BIAS ? av[nt] : av[nt] - cnh[nt];
       }
       float best = dd[0];
 #pragma unroll
@@ -911,7 +938,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     uint2 rec = wlist[t];
     const int lrow = (int)(rec.y >> 16);
     const float4 rr = rrec[lrow];
-    const float v = sv_d2(rr.x, cnl[rec.y & 0xffffu], __uint_as_float(rec.x) * inv_scale);
+    const float v = BIAS ? __fmaf_rn(-2.f, __uint_as_float(rec.x) * inv_scale, rr.x)
+                         : sv_d2(rr.x, cnl[rec.y & 0xffffu], __uint_as_float(rec.x) * inv_scale);
     if (v <= rr.y && v < INFINITY) {   // +inf: padding columns beyond N (admitted by the screen when thr = +inf)
       atomicAdd(&rowcnt[lrow], 1u);
       rec.x = __float_as_uint(v);
@@ -934,7 +962,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
           const float4 rr = rrec[lrow];
-          const float v = sv_d2(rr.x, cn[nt], acc_elem<ACC_A>(acc[mt][nt], r) * isc);
+          const float v = BIAS ? __fmaf_rn(-2.f, acc_elem<ACC_A>(acc[mt][nt], r) * isc, rr.x)
+                               : sv_d2(rr.x, cn[nt], acc_elem<ACC_A>(acc[mt][nt], r) * isc);
           if (v <= rr.y && v < INFINITY) atomicAdd(&rowcnt[lrow], 1u);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the 32 row-record loads from being hoisted (register pressure)
@@ -974,7 +1003,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         for (int nt = 0; nt < TN; ++nt) {
           const float4 rr = rrec[lrow];
           {
-            const float v = sv_d2(rr.x, cn[nt], acc_elem<ACC_A>(acc[mt][nt], r) * isc);
+            const float v = BIAS ? __fmaf_rn(-2.f, acc_elem<ACC_A>(acc[mt][nt], r) * isc, rr.x)
+                                 : sv_d2(rr.x, cn[nt], acc_elem<ACC_A>(acc[mt][nt], r) * isc);
             if (v <= rr.y && v < INFINITY) {
               const uint32_t slot = atomicAdd(&rowcnt[lrow], 1u);
               if (slot < (uint32_t)cap) {
@@ -996,7 +1026,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   }   // tile loop
 }
 
-template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0>
+template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
+          bool BIAS = false>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1028,7 +1059,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS>;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -1091,9 +1122,15 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 50: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2>(SV_F16_ARGS);  // ping-pong, 2 phases per k-tile
     case 51: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 4>(SV_F16_ARGS);  // ping-pong, 4 phases per k-tile
     case 52: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 1>(SV_F16_ARGS);  // ping-pong, 1 phase per k-tile
-    case 250:
+    case 250:   // the default for batches: biased accumulators (see BIAS) when segvlad_search found the norms balanced enough
+      if (!ctx->f16_bias_ok) goto unbiased_250;
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
-        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2>(SV_F16_ARGS);        // persistent + ping-pong
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true>(SV_F16_ARGS);        // persistent + ping-pong
+      return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true>(SV_F16_ARGS);
+    case 251:   // 250 without the bias (A/B; norms too unbalanced for the biased margin)
+    unbiased_250:
+      if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2>(SV_F16_ARGS);
       return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2>(SV_F16_ARGS);
     case 40: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 1>(SV_F16_ARGS);  // database rows non-temporal
     case 41: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 2>(SV_F16_ARGS);  // queries non-temporal
@@ -1786,6 +1823,31 @@ __global__ __launch_bounds__(256) void max_kernel(const float* __restrict__ x, i
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) m = max(m, f2key_(x[j]));
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+__global__ __launch_bounds__(256) void min_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0xffffffffu;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) m = min(m, f2key_(x[j]));
+  for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) atomicMin(out, m);
+}
+
+// smallest of n non-negative values (the query batch's smallest squared norm), read back to the host (synchronises)
+int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host) {
+  SV_HIP(ctx->s_minmax.reserve(32));
+  uint32_t* mm = ctx->s_minmax.as<uint32_t>() + 6;
+  SV_HIP(hipMemsetAsync(mm, 0xff, 4, ctx->stream));
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (n > 0) hipLaunchKernelGGL(min_kernel, dim3(blocks), dim3(256), 0, ctx->stream, norms, n, mm);
+  uint32_t key = 0;
+  SV_HIP(hipMemcpyAsync(&key, mm, 4, hipMemcpyDeviceToHost, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  const uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+  float f;
+  memcpy(&f, &u, 4);
+  *out_host = (n > 0 && key != 0xffffffffu) ? f : 0.f;
+  return SEGVLAD_OK;
 }
 
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host) {
