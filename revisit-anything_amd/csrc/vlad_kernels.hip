@@ -568,6 +568,35 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ T
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// one [32 d][128 token] chunk of assign_wide_kernel out of its LDS tile: scores (fp32 MFMA against the pre-swizzled centres),
+// squared norms, and the token-major copy Xt
+template <int NT>
+__device__ __forceinline__ void assign_wide_chunk(const float* __restrict__ tl, const float* __restrict__ bt, float* __restrict__ Xt,
+                                                  int b, int N, int D, int t0, int tid, int w, int l, int i, int kk, int c,
+                                                  f32x16 (&acc)[NT], float& ss) {
+  constexpr int DC = 32, TS = 128;
+  auto rot = [](int d) { return 8 * (d >> 2) + 32 * (d & 1); };
+#pragma unroll 8
+  for (int st = 0; st < DC / 2; ++st) {
+    const float x = tl[(2 * st + kk) * TS + ((32 * w + i + rot(2 * st + kk)) & 127)];
+    ss = fmaf(x, x, ss);
+    const float* bp = bt + ((size_t)(c * (DC / 2) + st) * NT) * 64 + l;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = MFMA32(x, bp[n * 64], acc[n]);
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = it * 256 + tid;
+    const int tok = idx >> 3, c4 = idx & 7;
+    if (t0 + tok < N) {
+      const float* q = tl + (4 * c4) * TS;   // rows 4 c4 + e: rotation 8 c4 + 32 (e & 1)
+      const int t_a = (tok + 8 * c4) & 127, t_b = (tok + 8 * c4 + 32) & 127;
+      const float4 o = make_float4(q[t_a], q[TS + t_b], q[2 * TS + t_a], q[3 * TS + t_b]);
+      *reinterpret_cast<float4*>(Xt + ((size_t)b * N + t0 + tok) * D + c * DC + 4 * c4) = o;
+    }
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restrict__ T, int N, int D, int K,
                                                           const float* __restrict__ bt, float* __restrict__ Xt,
@@ -595,51 +624,43 @@ __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restric
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
   float ss = 0.f;
   const int nch = D / DC;
-  float4 v[4];
-#define SV_LOAD_CHUNK(c)                                                              \
+  // Two named register sets: chunks c + 1 AND c + 2 are in flight while chunk c is multiplied (one 16-KiB chunk per
+  // workgroup in flight, four workgroups per CU, left the kernel at 3.8 TB/s of its read + write traffic; the loop is
+  // unrolled by two so that the sets are never indexed dynamically).
+  float4 va[4], vb[4];
+#define SV_LOAD_CHUNK(V, c)                                                           \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
     const float* p = Tb + (size_t)((c) * DC + lr + 8 * j) * N + tl0;                  \
     if (nvalid >= 4) {                                                                \
       const f32x4u u = *reinterpret_cast<const f32x4u*>(p);                           \
-      v[j] = make_float4(u[0], u[1], u[2], u[3]);                                     \
+      V[j] = make_float4(u[0], u[1], u[2], u[3]);                                     \
     } else {                                                                          \
-      v[j] = make_float4(nvalid > 0 ? p[0] : 0.f, nvalid > 1 ? p[1] : 0.f, nvalid > 2 ? p[2] : 0.f, 0.f); \
+      V[j] = make_float4(nvalid > 0 ? p[0] : 0.f, nvalid > 1 ? p[1] : 0.f, nvalid > 2 ? p[2] : 0.f, 0.f); \
     }                                                                                 \
   }
-#define SV_PARK_CHUNK(buf)                                                            \
+#define SV_PARK_CHUNK(V, buf)                                                         \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
     const int d_ = lr + 8 * j;                                                        \
     float* q = tile + (buf) * (DC * TS) + d_ * TS + ((4 * lq + rot(d_)) & 127);       \
-    *reinterpret_cast<float4*>(q) = v[j];                                             \
+    *reinterpret_cast<float4*>(q) = V[j];                                             \
   }
-  SV_LOAD_CHUNK(0)
-  SV_PARK_CHUNK(0)
+  SV_LOAD_CHUNK(va, 0)
+  SV_PARK_CHUNK(va, 0)
+  if (1 < nch) { SV_LOAD_CHUNK(va, 1) }
   __syncthreads();
-  for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) { SV_LOAD_CHUNK(c + 1) }
-    const float* tl = tile + (c & 1) * (DC * TS);
-#pragma unroll 8
-    for (int st = 0; st < DC / 2; ++st) {
-      const float x = tl[(2 * st + kk) * TS + ((32 * w + i + rot(2 * st + kk)) & 127)];
-      ss = fmaf(x, x, ss);
-      const float* bp = bt + ((size_t)(c * (DC / 2) + st) * NT) * 64 + l;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = MFMA32(x, bp[n * 64], acc[n]);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = it * 256 + tid;
-      const int tok = idx >> 3, c4 = idx & 7;
-      if (t0 + tok < N) {
-        const float* q = tl + (4 * c4) * TS;   // rows 4 c4 + e: rotation 8 c4 + 32 (e & 1)
-        const int t_a = (tok + 8 * c4) & 127, t_b = (tok + 8 * c4 + 32) & 127;
-        const float4 o = make_float4(q[t_a], q[TS + t_b], q[2 * TS + t_a], q[3 * TS + t_b]);
-        *reinterpret_cast<float4*>(Xt + ((size_t)b * N + t0 + tok) * D + c * DC + 4 * c4) = o;
-      }
-    }
-    if (c + 1 < nch) { SV_PARK_CHUNK((c + 1) & 1) }
-    __syncthreads();
+  // chunk c + 1 waits in set A when c is even, in set B when c is odd
+#define SV_ASSIGN_STEP(c, VNEXT, VFREE)                                               \
+  {                                                                                   \
+    if ((c) + 2 < nch) { SV_LOAD_CHUNK(VFREE, (c) + 2) }                              \
+    assign_wide_chunk<NT>(tile + ((c) & 1) * (DC * TS), bt, Xt, b, N, D, t0, tid, w, l, i, kk, (c), acc, ss);  \
+    if ((c) + 1 < nch) { SV_PARK_CHUNK(VNEXT, ((c) + 1) & 1) }                        \
+    __syncthreads();                                                                  \
   }
+  for (int c = 0; c < nch; c += 2) {
+    SV_ASSIGN_STEP(c, va, vb)
+    if (c + 1 < nch) SV_ASSIGN_STEP(c + 1, vb, va)
+  }
+#undef SV_ASSIGN_STEP
 #undef SV_LOAD_CHUNK
 #undef SV_PARK_CHUNK
   // ---- scores -> LDS [token][cluster]; one thread per token takes the first maximum and the runner-up ----------
