@@ -185,6 +185,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "assign_narrow")) return as_int(&o.assign_narrow);
   if (!strcmp(key, "agg_kpb")) return as_int(&o.agg_kpb);
   if (!strcmp(key, "pj_nw")) return as_int(&o.pj_nw);
+  if (!strcmp(key, "small_plan")) return as_int(&o.small_plan);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
   return ctx->fail(SEGVLAD_ERR_ARG, "set_option: unknown key '%s'", key);
 }
@@ -214,7 +215,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
                     &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys, &ctx->s_pz, &ctx->s_rowbase,
                     &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part, &ctx->s_rovf,   &ctx->s_ref_lim,
-                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc};
+                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc, &ctx->s_ref_keys, &ctx->s_ref_tick};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -862,6 +863,7 @@ struct SearchPlan {
   int d = 0, k = 0;
   int64_t n = 0;
   float c_eps = 0.f, inv_scale = 1.f, rn_max = 0.f;
+  int ratio = 16;          // sample growth per level (SV_RATIO; 256 for the one-filter-level plan of a single query image)
 };
 constexpr int SV_RATIO = 16, SV_CAP = 8192, SV_RCAP = 512, SV_CHUNK = 16384;
 
@@ -871,6 +873,20 @@ static int heur_rank(int target) {
   int r = 16;
   while (16.0 * r - 64.0 * std::sqrt((double)r) < (double)target) ++r;
   return r;
+}
+
+// The same question for a sample `ratio` times smaller and SMALL ranks, where the normal approximation is off: the
+// number of full-set values below the r-th smallest sample value is ~ ratio * Gamma(r, 1), so take the smallest r with
+// P[Gamma(r, 1) < target / ratio] < 2e-5 (one redo in ~1000 passes of 50 queries).
+static int heur_rank_small(int target, int ratio) {
+  const double x = (double)target / ratio, ex = std::exp(-x);
+  double term = 1.0, sum = 0.0;   // sum_{i < r} x^i / i!
+  for (int r = 1; r < target; ++r) {
+    sum += term;
+    term *= x / r;
+    if (r >= 2 && 1.0 - ex * sum < 2e-5) return r;
+  }
+  return target;
 }
 
 // One pass of the level scheme over m <= SV_CHUNK query rows: exact distances to the coarsest sample, then `levels`
@@ -893,7 +909,8 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   // rank of the threshold handed to level j+1 (rank[levels] = k: the final top-k)
   int rank[8];
   rank[levels] = k;
-  for (int j = levels - 1; j >= 0; --j) rank[j] = heuristic ? std::min(rank[j + 1], heur_rank(rank[j + 1])) : k;
+  for (int j = levels - 1; j >= 0; --j)
+    rank[j] = !heuristic ? k : std::min(rank[j + 1], pl.ratio == SV_RATIO ? heur_rank(rank[j + 1]) : heur_rank_small(rank[j + 1], pl.ratio));
   const int64_t n0 = (n + pl.stride0 - 1) / pl.stride0;
   const int64_t ld0 = (n0 + 3) & ~3ll;
   float* thr = ctx->s_thr_d2.as<float>();
@@ -935,7 +952,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   int64_t stride = pl.stride0;
   std::vector<uint32_t> hcnt;
   for (int lv = 1; lv <= levels; ++lv) {
-    stride /= SV_RATIO;
+    stride /= pl.ratio;
     const int64_t ns = (n + stride - 1) / stride;
     const bool last = (lv == levels);
     // the candidate counters start every level at zero: the mode-0 selects of the approximate-domain filters leave them so;
@@ -1139,13 +1156,24 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // shard: 256, 16, 1 instead of 16, 1 (1.35 -> 0.1 ms).  The rigorous redo keeps the plan above.
   const bool heuristic = pl.kind != 3 && ctx->opt.knn_heuristic && !ctx->db_heur_off && heur_rank(k) < k;
   SearchPlan plh = pl;
-  // (tried for single query images: stopping at a >= 2048-row sample -- one filter level less -- moves the time into the
-  //  64-keys-per-lane select of the 3906-entry sample row: 554 vs 553 us per pass, not kept)
-  if (heuristic)
+  // One query image per pass (<= 128 rows) is bound by its chain of dependent launches, not by the exact level's flops
+  // (option small_plan): ONE filter level behind an exact sample of 2048..4096 rows (stride = the power of two that gives
+  // it: 256 for 1 M rows, 64 for a 250 k-row shard).  The threshold is a low rank of that sample (heur_rank_small: ~7 at
+  // stride 256), the full level collects stride x rank candidates per query (~1800 + the margin's ~900 at 1 M rows: a
+  // workgroup select's worth, SV_CAP bounds it -- hence stride <= 512), and the deeper plan's two sampled filter launches
+  // with their selects (~90 us of a ~500 us pass) are gone.
+  int small_stride = 16;
+  while ((n + small_stride - 1) / small_stride > 4096 && small_stride <= 512) small_stride *= 2;
+  if (heuristic && nq <= 128 && ctx->opt.small_plan && small_stride <= 512) {
+    plh.levels = 1;
+    plh.stride0 = small_stride;
+    plh.ratio = small_stride;
+  } else if (heuristic) {
     while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
       plh.stride0 *= SV_RATIO;
       ++plh.levels;
     }
+  }
   ctx->sstats.levels = plh.levels;
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
     if (new_bytes <= b.cap) return hipSuccess;

@@ -99,6 +99,8 @@ struct SvOptions {
   int agg_kpb = 4;        // clusters per aggregation workgroup
   int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises); 7: token_norms_kernel waits for every
                           //    outstanding memory operation at every step (verification of its counted waits: same bits)
+  int small_plan = 1;     // <= 128 queries (one query image per pass): one filter level behind an exact sample of 2048..4096
+                          // rows (see segvlad_search); 0 = the deep plan of the batches
   int pj_nw = 8;          // waves (32-column slices) per workgroup of the P-space aggregation: 8, or 4 (three workgroups per
                           // CU instead of one: measured SLOWER, 3.72 vs 3.40 ms for the PCA stage of 200 images)
   int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
@@ -186,7 +188,7 @@ struct segvlad_ctx {
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
+      s_qh, s_ql, s_ref_cnt, s_ref_id, s_ref_keys, s_ref_tick, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
       s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part,
       s_rovf, s_ref_lim;
   // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time, the exchange buffers

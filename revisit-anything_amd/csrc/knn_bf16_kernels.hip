@@ -1328,6 +1328,23 @@ __device__ __forceinline__ uint32_t wave_sum_u32_(uint32_t v) {
                     __builtin_amdgcn_readlane(x, 48));
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32_(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
+  return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+             min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_max_u32_(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
+  return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+             max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
 // The same ranking for lists of up to 4096 candidates (every list of the low-rank level scheme, and nearly every list of
 // the rigorous one), one WAVE per query instead of one 256-thread workgroup: the keys live in registers (4, 16 or 64 per
 // lane, by the list's length), the rank-th smallest is found by a binary MSB-first radix select whose per-bit counts are
@@ -1350,17 +1367,43 @@ __device__ __forceinline__ void select_small_body(const float* __restrict__ cd2,
       else thr_out[row] = -INFINITY;
     }
   };
-  uint32_t key[PER];
+  constexpr uint32_t PAD = 0xffffffffu;   // padding sorts last (a real key is never all ones: NaN-free)
+  uint32_t key[PER], cidv[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int j = l + 64 * i;
-    key[i] = 0xffffffffu;   // padding sorts last (a real key is never all ones: NaN-free)
-    if (j < (int)c) key[i] = f2key_(cd2[row * cap + j]);
+    key[i] = PAD;
+    cidv[i] = 0u;
+    if (j < (int)c) {
+      key[i] = f2key_(cd2[row * cap + j]);
+      // mode 1: the ids travel with the keys (fetched behind a ballot branch, slot by slot, each was a round trip of its own:
+      // 12 of the 19 us of a pass's last select)
+      if (mode == 1) cidv[i] = cid[row * cap + j];
+    }
   }
   float ak = INFINITY;
   if ((int)c >= k) {
-    uint32_t prefix = 0, mask = 0, rem = (uint32_t)k;
-    for (int bit = 31; bit >= 0; --bit) {
+    // The keys of a list share their leading bits (distances of one query: same sign, a handful of exponents), and after a
+    // dozen more only one key still matches the prefix: the bit loop starts below the common prefix of the list's smallest and
+    // largest key and stops as soon as a single candidate is left (32 bits x 2 PER VALU instructions were 7 of the ~10 us of a
+    // 4096-key launch).  All of it is wave-uniform.
+    uint32_t kmn = 0xffffffffu, kmx = 0u;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      kmn = min(kmn, key[i]);
+      kmx = key[i] != PAD ? max(kmx, key[i]) : kmx;
+    }
+    kmn = wave_min_u32_(kmn);
+    kmx = wave_max_u32_(kmx);
+    const uint32_t diff = kmn ^ kmx;
+    uint32_t prefix = kmn, mask = 0xffffffffu, rem = (uint32_t)k, m = c;   // diff == 0: every key is kmn
+    int bit = -1;
+    if (diff) {
+      bit = 31 - __builtin_clz(diff);
+      mask = (bit == 31) ? 0u : ~((2u << bit) - 1u);
+      prefix = kmn & mask;
+    }
+    for (; bit >= 0 && m > 1u; --bit) {
       const uint32_t b = 1u << bit;
       // keys that match the prefix so far and have this bit clear: counted per lane (a compare + an add per key slot), then
       // ONE wave sum per bit by DPP row reductions + four readlanes.  (The butterfly of six ds_bpermute shuffles it replaces
@@ -1372,9 +1415,18 @@ __device__ __forceinline__ void select_small_body(const float* __restrict__ cd2,
       const uint32_t zeros = wave_sum_u32_(zl);
       if (rem > zeros) {
         rem -= zeros;
+        m -= zeros;
         prefix |= b;
+      } else {
+        m = zeros;
       }
       mask |= b;
+    }
+    if (bit >= 0) {   // one key left under the prefix: it is the answer, whatever its remaining bits
+      uint32_t v = 0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) v |= (key[i] != PAD && (key[i] & mask) == prefix) ? key[i] : 0u;
+      prefix = wave_max_u32_(v);
     }
     ak = key2f_(prefix);
   }
@@ -1391,16 +1443,154 @@ __device__ __forceinline__ void select_small_body(const float* __restrict__ cd2,
   uint32_t total = 0;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int j = l + 64 * i;
-    const bool hit = (j < (int)c) && key[i] <= klim;
+    const bool hit = key[i] <= klim;   // (klim is a finite float's key: the padding never hits)
     const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
     if (mk != 0ull) {
       const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-      if (hit && pos < (uint32_t)rcap) ref_id[row * rcap + pos] = cid[row * cap + j];
+      if (hit && pos < (uint32_t)rcap) ref_id[row * rcap + pos] = cidv[i];
       total += (uint32_t)__popcll(mk);
     }
   }
   if (l == 0) {
+    if (total > (uint32_t)rcap) {
+      if (rovf_rows) {   // second tier (see select_approx_kernel)
+        rovf_rows[row] = 1u;
+        ref_lim[row] = flim;
+        atomicAdd(rovf_count, 1u);
+      } else if (atomicExch(&ovf_rows[row], 1u) == 0u) {
+        atomicAdd(ovf_count, 1u);
+      }
+      ref_cnt[row] = 0;
+    } else {
+      ref_cnt[row] = total;
+    }
+  }
+}
+
+// One query image per pass (<= 128 lists): a whole workgroup per list instead of a wave -- 32 keys per thread (lists of up
+// to 8192 entries, the capacity of the candidate lists; longer ones are flagged for the exact path), the same
+// binary MSB-first radix select below the common prefix of the list's smallest and largest key, stopping when one key is
+// left; the per-bit count is a DPP wave sum + a four-entry LDS exchange (one barrier per bit: the exchange slots alternate).
+// The wave kernel's 64-keys-per-lane instantiation is ~8000 straight-line instructions that a pass runs through ONCE --
+// instruction fetch, not arithmetic: 29 us for a 3906-entry sample row; this kernel takes ~10.
+__global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+                                                        const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
+                                                        const float* __restrict__ thr_in, int64_t thr_in_ld,
+                                                        const float* __restrict__ qn, float c_eps, float rn_max,
+                                                        float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
+                                                        uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
+                                                        uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
+                                                        uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt) {
+  constexpr uint32_t PAD = 0xffffffffu;
+  constexpr int PER = 32;   // 8192 keys: the candidate lists' capacity (SV_CAP)
+  __shared__ uint32_t xs[2][4];
+  __shared__ uint32_t s_n;
+  const int tid = threadIdx.x, w = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];
+  const uint32_t flagged = ovf_rows[row];
+  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  uint32_t key[PER], cidv[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int j = tid + 256 * i;
+    key[i] = PAD;
+    cidv[i] = 0u;
+    if (j < (int)c && c <= (uint32_t)(256 * PER)) {
+      key[i] = f2key_(cd2[row * cap + j]);
+      if (mode == 1) cidv[i] = cid[row * cap + j];
+    }
+  }
+  if (tid == 0) s_n = 0u;
+  __syncthreads();   // every thread has read cnt[row]
+  if (tid == 0 && mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero
+  if (c > (uint32_t)cap || c > (uint32_t)(256 * PER) || flagged || (check && (int)c < k)) {
+    if (tid == 0) {
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      if (mode == 1) ref_cnt[row] = 0;
+      else thr_out[row] = -INFINITY;
+    }
+    return;
+  }
+  int turn = 0;
+  auto exchange = [&](uint32_t v_wave) {   // v_wave: this wave's (uniform) partial; returns the four partials
+    if ((tid & 63) == 0) xs[turn][w] = v_wave;
+    __syncthreads();
+    const uint4 r = make_uint4(xs[turn][0], xs[turn][1], xs[turn][2], xs[turn][3]);
+    turn ^= 1;
+    return r;
+  };
+  float ak = INFINITY;
+  if ((int)c >= k) {
+    uint32_t kmn = PAD, kmx = 0u;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      kmn = min(kmn, key[i]);
+      kmx = key[i] != PAD ? max(kmx, key[i]) : kmx;
+    }
+    {
+      const uint4 r = exchange(wave_min_u32_(kmn));
+      kmn = min(min(r.x, r.y), min(r.z, r.w));
+    }
+    {
+      const uint4 r = exchange(wave_max_u32_(kmx));
+      kmx = max(max(r.x, r.y), max(r.z, r.w));
+    }
+    const uint32_t diff = kmn ^ kmx;
+    uint32_t prefix = kmn, mask = 0xffffffffu, rem = (uint32_t)k, m = c;   // diff == 0: every key is kmn
+    int bit = -1;
+    if (diff) {
+      bit = 31 - __builtin_clz(diff);
+      mask = (bit == 31) ? 0u : ~((2u << bit) - 1u);
+      prefix = kmn & mask;
+    }
+    for (; bit >= 0 && m > 1u; --bit) {
+      const uint32_t b = 1u << bit;
+      uint32_t zl = 0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) zl += ((key[i] & (mask | b)) == prefix) ? 1u : 0u;
+      const uint4 r = exchange(wave_sum_u32_(zl));
+      const uint32_t zeros = r.x + r.y + r.z + r.w;
+      if (rem > zeros) {
+        rem -= zeros;
+        m -= zeros;
+        prefix |= b;
+      } else {
+        m = zeros;
+      }
+      mask |= b;
+    }
+    if (bit >= 0) {   // one key left under the prefix: it is the answer, whatever its remaining bits
+      uint32_t v = 0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) v |= (key[i] != PAD && (key[i] & mask) == prefix) ? key[i] : 0u;
+      const uint4 r = exchange(wave_max_u32_(v));
+      prefix = max(max(r.x, r.y), max(r.z, r.w));
+    }
+    ak = key2f_(prefix);
+  }
+  if (mode == 0) {
+    if (tid == 0) thr_out[row] = ak;
+    return;
+  }
+  if (check && !(ak <= t_in)) {   // see select_approx_kernel
+    if (tid == 0) {
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      ref_cnt[row] = 0;
+    }
+    return;
+  }
+  const float flim = ak + 2.f * c_eps * sqrtf(qn[row] * rn_max);
+  const uint32_t klim = f2key_(flim);
+#pragma unroll
+  for (int i = 0; i < PER; ++i)
+    if (key[i] <= klim) {   // (a finite float's key: the padding never hits)
+      const uint32_t pos = atomicAdd(&s_n, 1u);
+      if (pos < (uint32_t)rcap) ref_id[row * rcap + pos] = cidv[i];
+    }
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t total = s_n;
     if (total > (uint32_t)rcap) {
       if (rovf_rows) {   // second tier (see select_approx_kernel)
         rovf_rows[row] = 1u;
@@ -1472,9 +1662,14 @@ int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, const float* c
                             uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, uint32_t* rovf_count, float* ref_lim,
                             int fixed_cnt) {
   if (nq <= 0) return SEGVLAD_OK;
-  // a single query image (<= 128 rows): lists beyond 4096 entries are as good as unheard of there, and every launch of a
-  // streaming pass is ~10 us of its ~500: the workgroup kernel is left out (select_small flags such a row for the exact path)
-  const bool wave_only = nq <= 128 || (fixed_cnt >= 0 && fixed_cnt <= 4096);
+  if (nq <= 128) {   // one query image per pass: a workgroup per list
+    hipLaunchKernelGGL(select_wg_kernel, dim3(nq), dim3(256), 0, ctx->stream, cand_cnt, cand_d2, cand_id, cap, rank, mode, check, thr_in,
+                       thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, rovf_rows, rovf_count,
+                       ref_lim, fixed_cnt);
+    SV_HIP(hipGetLastError());
+    return SEGVLAD_OK;
+  }
+  const bool wave_only = fixed_cnt >= 0 && fixed_cnt <= 4096;
   uint32_t* todo = nullptr;
   if (!wave_only) {
     SV_HIP(ctx->s_sel_todo.reserve((size_t)nq * 4));
@@ -1789,6 +1984,118 @@ __global__ __launch_bounds__(256) void refine_exact_wide_kernel(const float* __r
   }
 }
 
+// A handful of queries (one query image per pass): fewer lists than CUs, and a list walked by ONE workgroup is one memory
+// round trip after the other (59 us for 240 rows of 1024 floats).  Here a list is dealt to `parts` workgroups, 32 rows each:
+// a workgroup requests 1024 floats of each of its 32 rows in ONE burst (thread t: 16 bytes of row 2 j + (t >> 7), in both
+// 512-float halves: 32 coalesced loads in flight per thread, one round trip per 1024 floats), parks one half at a time in an
+// LDS tile [32][516], and 32 lanes walk one row each (the same sequential fp32 chain; the query's floats are LDS broadcasts).  The keys go to global memory as device-scope stores; the workgroup that takes the last
+// ticket of its query reads them back, sorts them and writes the top k.  d % 1024 == 0.  tick[] is all zero before and after.
+__global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
+                                                                 const float* __restrict__ qn, const float* __restrict__ rn,
+                                                                 const uint32_t* __restrict__ ref_cnt,
+                                                                 const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
+                                                                 float* __restrict__ d2_out, int64_t* __restrict__ idx_out, int parts,
+                                                                 uint64_t* __restrict__ gkeys, uint32_t* __restrict__ tick) {
+  constexpr int ROWS = 32, KC = 512, LDR = KC + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                  // [ROWS][LDR]
+  uint64_t* a = reinterpret_cast<uint64_t*>(tile + ROWS * LDR);  // [rpad]
+  __shared__ uint32_t ids[ROWS];
+  __shared__ int last;
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x / parts;
+  const int base = (int)(blockIdx.x % parts) * ROWS;
+  // the list's length and this workgroup's slice of it are requested together (the slice lies inside the list's rcap slots
+  // whatever the length; entries beyond it are not looked at)
+  const uint32_t idv = tid < ROWS ? ref_id[row * rcap + base + tid] : 0u;
+  const int n = (int)ref_cnt[row];
+  const int cnt = min(ROWS, n - base);
+  if (cnt > 0) {
+    if (tid < ROWS) ids[tid] = idv;
+    __syncthreads();
+    if (tid >= cnt && tid < ROWS) ids[tid] = ids[0];   // rows beyond the list re-read its first one
+    __syncthreads();
+    const int h = tid >> 7, off = (tid & 127) * 4;
+    // (named registers: hipcc 7.2 sends a float4 g[..] filled in an unrolled loop to scratch memory here, with a vmcnt(0)
+    //  behind every load)
+#define SV_RS_J(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+#define SV_RS_SRC(j) const float* src##j = R + (size_t)ids[2 * j + h] * d + off;
+#define SV_RS_LOAD(j)                                                       \
+  const float4 gA##j = *reinterpret_cast<const float4*>(src##j + c0);        \
+  const float4 gB##j = *reinterpret_cast<const float4*>(src##j + c0 + KC);
+#define SV_RS_STORE_A(j) *reinterpret_cast<float4*>(tile + (2 * j + h) * LDR + off) = gA##j;
+#define SV_RS_STORE_B(j) *reinterpret_cast<float4*>(tile + (2 * j + h) * LDR + off) = gB##j;
+#define SV_RS_WALK(c_)                                                      \
+  if (tid < cnt) {                                                          \
+    const float* tr = tile + tid * LDR;                                     \
+    const float* qb = qs + (c_);                                            \
+    _Pragma("unroll 16") for (int s4 = 0; s4 < KC / 4; ++s4) {              \
+      const float4 rv = *reinterpret_cast<const float4*>(tr + s4 * 4);      \
+      const float4 qv = *reinterpret_cast<const float4*>(qb + s4 * 4);      \
+      acc = fmaf(qv.x, rv.x, acc);                                          \
+      acc = fmaf(qv.y, rv.y, acc);                                          \
+      acc = fmaf(qv.z, rv.z, acc);                                          \
+      acc = fmaf(qv.w, rv.w, acc);                                          \
+    }                                                                       \
+  }
+    SV_RS_J(SV_RS_SRC)
+    // (the query's 1024 floats of the step sit in LDS beside the tile, read as broadcasts: through the scalar cache every
+    //  batch of 64 floats was a cold ~0.7 us miss in front of its fmas)
+    float* qs = reinterpret_cast<float*>(a + rpad);   // [2 KC]
+    const float* qsrc = Q + row * d + tid * 4;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < d; c0 += 2 * KC) {
+      SV_RS_J(SV_RS_LOAD)
+      const float4 qv4 = *reinterpret_cast<const float4*>(qsrc + c0);
+      if (c0) __syncthreads();   // the walkers are done with the previous half
+      SV_RS_J(SV_RS_STORE_A)
+      *reinterpret_cast<float4*>(qs + tid * 4) = qv4;
+      __syncthreads();
+      SV_RS_WALK(0)
+      __syncthreads();
+      SV_RS_J(SV_RS_STORE_B)
+      __syncthreads();
+      SV_RS_WALK(KC)
+    }
+#undef SV_RS_WALK
+#undef SV_RS_STORE_B
+#undef SV_RS_STORE_A
+#undef SV_RS_LOAD
+#undef SV_RS_SRC
+#undef SV_RS_J
+    if (tid < cnt) {
+      const uint32_t id = ids[tid];
+      __hip_atomic_store(&gkeys[row * rcap + base + tid], ((uint64_t)f2key_(sv_d2(qn[row], rn[id], acc)) << 32) | id, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // The keys are device-scope (write-through) stores and device-scope loads; each wave waits for its stores to be
+  // acknowledged before the barrier that precedes the ticket.  (A __threadfence() on either side is an L2 write-back +
+  // invalidate on this eight-L2 part.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) last = (__hip_atomic_fetch_add(&tick[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(parts - 1));
+  __syncthreads();
+  if (!last) return;
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  for (int j = tid; j < np2; j += 256)
+    a[j] = j < n ? __hip_atomic_load(&gkeys[row * rcap + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+  if (tid == 0) __hip_atomic_store(&tick[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  bitonic64(a, np2, tid);
+  for (int j = tid; j < k; j += 256) {
+    float dd = INFINITY;
+    int64_t id = -1;
+    if (j < n) {
+      dd = key2f_((uint32_t)(a[j] >> 32));
+      id = (int64_t)(uint32_t)a[j];
+    }
+    d2_out[row * k + j] = dd;
+    idx_out[row * k + j] = id;
+  }
+}
+
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
                            const uint32_t* only_rows) {
@@ -1796,6 +2103,19 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
   int rpad = 2;
   while (rpad < rcap) rpad <<= 1;
   size_t lds = (size_t)d * 4 + (size_t)rpad * 8;
+  if (nq <= 128 && d % 1024 == 0 && rcap <= 1024 && rcap % 32 == 0 && !only_rows) {   // one query image: lists shared by workgroups
+    const int parts = rcap / 32;
+    const size_t tick_cap = ctx->s_ref_tick.cap;
+    SV_HIP(ctx->s_ref_tick.reserve((size_t)128 * 4));
+    if (ctx->s_ref_tick.cap != tick_cap) SV_HIP(hipMemsetAsync(ctx->s_ref_tick.p, 0, ctx->s_ref_tick.cap, ctx->stream));
+    SV_HIP(ctx->s_ref_keys.reserve((size_t)nq * rcap * 8));
+    lds = (size_t)(32 * 516 + 1024) * 4 + (size_t)rpad * 8;
+    if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_small_kernel), lds));
+    hipLaunchKernelGGL(refine_exact_small_kernel, dim3(nq * parts), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
+                       rpad, k, d2_out, idx_out, parts, ctx->s_ref_keys.as<uint64_t>(), ctx->s_ref_tick.as<uint32_t>());
+    SV_HIP(hipGetLastError());
+    return SEGVLAD_OK;
+  }
 #define SV_REFINE_ARGS dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap, rpad, k, d2_out, idx_out, only_rows
   if (lds <= 160 * 1024) {
     if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_kernel<true>), lds));

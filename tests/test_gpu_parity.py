@@ -642,12 +642,15 @@ def test_pipeline_device_adjacency_equals_host_qhull(eng):
     assert np.array_equal(d_dev, d_host)
 
 
+@pytest.mark.parametrize("small_plan", [0, 1])
 @pytest.mark.parametrize("n", [600000, 250000])
-def test_knn_bf16_path_two_levels_unit_vectors(eng, n):
+def test_knn_bf16_path_two_levels_unit_vectors(eng, n, small_plan):
     """Two filter levels (strides 256, 16, 1); unit-norm 128-d rows like the PCA'd descriptors.  600 000 rows: the
     sample of 2343 rows admits 8.5 % of the next level; 250 000 rows (the 1 M-row database on 4 GPUs): the level plan's
     smallest sample for k = 200, 976 rows, admits 20.5 % -- just below the filter's per-wave list capacity.
-    The fp16 and the bf16x3 filters (+ fp32 refinement) must reproduce the all-fp32 path bit for bit."""
+    The fp16 and the bf16x3 filters (+ fp32 refinement) must reproduce the all-fp32 path bit for bit.
+    small_plan = 1 (the default for <= 128 queries): ONE filter level behind a 2048..4096-row sample (strides 256 / 64),
+    lists ranked by the workgroup-per-list select, refinement lists shared by workgroups -- same bits again."""
     import torch
 
     g = torch.Generator(device=eng.device)
@@ -658,9 +661,12 @@ def test_knn_bf16_path_two_levels_unit_vectors(eng, n):
                                       0.3 * torch.randn(nq, d, device=eng.device, generator=g) / d ** 0.5, dim=1)
     eng.db_reset()
     eng.db_add(R)
-    d2, idx = eng.search(Q, k)                 # default: fp16 single-product filter
-    assert eng.search_stats()["filter"] == "f16" and eng.search_stats()["levels"] == 2
+    eng.set_option("small_plan", small_plan)
     try:
+        d2, idx = eng.search(Q, k)                 # default: fp16 single-product filter
+        st = eng.search_stats()
+        assert st["filter"] == "f16" and st["levels"] == (1 if small_plan else 2)
+        assert st["n_fallback"] == 0
         eng.set_option("knn_filter", "fp32")       # same levels, fp32 filter GEMM
         d2f, idxf = eng.search(Q, k)
         assert eng.search_stats()["filter"] == "fp32"
@@ -669,6 +675,7 @@ def test_knn_bf16_path_two_levels_unit_vectors(eng, n):
         assert eng.search_stats()["filter"] == "bf16x3"
     finally:
         eng.set_option("knn_filter", "auto")
+        eng.set_option("small_plan", 1)
     assert torch.equal(idx, idxf) and torch.equal(d2, d2f)
     assert torch.equal(idxb, idxf) and torch.equal(d2b, d2f)
     # and against the oracle on a slice of the queries

@@ -1,5 +1,6 @@
 """One 50-segment query image per pass over a 1 M x 1024 index: per-stage times (HIP events) and -- under
-rocprofv3 --kernel-trace --stats -- the per-kernel durations of the pass.   python tools/probe_stream.py [reps]"""
+rocprofv3 --kernel-trace --stats -- the per-kernel durations of the pass.   python tools/probe_stream.py [reps] [key=value ...]
+(key=value: segvlad_set_option switches, e.g. small_plan=0 for the deep level plan of the batches)"""
 import os
 import sys
 
@@ -11,6 +12,8 @@ from revisit_anything_amd.engine import SegVLADEngine  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 dev = torch.device("cuda:0")
 eng = SegVLADEngine(0)
+for kv in sys.argv[2:]:
+    eng.set_option(*kv.split("=", 1))
 g = torch.Generator(device=dev)
 g.manual_seed(1)
 n, d, k = 1_000_000, 1024, 200
