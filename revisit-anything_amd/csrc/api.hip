@@ -215,7 +215,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
                     &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys, &ctx->s_pz, &ctx->s_rowbase,
                     &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part, &ctx->s_rovf,   &ctx->s_ref_lim,
-                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc, &ctx->s_ref_keys, &ctx->s_ref_tick};
+                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc, &ctx->s_ref_keys, &ctx->s_ref_tick, &ctx->db_sample, &ctx->db_sample_norms, &ctx->s_qscale};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -754,6 +754,7 @@ int segvlad_db_reset(segvlad_ctx* ctx) {
   ctx->db_rn_max = 0.f;
   ctx->db_rn_max_rows = 0;
   ctx->db_heur_off = false;
+  ctx->db_sample_n = -1;
   return SEGVLAD_OK;
 }
 
@@ -766,6 +767,7 @@ int segvlad_db_add(segvlad_ctx* ctx, const float* R, int n, int d, const int32_t
   if (n == 0) return SEGVLAD_OK;
   if (!R) return ctx->fail(SEGVLAD_ERR_ARG, "db_add: null rows");
   const int64_t n_new = ctx->db_n + n;
+  ctx->db_sample_n = -1;
   // grow (keeping old contents)
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
     if (new_bytes <= b.cap) return hipSuccess;
@@ -855,6 +857,14 @@ __global__ __launch_bounds__(256) void scatter_topk_kernel(const float* __restri
   }
 }
 
+// every stride-th row (and its norm) into a dense block
+__global__ __launch_bounds__(256) void gather_strided_kernel(const float* __restrict__ X, const float* __restrict__ xn, int64_t stride,
+                                                             int d, float* __restrict__ Y, float* __restrict__ yn) {
+  const int64_t r = blockIdx.x, src = r * stride;
+  for (int j = threadIdx.x; j < d; j += 256) Y[r * d + j] = X[src * d + j];
+  if (threadIdx.x == 0) yn[r] = xn[src];
+}
+
 // ---- the level scheme ---------------------------------------------------------------------------------------------
 struct SearchPlan {
   int levels = 0;          // filter levels after the sampled exact level
@@ -863,6 +873,8 @@ struct SearchPlan {
   int d = 0, k = 0;
   int64_t n = 0;
   float c_eps = 0.f, inv_scale = 1.f, rn_max = 0.f;
+  const float* sample = nullptr;        // dense copy of the exact level's sample rows (single-image plans), else null
+  const float* sample_norms = nullptr;
   int ratio = 16;          // sample growth per level (SV_RATIO; 256 for the one-filter-level plan of a single query image)
 };
 constexpr int SV_RATIO = 16, SV_CAP = 8192, SV_RCAP = 512, SV_CHUNK = 16384;
@@ -898,10 +910,12 @@ static int heur_rank_small(int target, int ratio) {
 //              smallest approximate distance A_k exceeds the threshold T it was collected under (then {d2~ <= A_k + 2 eps}
 //              might not be contained in the collected {d2~ <= T + 2 eps}), flags the query; flagged queries are redone
 //              with the rigorous thresholds.  Exactness never depends on the ranks; they only decide how often the redo runs.
-// q16a / q16b: this chunk's 16-bit query planes (f16: plane, unused; bf16x3: hi, lo).  fail_rows [m] / fail_count: flags.
+// q16a / q16b: this chunk's 16-bit query planes (f16: plane, unused; bf16x3: hi, lo).  fail_rows [m]: flags;
+// fail_count[0] / fail_count[1]: running counts of the flagged rows and of the second-tier rows (adjacent: ONE read-back per
+// chunk); rovf_rows_in [m]: second-tier flags, zero on entry; n_rovf_seen: the caller's copy of fail_count[1] so far.
 static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, const float* qp, const uint16_t* q16a,
                         const uint16_t* q16b, const float* qn, int m, float* out_d2, int64_t* out_idx, uint32_t* fail_rows,
-                        uint32_t* fail_count, uint32_t* n_fail_host) {
+                        uint32_t* fail_count, uint32_t* rovf_rows_in, uint32_t* n_fail_host, uint32_t* n_rovf_seen) {
   const int d = pl.d, k = pl.k, levels = pl.levels;
   const int64_t n = pl.n;
   const float* R = ctx->db_rows.as<float>();
@@ -916,19 +930,22 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   float* thr = ctx->s_thr_d2.as<float>();
   // second refinement tier (filters with an approximate domain only): [m] row flags + 1 count, [m] band limits
   uint32_t* rovf_rows = nullptr;
+  uint32_t* rovf_count = fail_count + 1;
   float* ref_lim = nullptr;
   if (pl.kind != 3) {
-    SV_HIP(ctx->s_rovf.reserve(((size_t)m + 1) * 4));
     SV_HIP(ctx->s_ref_lim.reserve((size_t)m * 4));
-    SV_HIP(hipMemsetAsync(ctx->s_rovf.p, 0, ((size_t)m + 1) * 4, ctx->stream));
-    rovf_rows = ctx->s_rovf.as<uint32_t>();
+    rovf_rows = rovf_rows_in;
     ref_lim = ctx->s_ref_lim.as<float>();
   }
   const int r0 = rank[0];
   {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
       StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
-      SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
+      if (pl.sample)   // the sample's rows side by side: 16 MB that stay in the last-level cache from pass to pass, instead of
+                       // 3906 rows a megabyte apart (22 us of TLB misses and DRAM latency for 0.2 GFLOP)
+        SV_TRY(sv_launch_l2_strided(ctx, qp, pl.sample, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, pl.sample_norms, 1, true));
+      else
+        SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
       sc.count();
     }
     StageScope sc(ctx, "knn_select");
@@ -995,7 +1012,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
         SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
                                        SV_CAP, rank[lv], last ? 1 : 0, heuristic ? 1 : 0, thr_ptr, thr_ld, qn, pl.c_eps, pl.rn_max, thr,
                                        ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count,
-                                       rovf_rows, rovf_rows + m, ref_lim));
+                                       rovf_rows, rovf_count, ref_lim));
         sc.count();
         if (last) {
           SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP,
@@ -1008,10 +1025,12 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
         // refine band outgrew the first-tier list.  The latter are refined here, straight from their candidate lists,
         // which the next chunk would overwrite.
         uint32_t h_cnt[2] = {0, 0};
-        SV_HIP(hipMemcpyAsync(&h_cnt[0], fail_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-        SV_HIP(hipMemcpyAsync(&h_cnt[1], rovf_rows + m, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SV_HIP(hipMemcpyAsync(&h_cnt[0], fail_count, 8, hipMemcpyDeviceToHost, ctx->stream));
         SV_HIP(hipStreamSynchronize(ctx->stream));
         if (n_fail_host) *n_fail_host = h_cnt[0];
+        const uint32_t seen = n_rovf_seen ? *n_rovf_seen : 0u;
+        if (n_rovf_seen) *n_rovf_seen = h_cnt[1];
+        h_cnt[1] -= seen;   // the second-tier rows of THIS chunk
         if (h_cnt[1]) {
           StageScope sc(ctx, "knn_select");
           SV_TRY(sv_launch_refine2_compact(ctx, rovf_rows, ref_lim, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
@@ -1105,6 +1124,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   if (ctx->db_d == 0) return ctx->fail(SEGVLAD_ERR_STATE, "search: the index is empty and has no dimension yet");
   const int d = ctx->db_d;
   const int64_t n = ctx->db_n;
+  ctx->f16_scale_dev = nullptr;
   const void* dq;
   void *dd2, *didx;
   SV_TRY(sv_in(ctx, Q, (size_t)nq * d * 4, &dq));
@@ -1168,6 +1188,18 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     plh.levels = 1;
     plh.stride0 = small_stride;
     plh.ratio = small_stride;
+    const int64_t ns = (n + small_stride - 1) / small_stride;
+    if (ctx->db_sample_n != ns || ctx->db_sample_stride != small_stride) {
+      SV_HIP(ctx->db_sample.reserve((size_t)ns * d * 4));
+      SV_HIP(ctx->db_sample_norms.reserve((size_t)ns * 4));
+      hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)ns), dim3(256), 0, ctx->stream, ctx->db_rows.as<float>(),
+                         ctx->db_norms.as<float>(), (int64_t)small_stride, d, ctx->db_sample.as<float>(), ctx->db_sample_norms.as<float>());
+      SV_HIP(hipGetLastError());
+      ctx->db_sample_n = ns;
+      ctx->db_sample_stride = small_stride;
+    }
+    plh.sample = ctx->db_sample.as<float>();
+    plh.sample_norms = ctx->db_sample_norms.as<float>();
   } else if (heuristic) {
     while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
       plh.stride0 *= SV_RATIO;
@@ -1226,12 +1258,22 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       SV_TRY(sv_launch_to_f16(ctx, R + (size_t)r0 * d, (n - r0) * d, ctx->db_f16_scale, ctx->db_f16.as<uint16_t>() + (size_t)r0 * d));
       ctx->db_f16_rows = n;
     }
-    float qmax = 0.f;
-    SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
-    qscale = pow2_scale(qmax);
     SV_HIP(ctx->s_qf16.reserve((size_t)nq * d * 2));
-    SV_TRY(sv_launch_to_f16(ctx, (const float*)dq, (int64_t)nq * d, qscale, ctx->s_qf16.as<uint16_t>()));
-    pl.inv_scale = 1.f / (qscale * ctx->db_f16_scale);
+    if (nq <= 128 && (((int64_t)nq * d) & 3) == 0) {
+      // one query image per pass: the scale is computed AND consumed on the device (a host round trip in front of every pass
+      // was ~45 us of a ~600 us call)
+      SV_HIP(ctx->s_qscale.reserve(16));
+      SV_TRY(sv_launch_query_f16_small(ctx, (const float*)dq, (int64_t)nq * d, ctx->db_f16_scale, ctx->s_qf16.as<uint16_t>(),
+                                       ctx->s_qscale.as<float>()));
+      ctx->f16_scale_dev = ctx->s_qscale.as<float>();
+      pl.inv_scale = 0.f;   // (unused: the kernels read s_qscale[1])
+    } else {
+      float qmax = 0.f;
+      SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
+      qscale = pow2_scale(qmax);
+      SV_TRY(sv_launch_to_f16(ctx, (const float*)dq, (int64_t)nq * d, qscale, ctx->s_qf16.as<uint16_t>()));
+      pl.inv_scale = 1.f / (qscale * ctx->db_f16_scale);
+    }
     // |d2~ - d2| <= c_eps ||q|| ||r||: ctx.h, sv_f16_c_eps (the constant of the kernel variant that will run).  Batches
     // (> 128 queries, default configuration) take the biased-accumulator kernel when the norms are balanced enough for
     // its margin: bias_mult = 1 + max||r|| / (2 min||q||), 1.5 for unit vectors
@@ -1277,20 +1319,25 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   plh.c_eps = pl.c_eps;
   plh.inv_scale = pl.inv_scale;
   plh.rn_max = pl.rn_max;
-  SV_HIP(ctx->s_ovf.reserve(((size_t)nq + 1) * 4));
-  SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ((size_t)nq + 1) * 4, ctx->stream));
+  // layout: [nq] row flags, 2 counts (flagged, second-tier), [mrows] second-tier flags of the current chunk -- one memset
+  const size_t ovf_bytes = (((size_t)nq + 2 + mrows) * 4 + 255) & ~(size_t)255;   // (a whole number of 256-byte blocks: one fill kernel)
+  SV_HIP(ctx->s_ovf.reserve(ovf_bytes));
+  SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ovf_bytes, ctx->stream));
   uint32_t* flag_rows = ctx->s_ovf.as<uint32_t>();
   uint32_t* flag_count = flag_rows + nq;
+  uint32_t* rovf_flags = flag_count + 2;
+  uint32_t n_rovf_seen = 0;
   auto plane_a = [&](const DevBuf& f16, const DevBuf& hi, int64_t q0) -> const uint16_t* {
     return (pl.kind == 1 ? reinterpret_cast<const uint16_t*>(f16.p) : reinterpret_cast<const uint16_t*>(hi.p)) + (size_t)q0 * d;
   };
   uint32_t n_flag = 0;   // running count of the flagged rows, read back by every chunk (levels_chunk synchronises once)
   for (int q0 = 0; q0 < nq; q0 += SV_CHUNK) {
     const int m = (nq - q0 < SV_CHUNK) ? (nq - q0) : SV_CHUNK;
+    if (q0) SV_HIP(hipMemsetAsync(rovf_flags, 0, (size_t)m * 4, ctx->stream));
     SV_TRY(levels_chunk(ctx, heuristic ? plh : pl, heuristic, (const float*)dq + (size_t)q0 * d,
                         pl.kind == 3 ? nullptr : plane_a(ctx->s_qf16, ctx->s_qh, q0),
                         pl.kind == 2 ? ctx->s_ql.as<uint16_t>() + (size_t)q0 * d : nullptr, qn + q0, m, (float*)dd2 + (size_t)q0 * k,
-                        (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count, &n_flag));
+                        (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count, rovf_flags, &n_flag, &n_rovf_seen));
   }
   if (n_flag && !heuristic) {
     int nf = 0;
@@ -1310,8 +1357,9 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_HIP(ctx->s_rd_q.reserve((size_t)nr * ((size_t)d + 1) * 4));
     SV_HIP(ctx->s_rd_d2.reserve((size_t)nr * k * 4));
     SV_HIP(ctx->s_rd_idx.reserve((size_t)nr * k * 8));
-    SV_HIP(ctx->s_rd_flags.reserve(((size_t)nr + 1) * 4));
-    SV_HIP(hipMemsetAsync(ctx->s_rd_flags.p, 0, ((size_t)nr + 1) * 4, ctx->stream));
+    const size_t rd_m = (size_t)std::min(nr, SV_CHUNK);
+    SV_HIP(ctx->s_rd_flags.reserve(((size_t)nr + 2 + rd_m) * 4));   // (same layout as s_ovf)
+    SV_HIP(hipMemsetAsync(ctx->s_rd_flags.p, 0, ((size_t)nr + 2 + rd_m) * 4, ctx->stream));
     SV_HIP(hipMemcpyAsync(ctx->s_rd_rows.p, rows.data(), (size_t)nr * 4, hipMemcpyHostToDevice, ctx->stream));
     float* rq = ctx->s_rd_q.as<float>();
     float* rqn = rq + (size_t)nr * d;
@@ -1320,21 +1368,25 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_HIP(hipGetLastError());
     SV_HIP(ctx->s_rd_p1.reserve((size_t)nr * d * 2));
     if (pl.kind == 1) {
-      SV_TRY(sv_launch_to_f16(ctx, rq, (int64_t)nr * d, qscale, ctx->s_rd_p1.as<uint16_t>()));   // same scale as the main pass
+      if (ctx->f16_scale_dev)   // same scale as the main pass
+        SV_TRY(sv_launch_to_f16_devscale(ctx, rq, (int64_t)nr * d, ctx->f16_scale_dev, ctx->s_rd_p1.as<uint16_t>()));
+      else
+        SV_TRY(sv_launch_to_f16(ctx, rq, (int64_t)nr * d, qscale, ctx->s_rd_p1.as<uint16_t>()));
     } else {
       SV_HIP(ctx->s_rd_p2.reserve((size_t)nr * d * 2));
       SV_TRY(sv_launch_split_bf16(ctx, rq, (int64_t)nr * d, ctx->s_rd_p1.as<uint16_t>(), ctx->s_rd_p2.as<uint16_t>()));
     }
     uint32_t* rflags = ctx->s_rd_flags.as<uint32_t>();
-    uint32_t n_ovf = 0;
+    uint32_t n_ovf = 0, rd_rovf_seen = 0;
     for (int q0 = 0; q0 < nr; q0 += SV_CHUNK) {
       const int m = (nr - q0 < SV_CHUNK) ? (nr - q0) : SV_CHUNK;
+      if (q0) SV_HIP(hipMemsetAsync(rflags + nr + 2, 0, (size_t)m * 4, ctx->stream));
       StageScope sc(ctx, "knn_redo");   // the whole redo is ONE stage: its inner level / filter / select scopes are muted,
       ctx->scope_mute = true;           // so "knn_gemm" etc. keep describing the main pass only (no double counting)
       const int rc = levels_chunk(ctx, pl, false, rq + (size_t)q0 * d, ctx->s_rd_p1.as<uint16_t>() + (size_t)q0 * d,
                                   pl.kind == 2 ? ctx->s_rd_p2.as<uint16_t>() + (size_t)q0 * d : nullptr, rqn + q0, m,
                                   ctx->s_rd_d2.as<float>() + (size_t)q0 * k, ctx->s_rd_idx.as<int64_t>() + (size_t)q0 * k, rflags + q0,
-                                  rflags + nr, &n_ovf);
+                                  rflags + nr, rflags + nr + 2, &n_ovf, &rd_rovf_seen);
       ctx->scope_mute = false;
       SV_TRY(rc);
       sc.count(m);

@@ -183,12 +183,17 @@ struct segvlad_ctx {
   float db_rn_max = 0.f;
   int64_t db_rn_max_rows = 0;
   bool f16_bias_ok = false;   // this search's batch filter launches may use the biased-accumulator kernel (segvlad_search)
+  // dense copy of the exact level's strided sample of a single-image plan (rows 0, s, 2 s, ... + their norms): [sample_n][d];
+  // rebuilt when the index or the stride changed (db_add / db_reset set db_sample_n = -1)
+  int64_t db_sample_n = -1;
+  int db_sample_stride = 0;
+  const float* f16_scale_dev = nullptr;   // set by segvlad_search for the duration of a single-image search (see above)
   bool db_heur_off = false;   // set when > 25 % of a search's queries needed the rigorous redo (until the index changes)
 
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id, s_ref_keys, s_ref_tick, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
+      s_qh, s_ql, s_ref_cnt, s_ref_id, s_ref_keys, s_ref_tick, db_sample, db_sample_norms, s_qscale, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
       s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part,
       s_rovf, s_ref_lim;
   // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time, the exchange buffers
@@ -316,6 +321,10 @@ int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* w
                                 const uint64_t* colmask, const int32_t* lab_off, const int32_t* rowbase, const int32_t* seg_off_dev,
                                 int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y);
 int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out);
+// single-image searches: the query plane and its scales without a host round trip (scales_dev[0] = query scale,
+// [1] = 1 / (query scale x db_scale)); ctx->f16_scale_dev != null makes the filter kernel read [1] instead of its argument
+int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev);
+int sv_launch_to_f16_devscale(segvlad_ctx* ctx, const float* X, int64_t n_elems, const float* scales_dev, uint16_t* out);
 int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,
                          float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap);

@@ -327,6 +327,83 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float* __restrict__ X
   }
 }
 
+// A handful of query rows (<= 128 x d floats): largest magnitude, the power-of-two scale that puts it in [8192, 16384) --
+// the host's pow2_scale, bit for bit -- and the fp16 plane, in ONE workgroup and one launch; the scales stay on the device
+// (scales[0] = query scale, scales[1] = 1 / (query scale x db_scale)): no memset, no atomics, no host round trip.
+__global__ __launch_bounds__(1024) void query_f16_small_kernel(const float* __restrict__ X, int64_t n4, float db_scale,
+                                                               _Float16* __restrict__ out, float* __restrict__ scales) {
+  __shared__ uint32_t wmax[16];
+  __shared__ float s_scale;
+  const int tid = threadIdx.x;
+  uint32_t m = 0;
+  for (int64_t j = tid; j < n4; j += 1024) {
+    const float4 v = reinterpret_cast<const float4*>(X)[j];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, __float_as_uint(v.z) & 0x7fffffffu));
+    m = max(m, __float_as_uint(v.w) & 0x7fffffffu);
+  }
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((tid & 63) == 0) wmax[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) m = max(m, wmax[w]);
+    const float maxabs = __uint_as_float(m);
+    float scale = 1.f;
+    if (maxabs > 0.f && isfinite(maxabs)) {
+      int e;
+      frexpf(maxabs, &e);
+      scale = ldexpf(1.f, 14 - e);
+    }
+    s_scale = scale;
+    scales[0] = scale;
+    scales[1] = 1.f / (scale * db_scale);
+  }
+  __syncthreads();
+  const float scale = s_scale;
+  for (int64_t j = tid; j < n4; j += 1024) {
+    const float4 v = reinterpret_cast<const float4*>(X)[j];
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h;
+    h[0] = (_Float16)(v.x * scale);
+    h[1] = (_Float16)(v.y * scale);
+    h[2] = (_Float16)(v.z * scale);
+    h[3] = (_Float16)(v.w * scale);
+    reinterpret_cast<h4*>(out)[j] = h;
+  }
+}
+
+int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev) {
+  hipLaunchKernelGGL(query_f16_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, X, n_elems / 4, db_scale,
+                     reinterpret_cast<_Float16*>(out), scales_dev);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
+__global__ __launch_bounds__(256) void to_f16_devscale_kernel(const float* __restrict__ X, int64_t n4, const float* __restrict__ scales,
+                                                              _Float16* __restrict__ out) {
+  const float scale = scales[0];
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(X)[j];
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h;
+    h[0] = (_Float16)(v.x * scale);
+    h[1] = (_Float16)(v.y * scale);
+    h[2] = (_Float16)(v.z * scale);
+    h[3] = (_Float16)(v.w * scale);
+    reinterpret_cast<h4*>(out)[j] = h;
+  }
+}
+
+int sv_launch_to_f16_devscale(segvlad_ctx* ctx, const float* X, int64_t n_elems, const float* scales_dev, uint16_t* out) {
+  if (n_elems <= 0) return SEGVLAD_OK;
+  const int64_t n4 = n_elems / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(to_f16_devscale_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, X, n4, scales_dev,
+                     reinterpret_cast<_Float16*>(out));
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
 int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out) {
   if (n_elems <= 0) return SEGVLAD_OK;
   const int64_t n4 = n_elems / 4;
@@ -401,7 +478,10 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     int seq_total,
     float inv_scale, const float* __restrict__ qn, const float* __restrict__ rn, const float* __restrict__ thr,
     int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* __restrict__ cand_cnt,
-    float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap) {
+    float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap, const float* __restrict__ inv_scale_dev) {
+  // single-image searches leave the query scale on the device (no host round trip in front of the pass): [0] = scale,
+  // [1] = 1 / (query scale x database scale)
+  if (inv_scale_dev) inv_scale = inv_scale_dev[1];
   constexpr int NW = WM * WN;
   constexpr int AUXA = (POL & 2) ? 2 : 0, AUXB = (POL & 1) ? 2 : 0;   // aux = 2: "nt" (streaming) hint
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -1063,7 +1143,8 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
-                     gm, seq_total, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap);
+                     gm, seq_total, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap,
+                     ctx->f16_scale_dev);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -1467,51 +1548,12 @@ __device__ __forceinline__ void select_small_body(const float* __restrict__ cd2,
   }
 }
 
-// One query image per pass (<= 128 lists): a whole workgroup per list instead of a wave -- 32 keys per thread (lists of up
-// to 8192 entries, the capacity of the candidate lists; longer ones are flagged for the exact path), the same
-// binary MSB-first radix select below the common prefix of the list's smallest and largest key, stopping when one key is
-// left; the per-bit count is a DPP wave sum + a four-entry LDS exchange (one barrier per bit: the exchange slots alternate).
-// The wave kernel's 64-keys-per-lane instantiation is ~8000 straight-line instructions that a pass runs through ONCE --
-// instruction fetch, not arithmetic: 29 us for a 3906-entry sample row; this kernel takes ~10.
-__global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
-                                                        const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
-                                                        const float* __restrict__ thr_in, int64_t thr_in_ld,
-                                                        const float* __restrict__ qn, float c_eps, float rn_max,
-                                                        float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
-                                                        uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
-                                                        uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
-                                                        uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt) {
+// k-th smallest of a workgroup's keys (PER per thread, padding = all ones), c >= 1 real keys among them; +inf if c < k.
+// xs: [2][4] LDS exchange slots.  Every thread returns the same value.
+template <int PER>
+__device__ __forceinline__ float wg_kth_smallest_(const uint32_t (&key)[PER], uint32_t c, int k, uint32_t (*xs)[4], int tid) {
   constexpr uint32_t PAD = 0xffffffffu;
-  constexpr int PER = 32;   // 8192 keys: the candidate lists' capacity (SV_CAP)
-  __shared__ uint32_t xs[2][4];
-  __shared__ uint32_t s_n;
-  const int tid = threadIdx.x, w = tid >> 6;
-  const int64_t row = blockIdx.x;
-  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];
-  const uint32_t flagged = ovf_rows[row];
-  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
-  uint32_t key[PER], cidv[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int j = tid + 256 * i;
-    key[i] = PAD;
-    cidv[i] = 0u;
-    if (j < (int)c && c <= (uint32_t)(256 * PER)) {
-      key[i] = f2key_(cd2[row * cap + j]);
-      if (mode == 1) cidv[i] = cid[row * cap + j];
-    }
-  }
-  if (tid == 0) s_n = 0u;
-  __syncthreads();   // every thread has read cnt[row]
-  if (tid == 0 && mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero
-  if (c > (uint32_t)cap || c > (uint32_t)(256 * PER) || flagged || (check && (int)c < k)) {
-    if (tid == 0) {
-      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
-      if (mode == 1) ref_cnt[row] = 0;
-      else thr_out[row] = -INFINITY;
-    }
-    return;
-  }
+  const int w = tid >> 6;
   int turn = 0;
   auto exchange = [&](uint32_t v_wave) {   // v_wave: this wave's (uniform) partial; returns the four partials
     if ((tid & 63) == 0) xs[turn][w] = v_wave;
@@ -1569,6 +1611,55 @@ __global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ c
     }
     ak = key2f_(prefix);
   }
+  return ak;
+}
+
+// One query image per pass (<= 128 lists): a whole workgroup per list instead of a wave -- 32 keys per thread (lists of up
+// to 8192 entries, the capacity of the candidate lists; longer ones are flagged for the exact path), the same
+// binary MSB-first radix select below the common prefix of the list's smallest and largest key, stopping when one key is
+// left; the per-bit count is a DPP wave sum + a four-entry LDS exchange (one barrier per bit: the exchange slots alternate).
+// The wave kernel's 64-keys-per-lane instantiation is ~8000 straight-line instructions that a pass runs through ONCE --
+// instruction fetch, not arithmetic: 29 us for a 3906-entry sample row; this kernel takes ~10.
+__global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+                                                        const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
+                                                        const float* __restrict__ thr_in, int64_t thr_in_ld,
+                                                        const float* __restrict__ qn, float c_eps, float rn_max,
+                                                        float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
+                                                        uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
+                                                        uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
+                                                        uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt) {
+  constexpr uint32_t PAD = 0xffffffffu;
+  constexpr int PER = 32;   // 8192 keys: the candidate lists' capacity (SV_CAP)
+  __shared__ uint32_t xs[2][4];
+  __shared__ uint32_t s_n;
+  const int tid = threadIdx.x, w = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];
+  const uint32_t flagged = ovf_rows[row];
+  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  uint32_t key[PER], cidv[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int j = tid + 256 * i;
+    key[i] = PAD;
+    cidv[i] = 0u;
+    if (j < (int)c && c <= (uint32_t)(256 * PER)) {
+      key[i] = f2key_(cd2[row * cap + j]);
+      if (mode == 1) cidv[i] = cid[row * cap + j];
+    }
+  }
+  if (tid == 0) s_n = 0u;
+  __syncthreads();   // every thread has read cnt[row]
+  if (tid == 0 && mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero
+  if (c > (uint32_t)cap || c > (uint32_t)(256 * PER) || flagged || (check && (int)c < k)) {
+    if (tid == 0) {
+      if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
+      if (mode == 1) ref_cnt[row] = 0;
+      else thr_out[row] = -INFINITY;
+    }
+    return;
+  }
+  const float ak = wg_kth_smallest_<PER>(key, c, k, xs, tid);
   if (mode == 0) {
     if (tid == 0) thr_out[row] = ak;
     return;
