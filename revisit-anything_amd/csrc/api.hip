@@ -215,7 +215,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
                     &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
                     &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys, &ctx->s_pz, &ctx->s_rowbase,
                     &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part, &ctx->s_rovf,   &ctx->s_ref_lim,
-                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc, &ctx->s_ref_keys, &ctx->s_ref_tick, &ctx->db_sample, &ctx->db_sample_norms, &ctx->s_qscale};
+                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc, &ctx->s_ref_keys, &ctx->s_ref_tick, &ctx->s_qscale};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : ctx->stage) b.release();
   for (auto& kv : ctx->timers)
@@ -754,7 +754,6 @@ int segvlad_db_reset(segvlad_ctx* ctx) {
   ctx->db_rn_max = 0.f;
   ctx->db_rn_max_rows = 0;
   ctx->db_heur_off = false;
-  ctx->db_sample_n = -1;
   return SEGVLAD_OK;
 }
 
@@ -767,7 +766,6 @@ int segvlad_db_add(segvlad_ctx* ctx, const float* R, int n, int d, const int32_t
   if (n == 0) return SEGVLAD_OK;
   if (!R) return ctx->fail(SEGVLAD_ERR_ARG, "db_add: null rows");
   const int64_t n_new = ctx->db_n + n;
-  ctx->db_sample_n = -1;
   // grow (keeping old contents)
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
     if (new_bytes <= b.cap) return hipSuccess;
@@ -857,14 +855,6 @@ __global__ __launch_bounds__(256) void scatter_topk_kernel(const float* __restri
   }
 }
 
-// every stride-th row (and its norm) into a dense block
-__global__ __launch_bounds__(256) void gather_strided_kernel(const float* __restrict__ X, const float* __restrict__ xn, int64_t stride,
-                                                             int d, float* __restrict__ Y, float* __restrict__ yn) {
-  const int64_t r = blockIdx.x, src = r * stride;
-  for (int j = threadIdx.x; j < d; j += 256) Y[r * d + j] = X[src * d + j];
-  if (threadIdx.x == 0) yn[r] = xn[src];
-}
-
 // ---- the level scheme ---------------------------------------------------------------------------------------------
 struct SearchPlan {
   int levels = 0;          // filter levels after the sampled exact level
@@ -873,8 +863,6 @@ struct SearchPlan {
   int d = 0, k = 0;
   int64_t n = 0;
   float c_eps = 0.f, inv_scale = 1.f, rn_max = 0.f;
-  const float* sample = nullptr;        // dense copy of the exact level's sample rows (single-image plans), else null
-  const float* sample_norms = nullptr;
   int ratio = 16;          // sample growth per level (SV_RATIO; 256 for the one-filter-level plan of a single query image)
 };
 constexpr int SV_RATIO = 16, SV_CAP = 8192, SV_RCAP = 512, SV_CHUNK = 16384;
@@ -941,11 +929,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
       StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
-      if (pl.sample)   // the sample's rows side by side: 16 MB that stay in the last-level cache from pass to pass, instead of
-                       // 3906 rows a megabyte apart (22 us of TLB misses and DRAM latency for 0.2 GFLOP)
-        SV_TRY(sv_launch_l2_strided(ctx, qp, pl.sample, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, pl.sample_norms, 1, true));
-      else
-        SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
+      SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
       sc.count();
     }
     StageScope sc(ctx, "knn_select");
@@ -1188,18 +1172,6 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     plh.levels = 1;
     plh.stride0 = small_stride;
     plh.ratio = small_stride;
-    const int64_t ns = (n + small_stride - 1) / small_stride;
-    if (ctx->db_sample_n != ns || ctx->db_sample_stride != small_stride) {
-      SV_HIP(ctx->db_sample.reserve((size_t)ns * d * 4));
-      SV_HIP(ctx->db_sample_norms.reserve((size_t)ns * 4));
-      hipLaunchKernelGGL(gather_strided_kernel, dim3((unsigned)ns), dim3(256), 0, ctx->stream, ctx->db_rows.as<float>(),
-                         ctx->db_norms.as<float>(), (int64_t)small_stride, d, ctx->db_sample.as<float>(), ctx->db_sample_norms.as<float>());
-      SV_HIP(hipGetLastError());
-      ctx->db_sample_n = ns;
-      ctx->db_sample_stride = small_stride;
-    }
-    plh.sample = ctx->db_sample.as<float>();
-    plh.sample_norms = ctx->db_sample_norms.as<float>();
   } else if (heuristic) {
     while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
       plh.stride0 *= SV_RATIO;

@@ -183,17 +183,13 @@ struct segvlad_ctx {
   float db_rn_max = 0.f;
   int64_t db_rn_max_rows = 0;
   bool f16_bias_ok = false;   // this search's batch filter launches may use the biased-accumulator kernel (segvlad_search)
-  // dense copy of the exact level's strided sample of a single-image plan (rows 0, s, 2 s, ... + their norms): [sample_n][d];
-  // rebuilt when the index or the stride changed (db_add / db_reset set db_sample_n = -1)
-  int64_t db_sample_n = -1;
-  int db_sample_stride = 0;
   const float* f16_scale_dev = nullptr;   // set by segvlad_search for the duration of a single-image search (see above)
   bool db_heur_off = false;   // set when > 25 % of a search's queries needed the rigorous redo (until the index changes)
 
   // scratch (grow-only, reused across calls)
   DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id, s_ref_keys, s_ref_tick, db_sample, db_sample_norms, s_qscale, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
+      s_qh, s_ql, s_ref_cnt, s_ref_id, s_ref_keys, s_ref_tick, s_qscale, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
       s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part,
       s_rovf, s_ref_lim;
   // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time, the exchange buffers
