@@ -208,6 +208,11 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *                                                      image can therefore come out ~1e-5 relative apart in two batches
  *                                                      of different size -- fix the form when runs must be comparable
  *                                                      digit for digit (bench.py does)
+ *        "small_plan"    1 | 0                         searches of <= 128 query rows (ONE query image per pass: the
+ *                                                      HBM-bound regime of SURVEY 8d) take their own plan -- one filter
+ *                                                      level behind an exact sample of 2048..4096 rows, a workgroup per
+ *                                                      list in the selects, refinement lists shared by workgroups, the
+ *                                                      query scale left on the device | the plan of the batches
  *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning   */
 int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
 
