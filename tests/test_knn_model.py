@@ -127,3 +127,49 @@ def test_two_term_fp16_split_projection_is_fp32_class():
     e16 = np.abs((a1 @ b1.T) / (sx * sw) - ref).max() / scale       # single fp16 product, for contrast
     assert e3 < 2e-6 and e3 < 8 * e32 + 1e-7, (e3, e32)
     assert e16 > 20 * e3                                             # one product alone is fp16-class
+
+
+def heur_rank_small(target, ratio):
+    """csrc/api.hip: heur_rank_small -- the smallest r >= 2 with P[Gamma(r, 1) < target / ratio] < 2e-5."""
+    import math
+
+    x = target / ratio
+    ex, term, acc = math.exp(-x), 1.0, 0.0
+    for r in range(1, target):
+        acc += term
+        term *= x / r
+        if r >= 2 and 1.0 - ex * acc < 2e-5:
+            return r
+    return target
+
+
+def test_single_image_plan_low_rank_threshold_rule():
+    """One filter level behind a 1/stride exact sample (the single-image plan): the threshold is the r-th smallest sample
+    distance; the full set then holds ~ stride * Gamma(r) rows below it.  The rule must (a) leave fewer than k rows below the
+    threshold only very rarely (that query is redone, never wrong), (b) keep the expected list far below the 8192-entry
+    lists.  Checked against the order-statistics model AND by simulation on uniform 'distances' (any continuous distribution
+    gives the same counts: they depend on ranks only)."""
+    from scipy import stats
+
+    for k, stride in ((200, 256), (200, 64), (200, 32), (50, 256), (20, 512)):
+        r = heur_rank_small(k, stride)
+        assert 2 <= r <= k
+        # (a) model: the fraction below the r-th of an s-row sample is Beta(r, s - r + 1) ~ Gamma(r) / s
+        assert stats.gamma.cdf(k / stride, r) < 2e-5
+        assert r == 2 or stats.gamma.cdf(k / stride, r - 1) >= 2e-5          # and r is the smallest such rank
+        # (b) expected list length ~ stride * r rows (+ the margin's band, which the GPU tests measure)
+        assert stride * r < 4096
+    # simulation at the bench's shape: 1 M rows, stride 256, k = 200
+    rng = np.random.Generator(np.random.PCG64(11))
+    n, stride, k = 1_000_000, 256, 200
+    r = heur_rank_small(k, stride)
+    assert r == 7
+    short, counts = 0, []
+    for _ in range(300):
+        x = rng.random(n, dtype=np.float32)
+        t = np.partition(x[::stride], r - 1)[r - 1]
+        c = int((x <= t).sum())
+        counts.append(c)
+        short += c < k
+    assert short == 0                                     # expected 300 * 2e-5
+    assert 1200 < np.mean(counts) < 2400 and max(counts) < 8192     # ~ 256 * 7 = 1792
