@@ -12,17 +12,22 @@ from revisit_anything_amd.engine import SegVLADEngine  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 dev = torch.device("cuda:0")
 eng = SegVLADEngine(0)
-for kv in sys.argv[2:]:
-    eng.set_option(*kv.split("=", 1))
+opts = [kv.split("=", 1) for kv in sys.argv[2:]]
 g = torch.Generator(device=dev)
 g.manual_seed(1)
 n, d, k = 1_000_000, 1024, 200
 R = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
 eng.db_add(R)
 Q = torch.nn.functional.normalize(R[torch.arange(50, device=dev) * 977] + 0.03 * torch.randn(50, d, device=dev, generator=g), dim=1)
+ref = eng.search(Q, k)          # default options: the reference result of this run
+for key, val in opts:
+    eng.set_option(key, val)
 for _ in range(5):
-    eng.search(Q, k)
+    got = eng.search(Q, k)
 torch.cuda.synchronize()
+if opts:
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), "options changed the result"
+    print("options", opts, ": result bit-identical to the default's")
 eng.set_profiling(True)
 eng.profile_reset()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
