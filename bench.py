@@ -631,6 +631,17 @@ def run(a, top=True):
             eng.search(qd1, 200)
         torch.cuda.synchronize()
         call_ms = (time.perf_counter() - t0) / reps * 1e3
+        # ... and ONE query image through the whole path (describe -> search 200 -> keep 50 -> vote), host to host: what an
+        # online caller waits for (the pca_path of the run is the batch's; a one-image describe pads every cluster to a tile)
+        off1 = np.array([0, S], dtype=np.int32)
+        for _ in range(3):
+            index.retrieve(pipe.describe(q_tok[:1], q_msk[:S], off1), off1, 200, 50, 5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            index.retrieve(pipe.describe(q_tok[:1], q_msk[:S], off1), off1, 200, 50, 5)
+        torch.cuda.synchronize()
+        image_ms = (time.perf_counter() - t0) / reps * 1e3
         alg = 4.0 * n_local_rows * d_knn + 4.0 * S * d_knn + 8.0 * S * 200     # fp32 DB rows read once
         moved = alg / 2 if FILTER_KIND == "f16" else alg                        # the fp16 filter streams a 2-byte plane
         pass_ms = g_ms + s_ms
@@ -641,6 +652,7 @@ def run(a, top=True):
                        "filter_only_gbs": moved / (g_ms * 1e-3) / 1e9, "filter_only_frac": moved / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                        "survey_fp32_bytes_gbs": alg / (pass_ms * 1e-3) / 1e9,
                        "filter_ms": g_ms, "select_refine_ms": s_ms, "pass_ms": pass_ms, "call_ms_wall": call_ms,
+                       "one_image_end_to_end_ms_wall": image_ms,
                        "search_stats": eng.search_stats(),
                        "note": "one 50-segment query image per pass over the whole shard; 'achieved' = bytes actually streamed "
                                "(2-byte fp16 plane when the filter is f16) / (filter + select + refine time)"}
