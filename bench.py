@@ -184,6 +184,8 @@ def parse():
     p.add_argument("--search-stats", action="store_true", help="record candidate / refine list occupancies (one extra read-back per search)")
     p.add_argument("--native-comm", action="store_true", help="N>1: exchange through the C-ABI's own RCCL communicator "
                    "(segvlad_search_sharded / segvlad_allgather_rows) instead of torch.distributed collectives")
+    p.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="segvlad_set_option switches of the search context "
+                   "(tuning A/B: e.g. --set batch_plan=1); recorded in the line")
     p.add_argument("--no-ubench", action="store_true", help="skip the live MFMA ceiling micro-benchmark (tools/ubench/mfma_peak)")
     return p.parse_args()
 
@@ -270,6 +272,8 @@ def run(a, top=True):
     eng = SegVLADEngine(local)
     if a.search_stats:
         eng.set_option("search_stats", 1)
+    for kv in a.set:
+        eng.set_option(*kv.split("=", 1))
     C_np = synth.make_vocab(K, D, seed=1000)
     eng.set_vocab(C_np)
     C = torch.from_numpy(C_np).to(dev)
@@ -664,6 +668,7 @@ def run(a, top=True):
         "timing_note": "value / ms_per_step: wall clock over the K steps between two barrier + synchronize fences (the contract); "
                        "the hip_event figures are per-step HIP events on the issuing stream (SURVEY 8d)",
         "mode": "pipelined (describe i+1 on its own context/stream under search i)" if a.pipeline else "serial",
+        "options": a.set or None,
         "pipelined": pipelined,
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "filter_dtype": FILTER_KIND, "pca_gemm_dtype": "f16x3" if eng_pca_products(K * D, P) == 3 else "f32",

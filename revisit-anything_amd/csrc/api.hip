@@ -863,7 +863,8 @@ struct SearchPlan {
   int d = 0, k = 0;
   int64_t n = 0;
   float c_eps = 0.f, inv_scale = 1.f, rn_max = 0.f;
-  int ratio = 16;          // sample growth per level (SV_RATIO; 256 for the one-filter-level plan of a single query image)
+  int ratio_last = 16;     // sample growth into the LAST (full) level; the levels before it grow by SV_RATIO = 16
+  double pfail = 2e-5;     // heur_rank_small's tolerance when ratio_last != 16 (one redone query in ~1000 passes of 50)
 };
 constexpr int SV_RATIO = 16, SV_CAP = 8192, SV_RCAP = 512, SV_CHUNK = 16384;
 
@@ -877,14 +878,14 @@ static int heur_rank(int target) {
 
 // The same question for a sample `ratio` times smaller and SMALL ranks, where the normal approximation is off: the
 // number of full-set values below the r-th smallest sample value is ~ ratio * Gamma(r, 1), so take the smallest r with
-// P[Gamma(r, 1) < target / ratio] < 2e-5 (one redo in ~1000 passes of 50 queries).
-static int heur_rank_small(int target, int ratio) {
+// P[Gamma(r, 1) < target / ratio] < pfail (2e-5: one redo in ~1000 passes of 50 queries).
+static int heur_rank_small(int target, int ratio, double pfail) {
   const double x = (double)target / ratio, ex = std::exp(-x);
   double term = 1.0, sum = 0.0;   // sum_{i < r} x^i / i!
   for (int r = 1; r < target; ++r) {
     sum += term;
     term *= x / r;
-    if (r >= 2 && 1.0 - ex * sum < 2e-5) return r;
+    if (r >= 2 && 1.0 - ex * sum < pfail) return r;
   }
   return target;
 }
@@ -912,7 +913,11 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   int rank[8];
   rank[levels] = k;
   for (int j = levels - 1; j >= 0; --j)
-    rank[j] = !heuristic ? k : std::min(rank[j + 1], pl.ratio == SV_RATIO ? heur_rank(rank[j + 1]) : heur_rank_small(rank[j + 1], pl.ratio));
+  {
+    const int ratio_j = (j + 1 == levels) ? pl.ratio_last : SV_RATIO;   // growth from level j's sample to level j + 1's
+    rank[j] = !heuristic ? k
+                         : std::min(rank[j + 1], ratio_j == SV_RATIO ? heur_rank(rank[j + 1]) : heur_rank_small(rank[j + 1], ratio_j, pl.pfail));
+  }
   const int64_t n0 = (n + pl.stride0 - 1) / pl.stride0;
   const int64_t ld0 = (n0 + 3) & ~3ll;
   float* thr = ctx->s_thr_d2.as<float>();
@@ -953,7 +958,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   int64_t stride = pl.stride0;
   std::vector<uint32_t> hcnt;
   for (int lv = 1; lv <= levels; ++lv) {
-    stride /= pl.ratio;
+    stride /= (lv == levels) ? pl.ratio_last : SV_RATIO;
     const int64_t ns = (n + stride - 1) / stride;
     const bool last = (lv == levels);
     // the candidate counters start every level at zero: the mode-0 selects of the approximate-domain filters leave them so;
@@ -1165,13 +1170,15 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // it: 256 for 1 M rows, 64 for a 250 k-row shard).  The threshold is a low rank of that sample (heur_rank_small: ~7 at
   // stride 256), the full level collects stride x rank candidates per query (~1800 + the margin's ~900 at 1 M rows: a
   // workgroup select's worth, SV_CAP bounds it -- hence stride <= 512), and the deeper plan's two sampled filter launches
-  // with their selects (~90 us of a ~500 us pass) are gone.
+  // with their selects (~90 us of a ~500 us pass) are gone.  (The same last step for batches -- strides 4096, 256, 1 instead
+  // of 4096, 256, 16, 1 -- was measured and dropped: the stride-16 level's 1.3 ms come back as epilogue time of the full
+  // level, which then collects 2900 candidates per query instead of 780, and as 0.2 ms of longer selects.)
   int small_stride = 16;
   while ((n + small_stride - 1) / small_stride > 4096 && small_stride <= 512) small_stride *= 2;
   if (heuristic && nq <= 128 && ctx->opt.small_plan && small_stride <= 512) {
     plh.levels = 1;
     plh.stride0 = small_stride;
-    plh.ratio = small_stride;
+    plh.ratio_last = small_stride;
   } else if (heuristic) {
     while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
       plh.stride0 *= SV_RATIO;
