@@ -191,7 +191,7 @@ struct segvlad_ctx {
   DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
       s_qh, s_ql, s_ref_cnt, s_ref_id, s_ref_keys, s_ref_tick, s_qscale, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
       s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part,
-      s_rovf, s_ref_lim;
+      s_ref_lim;
   // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time, the exchange buffers
   void* comm = nullptr;   // ncclComm_t
   int comm_rank = 0, comm_world = 1;
