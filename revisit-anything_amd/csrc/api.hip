@@ -1291,7 +1291,10 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_HIP(ctx->s_cand_id.reserve(mrows * SV_CAP * 4));
   SV_HIP(ctx->s_thr_d2.reserve(mrows * k * 4));
   SV_HIP(ctx->s_thr_idx.reserve(mrows * k * 8));
-  const int64_t n0 = (n + pl.stride0 - 1) / pl.stride0;
+  // the exact level's distance block: the larger of the two plans' samples (the single-image plan's stride can be SMALLER than
+  // the rigorous plan's: 64 against 256 for a 250 k-row shard)
+  const int64_t stride_min = heuristic ? std::min(pl.stride0, plh.stride0) : pl.stride0;
+  const int64_t n0 = (n + stride_min - 1) / stride_min;
   SV_HIP(ctx->s_dist.reserve(mrows * ((n0 + 3) & ~3ll) * 4));
   // Flags: [nq] rows + 1 count.  A heuristic pass flags the queries whose low-rank thresholds did not verify (-> redo
   // with the rigorous thresholds, below); a rigorous pass flags list overflows (-> exact distance-matrix path, alone).

@@ -395,3 +395,52 @@ def test_vote_handles_oversized_query_images(eng):
         order = np.lexsort((np.arange(len(bc)), -bc))[:5]
         assert predc.cpu().numpy()[i].tolist() == order.tolist()
         assert scc.cpu().numpy()[i].tolist() == bc[order].astype(np.float64).tolist()
+
+
+@pytest.mark.parametrize("case", [
+    # (rows, d, queries, k, kind)
+    (40000, 64, 1, 10, "gauss"), (70001, 128, 37, 200, "unit"), (300000, 256, 128, 50, "unit"),
+    (100000, 1024, 50, 200, "clustered"), (65537, 2048, 9, 100, "unit"), (50000, 512, 64, 1, "scaled"),
+    (120000, 1024, 50, 200, "duplicates"),
+])
+def test_knn_single_image_plan_sweep_equals_deep_plan(case):
+    """The single-image plan (<= 128 query rows: one filter level, workgroup selects, shared refinement lists, device-side
+    query scale) against the batches' deep plan (small_plan = 0) on the same queries: bit-identical distances and ids over a
+    sweep of index sizes (sample strides 16..128), widths (the shared-list refinement needs d % 1024 == 0, the others take
+    the one-workgroup kernels), list depths and data kinds -- Gaussian rows of mixed scale, unit rows, tight clusters (long
+    refine bands), rows scaled over six decades, exact duplicates of the nearest rows (ties: ordered by id on both paths).
+    A FRESH context per case, single-image search first: grow-only scratch that an earlier, larger call had sized would hide
+    an under-allocation (it did: the exact level's distance block was sized from the batches' plan)."""
+    import torch
+
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    eng = SegVLADEngine(0)
+    n, d, nq, k, kind = case
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(n + d + nq)
+    R = torch.randn(n, d, device=eng.device, generator=g)
+    if kind in ("unit", "duplicates"):
+        R = torch.nn.functional.normalize(R, dim=1)
+    elif kind == "clustered":
+        cen = torch.nn.functional.normalize(torch.randn(200, d, device=eng.device, generator=g), dim=1)
+        R = torch.nn.functional.normalize(cen[torch.randint(0, 200, (n,), device=eng.device, generator=g)] + 0.02 * R / d ** 0.5, dim=1)
+    elif kind == "scaled":
+        R = R * torch.logspace(-3, 3, n, device=eng.device)[torch.randperm(n, device=eng.device, generator=g)][:, None]
+    src = torch.randint(0, n, (nq,), device=eng.device, generator=g)
+    Q = R[src] + 0.1 * R[src].norm(dim=1, keepdim=True) * torch.randn(nq, d, device=eng.device, generator=g) / d ** 0.5
+    if kind == "duplicates":
+        R[1000:1000 + 3 * nq] = R[src].repeat(3, 1)          # three exact copies of every query's nearest row
+    R = R.contiguous()
+    eng.db_add(R)
+    d2b, ib = eng.search(Q.contiguous(), k)          # the single-image plan, on untouched scratch
+    stb = eng.search_stats()
+    eng.set_option("small_plan", 0)
+    d2a, ia = eng.search(Q.contiguous(), k)
+    sta = eng.search_stats()
+    assert stb["levels"] == 1 and sta["levels"] >= 1, (sta, stb)
+    assert torch.equal(ia, ib) and torch.equal(d2a, d2b), (case, sta, stb)
+    # and a sanity anchor on the exact answer itself: the nearest row of a noisy copy is its source (or an exact duplicate)
+    if kind != "clustered":
+        near = ib[:, 0]
+        assert bool(((near == src) | (near >= 1000) & (near < 1000 + 3 * nq)).all())
