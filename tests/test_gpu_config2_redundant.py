@@ -321,3 +321,58 @@ def test_second_tier_runs_per_chunk_of_queries(eng):
     clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
     assert np.array_equal(idx[sel].cpu().numpy()[clear], ridx[clear])
     eng.db_reset()
+
+
+@pytest.mark.parametrize("d", [256, 1024])
+def test_single_image_pass_overflow_paths_on_a_fresh_context(d):
+    """The same two overflows in ONE query image's pass (40 query rows: the single-image plan -- workgroup selects, and at
+    d = 1024 the shared-list refinement), on a context that has never run anything else (grow-only scratch sized by an earlier,
+    larger call would hide an under-allocation): query 7's 600 duplicates take the second refinement tier, query 23's 9000
+    overflow the candidate list -> redone with the rigorous thresholds -> matrix path, alone; everything equals the oracle."""
+    import torch
+
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    eng = SegVLADEngine(0)
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(13)
+    n, nq, k = 200000, 40, 50
+    R = torch.randn(n, d, device=dev, generator=g)
+    R[:, d - 2:] = 0.0
+    R = torch.nn.functional.normalize(R, dim=1)
+    star = 0.2 * torch.nn.functional.normalize(torch.randn(2, d, device=dev, generator=g) * (torch.arange(d, device=dev) < d - 2), dim=1)
+    star[0, d - 2] = 1.0
+    star[1, d - 1] = 1.0
+    star = torch.nn.functional.normalize(star, dim=1)
+    dup_a = torch.arange(0, 600, device=dev) * 331 + 17
+    dup_b = torch.arange(0, 9000, device=dev) * 22 + 5
+    dup_b = dup_b[~torch.isin(dup_b, dup_a)]
+    R[dup_a] = star[0]
+    R[dup_b] = star[1]
+    special = torch.cat([dup_a, dup_b])
+    src = torch.randint(0, n - 1, (nq,), device=dev, generator=g)
+    for _ in range(4):
+        src = torch.where(torch.isin(src, special), src + 1, src)
+    Q = R[src] + (1.0 / d ** 0.5) * torch.randn(nq, d, device=dev, generator=g)
+    Q[:, d - 2:] = 0.0
+    Q = torch.nn.functional.normalize(Q, dim=1)
+    Q[7] = star[0]
+    Q[23] = star[1]
+    eng.db_add(R)
+    d2, idx = eng.search(Q, k)
+    st = eng.search_stats()
+    assert st["levels"] == 1 and st["filter"] == "f16", st
+    assert st["n_refine2"] >= 1 and st["n_fallback"] == 1, st
+    rd2, ridx = O().topk_from_d2(O().l2_matrix(R.cpu().numpy(), Q.cpu().numpy()), k)
+    dd, ii = d2.cpu().numpy(), idx.cpu().numpy()
+    assert np.abs(dd - rd2).max() < 1e-5
+    assert np.array_equal(ii[7], np.sort(dup_a.cpu().numpy())[:k])
+    assert np.array_equal(ii[23], np.sort(dup_b.cpu().numpy())[:k])
+    clear = np.minimum(np.diff(rd2, axis=1, prepend=-1.0), np.diff(rd2, axis=1, append=10.0)) > 1e-5
+    clear[[7, 23]] = False
+    assert np.array_equal(ii[clear], ridx[clear])
+    # a second pass on the same context (scratch now sized, tickets back at zero): same bits
+    d2b, idxb = eng.search(Q, k)
+    assert torch.equal(idxb, idx) and torch.equal(d2b, d2)
+    eng.close()
