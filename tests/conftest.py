@@ -39,3 +39,10 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def engine_scope(fixture_name, config):
+    """Scope of the GPU test modules' `eng` fixture: one context per module (fast) -- or, with SEGVLAD_FRESH_ENGINE=1, a
+    FRESH context for every test: the library's scratch buffers only ever grow, so a context that an earlier, larger call
+    has sized hides under-allocations (one was found that way: the exact level's distance block of a single-image search)."""
+    return "function" if os.environ.get("SEGVLAD_FRESH_ENGINE") else "module"

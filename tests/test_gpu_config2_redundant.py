@@ -16,12 +16,13 @@ import time
 
 import numpy as np
 import pytest
+from conftest import engine_scope
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope=engine_scope)
 def eng():
     import torch
 

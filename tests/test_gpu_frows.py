@@ -5,11 +5,12 @@ import os
 
 import numpy as np
 import pytest
+from conftest import engine_scope
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope=engine_scope)
 def eng():
     import torch
 

@@ -5,13 +5,14 @@ import os
 
 import numpy as np
 import pytest
+from conftest import engine_scope
 
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope=engine_scope)
 def eng():
     import torch
 
