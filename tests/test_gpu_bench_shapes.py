@@ -46,13 +46,14 @@ def cos_rows(a, b):
 # (a) exact kNN at d = 1024: 1 M planted rows and the shard sizes of the 2/4/8-GPU runs
 # ------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def planted_1m(eng):
+def planted_1m():
     """20 000 reference 'images' x 50 segments x 1024-d, groups of 4 near-duplicate places, generated on
     the device; queries of three kinds: planted (sigma_q = 4), un-planted random unit vectors, and near-copies of
     database rows (tight clusters)."""
     import torch
 
-    dev = eng.device
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device (no CPU fallback exists)"
+    dev = torch.device("cuda:0")        # (data only: no context -- the `eng` fixture may be per test, see conftest.engine_scope)
     n_img, S, d, group = 20000, 50, 1024, 4
     g = torch.Generator(device=dev)
     g.manual_seed(3000)
