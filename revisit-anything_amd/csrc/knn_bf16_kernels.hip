@@ -2175,8 +2175,21 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
   if (!last) return;
   int np2 = 2;
   while (np2 < n) np2 <<= 1;
-  for (int j = tid; j < np2; j += 256)
-    a[j] = j < n ? __hip_atomic_load(&gkeys[row * rcap + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+  // gkeys holds all ones wherever no key of THIS launch has landed (the launcher fills a new buffer so, the reader puts the
+  // fill back behind every key it takes; a key is never all ones: finite distance, 32-bit id).  A key that another XCD's
+  // workgroup stored before its ticket is visible here by the protocol above -- the check is a seat belt: a stale slot is
+  // re-read (a bounded number of times) instead of silently sorted.
+  for (int j = tid; j < np2; j += 256) {
+    uint64_t v = ~0ull;
+    if (j < n) {
+      for (int spin = 0; spin < 4096; ++spin) {
+        v = __hip_atomic_load(&gkeys[row * rcap + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != ~0ull) break;
+      }
+      __hip_atomic_store(&gkeys[row * rcap + j], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a[j] = v;
+  }
   if (tid == 0) __hip_atomic_store(&tick[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   bitonic64(a, np2, tid);
@@ -2204,7 +2217,9 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
     const size_t tick_cap = ctx->s_ref_tick.cap;
     SV_HIP(ctx->s_ref_tick.reserve((size_t)128 * 4));
     if (ctx->s_ref_tick.cap != tick_cap) SV_HIP(hipMemsetAsync(ctx->s_ref_tick.p, 0, ctx->s_ref_tick.cap, ctx->stream));
+    const size_t keys_cap = ctx->s_ref_keys.cap;
     SV_HIP(ctx->s_ref_keys.reserve((size_t)nq * rcap * 8));
+    if (ctx->s_ref_keys.cap != keys_cap) SV_HIP(hipMemsetAsync(ctx->s_ref_keys.p, 0xff, ctx->s_ref_keys.cap, ctx->stream));
     lds = (size_t)(32 * 516 + 1024) * 4 + (size_t)rpad * 8;
     if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_small_kernel), lds));
     hipLaunchKernelGGL(refine_exact_small_kernel, dim3(nq * parts), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
