@@ -32,7 +32,6 @@ pipe = SegVLADPipeline(eng, H, W, 14, order=3, use_pca=True)
 n = 1_000_000
 R = torch.nn.functional.normalize(torch.randn(n, P, device=dev, generator=g), dim=1)
 eng.db_add(R, torch.arange(n, device=dev, dtype=torch.int32) // S)
-rng = np.random.Generator(np.random.PCG64(3))
 tok = torch.from_numpy(synth.make_tokens(C_np, N, seed=2000)[None]).to(dev)
 msk = torch.from_numpy(synth.make_masks(S, H // 2, W // 2, seed=2000)).to(dev)
 off = np.array([0, S], dtype=np.int32)
