@@ -1238,9 +1238,10 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       ctx->db_f16_rows = n;
     }
     SV_HIP(ctx->s_qf16.reserve((size_t)nq * d * 2));
-    if (nq <= 128 && (((int64_t)nq * d) & 3) == 0) {
+    if (nq <= 128 && (((int64_t)nq * d) & 3) == 0 && (int64_t)nq * d <= (1 << 18)) {
       // one query image per pass: the scale is computed AND consumed on the device (a host round trip in front of every pass
-      // was ~45 us of a ~600 us call)
+      // was ~45 us of a ~600 us call).  One workgroup reads the block twice: up to 1 MiB of queries (128 x 2048 floats);
+      // deeper rows (raw K*D descriptors) keep the many-workgroup kernels and their read-back.
       SV_HIP(ctx->s_qscale.reserve(16));
       SV_TRY(sv_launch_query_f16_small(ctx, (const float*)dq, (int64_t)nq * d, ctx->db_f16_scale, ctx->s_qf16.as<uint16_t>(),
                                        ctx->s_qscale.as<float>()));
