@@ -263,37 +263,58 @@ class SamAutoMasks:
         m = m[..., :in_hw[0], :in_hw[1]]
         return torch.nn.functional.interpolate(m, out_hw, mode="bilinear", align_corners=False)
 
+    # ---- the network half: everything that needs weights -------------------------------------------------------------
+    def _embed(self, img_rgb: np.ndarray):
+        """predictor.set_image: the image embedding and the (height, width) of the resized image inside the model frame."""
+        x, in_hw = self.preprocess(img_rgb)
+        return self.model.get_image_embeddings(x), in_hw
+
+    def _predict(self, state, pts_img: np.ndarray, out_hw):
+        """predictor.predict_torch(points[:, None, :], ones, multimask_output=True, return_logits=True) for one batch of
+        prompt points given in IMAGE coordinates: mask logits at the image's resolution [nb, 3, H, W] and the predicted
+        IoUs [nb, 3].  (ResizeLongestSide.apply_coords scales the points into the model frame.)"""
+        emb, (nh, nw) = state
+        H, W = out_hw
+        pm = torch.as_tensor(pts_img * np.array([[nw / W, nh / H]]), dtype=torch.float32, device=self.device)
+        nb = pm.shape[0]
+        out = self.model(image_embeddings=emb, input_points=pm.view(1, nb, 1, 2),
+                         input_labels=torch.ones((1, nb, 1), dtype=torch.int, device=self.device), multimask_output=True)
+        return self._upscale(out.pred_masks[0], (nh, nw), (H, W)), out.iou_scores[0]
+
+    # ---- the flow of SamAutomaticMaskGenerator.generate (automatic_mask_generator.py:137-330) ---------------------------
+    # Pinned: tools/make_golden.py runs the vendored class body (generate -> _generate_masks -> _process_crop -> _process_batch)
+    # on a stub predictor with seeded logits / IoUs; tests/test_producers.py feeds the same logits through _predict and
+    # requires the same records in the same order (tests/golden/sam_generate.npz).
     @torch.no_grad()
     def generate(self, img_rgb: np.ndarray):
         a = np.asarray(img_rgb)
         if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
             raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {a.dtype} {a.shape}")
         H, W = a.shape[:2]
-        x, (nh, nw) = self.preprocess(a)
-        emb = self.model.get_image_embeddings(x)
+        state = self._embed(a)
         pts_img = self.point_grid * np.array([[W, H]], dtype=np.float64)                 # (x, y) in the image
-        pts_model = pts_img * np.array([[nw / W, nh / H]])                                # ResizeLongestSide.apply_coords
         masks_l, ious_l, stab_l, pts_l = [], [], [], []
-        for b0 in range(0, len(pts_img), self.points_per_batch):
-            pm = torch.as_tensor(pts_model[b0:b0 + self.points_per_batch], dtype=torch.float32, device=self.device)
-            nb = pm.shape[0]
-            out = self.model(image_embeddings=emb, input_points=pm.view(1, nb, 1, 2),
-                             input_labels=torch.ones((1, nb, 1), dtype=torch.int, device=self.device), multimask_output=True)
-            logits = self._upscale(out.pred_masks[0], (nh, nw), (H, W)).flatten(0, 1)      # [nb * 3, H, W]
-            iou = out.iou_scores[0].flatten(0, 1)
-            pts = torch.as_tensor(pts_img[b0:b0 + nb], dtype=torch.float64).repeat_interleave(logits.shape[0] // nb, dim=0)
-            keep = iou > self.pred_iou_thresh if self.pred_iou_thresh > 0.0 else torch.ones_like(iou, dtype=torch.bool)
-            logits, iou, pts = logits[keep], iou[keep], pts[keep.cpu()]
+        for b0 in range(0, len(pts_img), self.points_per_batch):                         # _process_batch
+            pb = pts_img[b0:b0 + self.points_per_batch]
+            logits, iou = self._predict(state, pb, (H, W))
+            per_point = logits.shape[1]
+            logits, iou = logits.flatten(0, 1), iou.flatten(0, 1)                          # [nb * 3, H, W], [nb * 3]
+            pts = torch.as_tensor(pb, dtype=torch.float64).repeat_interleave(per_point, dim=0)
+            if self.pred_iou_thresh > 0.0:
+                keep = iou > self.pred_iou_thresh
+                logits, iou, pts = logits[keep], iou[keep], pts[keep.cpu()]
             st = stability_score(logits, self.mask_threshold, self.stability_score_offset)
             if self.stability_score_thresh > 0.0:
                 keep = st >= self.stability_score_thresh
                 logits, iou, pts, st = logits[keep], iou[keep], pts[keep.cpu()], st[keep]
             masks_l.append(logits > self.mask_threshold)
             ious_l.append(iou), stab_l.append(st), pts_l.append(pts)
+            # (is_box_near_crop_edge keeps every box here: with crop_n_layers = 0 the crop IS the image, and a box on the
+            #  image's own border is exempt -- automatic_mask_generator.py:271-274, utils/amg.py:80-90)
         masks = torch.cat(masks_l)
         ious, stab, pts = torch.cat(ious_l), torch.cat(stab_l), torch.cat(pts_l)
         boxes = mask_boxes(masks)
-        keep = box_nms(boxes, ious, self.box_nms_thresh)                                   # within-crop NMS, score = predicted IoU
+        keep = box_nms(boxes, ious, self.box_nms_thresh)                                   # _process_crop: NMS by predicted IoU
         kc = keep.cpu()
         masks, ious, stab, pts, boxes = masks[keep].cpu().numpy(), ious[keep].cpu(), stab[keep].cpu(), pts[kc], boxes[keep].cpu()
         recs = []

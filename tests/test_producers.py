@@ -240,3 +240,48 @@ def test_sam_auto_masks_records_and_half_resolution(tiny_sam, tmp_path):
     back = preload_masks(st.FeatureStore(str(tmp_path / "m"), "masks"), "a.jpg")
     assert len(back) == len(recs2) and all(np.array_equal(b, r["segmentation"]) for b, r in zip(back, recs2))
     assert np.array_equal(pr.resize_like_cv2(img, 128, 96), img)                              # identity size: untouched
+
+
+def test_sam_generate_flow_equals_the_vendored_generator(golden_dir):
+    """SamAutoMasks.generate (batching, predicted-IoU cut, stability cut, threshold, boxes, NMS by predicted IoU, records)
+    against the reference's vendored SamAutomaticMaskGenerator.generate, both on the stub decoder of tests/sam_stub.py:
+    same records, same order, masks bit for bit (tools/make_golden.py::gen_sam_generate)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sam_stub import stub_predict
+
+    z = np.load(os.path.join(golden_dir, "sam_generate.npz"))
+
+    class Stubbed(pr.SamAutoMasks):
+        def __init__(self, seed, **kw):   # no network: the two model-facing members are replaced below
+            self.device = torch.device("cpu")
+            self.points_per_batch = int(kw.pop("points_per_batch"))
+            self.pred_iou_thresh, self.stability_score_thresh = float(kw.pop("pred_iou_thresh")), float(kw.pop("stability_score_thresh"))
+            self.stability_score_offset, self.box_nms_thresh = float(kw.pop("stability_score_offset")), float(kw.pop("box_nms_thresh"))
+            self.min_mask_region_area, self.mask_threshold = 0, float(kw.pop("mask_threshold"))
+            self.point_grid = pr.build_point_grid(kw.pop("points_per_side"))
+            self.seed = seed
+            assert not kw
+
+        def _embed(self, img_rgb):
+            return None
+
+        def _predict(self, state, pts_img, out_hw):
+            lg, io = stub_predict(pts_img, out_hw[0], out_hw[1], self.seed)
+            return torch.from_numpy(lg), torch.from_numpy(io)
+
+    for c in range(int(z["n_cases"])):
+        H, W, pps, ppb, seed = (int(v) for v in z[f"c{c}_args"])
+        thr, piou, stab, off, nms = (float(v) for v in z[f"c{c}_thr"])
+        gen = Stubbed(seed, points_per_side=pps, points_per_batch=ppb, pred_iou_thresh=piou, stability_score_thresh=stab,
+                      stability_score_offset=off, box_nms_thresh=nms, mask_threshold=thr)
+        recs = gen.generate(np.zeros((H, W, 3), dtype=np.uint8))
+        want_seg = np.unpackbits(z[f"c{c}_seg"], axis=-1)[..., :W].astype(bool)
+        assert len(recs) == len(want_seg) >= 3, (c, len(recs), len(want_seg))
+        assert np.array_equal(np.stack([r["segmentation"] for r in recs]), want_seg)           # same masks in the same ORDER
+        assert [r["area"] for r in recs] == z[f"c{c}_area"].tolist()
+        assert [r["bbox"] for r in recs] == z[f"c{c}_bbox"].tolist()
+        assert [r["crop_box"] for r in recs] == z[f"c{c}_crop"].tolist()
+        assert np.array_equal(np.array([r["predicted_iou"] for r in recs]), z[f"c{c}_iou"])
+        assert np.array_equal(np.array([r["stability_score"] for r in recs]), z[f"c{c}_stab"])
+        assert np.array_equal(np.array([r["point_coords"][0] for r in recs]), z[f"c{c}_pts"])

@@ -494,11 +494,109 @@ def gen_producers():
     print("producers.npz", {k: np.asarray(v).shape for k, v in out.items() if not k.endswith("_img")})
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the flow of the vendored SamAutomaticMaskGenerator (round-3 verdict item 6)
+# ---------------------------------------------------------------------------------------------------------------------
+SAM_CASES = [  # (H, W, points_per_side, points_per_batch, generator keyword arguments, mask_threshold of the stub model, seed)
+    (72, 96, 8, 24, {}, 0.0, 9401),                                                        # the reference's defaults
+    (72, 96, 8, 64, {"pred_iou_thresh": 0.0, "stability_score_thresh": 0.0, "box_nms_thresh": 0.5, "stability_score_offset": 0.5}, 0.0, 9402),
+    (50, 50, 5, 7, {"pred_iou_thresh": 0.8, "stability_score_thresh": 0.9}, 0.3, 9403),     # a model threshold off zero
+]
+
+
+def torchvision_nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms restated from its documented semantics (torchvision is not installable in this image): boxes in
+    decreasing score order, each kept unless its IoU with an already kept box exceeds the threshold; returns the kept
+    indices in that order.  (The fixture's scores are distinct, so torchvision's unspecified tie order does not enter.)"""
+    order = sorted(range(len(scores)), key=lambda i: -float(scores[i]))
+    keep = []
+    b = boxes.tolist()
+
+    def iou(p, q):
+        iw, ih = min(p[2], q[2]) - max(p[0], q[0]), min(p[3], q[3]) - max(p[1], q[1])
+        inter = max(iw, 0.0) * max(ih, 0.0)
+        return inter / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - inter)
+
+    for i in order:
+        if all(not (iou(b[i], b[j]) > iou_threshold) for j in keep):
+            keep.append(i)
+    return torch.tensor(keep, dtype=torch.int64)
+
+
+def gen_sam_generate():
+    """tests/golden/sam_generate.npz: SamAutomaticMaskGenerator.generate -> _generate_masks -> _process_crop ->
+    _process_batch (sam/segment_anything/automatic_mask_generator.py, the class body executed where it lies, together
+    with the whole of utils/amg.py, imported as the module it is) on a STUB predictor whose logits / predicted IoUs are
+    tests/sam_stub.stub_predict -- the mask decoder needs weights this image does not have.  Restated, and said so:
+    torchvision's batched_nms / box_area (one category: batched_nms is nms) -- torchvision cannot be installed here."""
+    import importlib.util
+    from typing import Any, Dict, List, Optional, Tuple
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sam_stub import stub_predict
+
+    spec = importlib.util.spec_from_file_location("ref_amg", f"{REF}/sam/segment_anything/utils/amg.py")
+    amg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(amg)
+
+    class StubPredictor:   # the five members the generator touches
+        def __init__(self, model):
+            self.model = model
+            self.device = "cpu"
+            self.transform = types.SimpleNamespace(apply_coords=lambda pts, im_size: np.asarray(pts, dtype=np.float64))
+            self.im = None
+
+        def set_image(self, im):
+            self.im = im.shape[:2]
+
+        def reset_image(self):
+            self.im = None
+
+        def predict_torch(self, pts, labels, multimask_output, return_logits):
+            assert multimask_output and return_logits and pts.shape[1] == 1 and bool((labels == 1).all())
+            lg, io = stub_predict(pts[:, 0, :].numpy(), self.im[0], self.im[1], self.model.seed)
+            return torch.from_numpy(lg), torch.from_numpy(io), None
+
+    ns = {k: getattr(amg, k) for k in dir(amg) if not k.startswith("__")}
+    ns.update(np=np, torch=torch, Any=Any, Dict=Dict, List=List, Optional=Optional, Tuple=Tuple, Sam=object, SamPredictor=StubPredictor,
+              batched_nms=lambda boxes, scores, idxs, iou_threshold: torchvision_nms(boxes, scores, iou_threshold),
+              box_area=lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
+    path = f"{REF}/sam/segment_anything/automatic_mask_generator.py"
+    body = [n for n in ast.parse(open(path).read()).body if isinstance(n, ast.ClassDef) and n.name == "SamAutomaticMaskGenerator"]
+    assert len(body) == 1
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    out = {"n_cases": np.array(len(SAM_CASES))}
+    for c, (H, W, pps, ppb, kw, thr, seed) in enumerate(SAM_CASES):
+        model = types.SimpleNamespace(mask_threshold=thr, seed=seed)
+        gen = ns["SamAutomaticMaskGenerator"](model, points_per_side=pps, points_per_batch=ppb, **kw)
+        img = np.zeros((H, W, 3), dtype=np.uint8)
+        recs = gen.generate(img)
+        assert len(recs) >= 3, (c, len(recs))
+        ious = [r["predicted_iou"] for r in recs]
+        assert len(set(ious)) == len(ious)   # distinct scores: no tie order to pin
+        out[f"c{c}_args"] = np.array([H, W, pps, ppb, seed], dtype=np.int64)
+        out[f"c{c}_thr"] = np.array([thr, kw.get("pred_iou_thresh", 0.88), kw.get("stability_score_thresh", 0.95),
+                                     kw.get("stability_score_offset", 1.0), kw.get("box_nms_thresh", 0.7)])
+        out[f"c{c}_seg"] = np.packbits(np.stack([r["segmentation"] for r in recs]), axis=-1)
+        out[f"c{c}_area"] = np.array([r["area"] for r in recs], dtype=np.int64)
+        out[f"c{c}_bbox"] = np.array([r["bbox"] for r in recs], dtype=np.int64)
+        out[f"c{c}_iou"] = np.array(ious, dtype=np.float64)
+        out[f"c{c}_pts"] = np.array([r["point_coords"][0] for r in recs], dtype=np.float64)
+        out[f"c{c}_stab"] = np.array([r["stability_score"] for r in recs], dtype=np.float64)
+        out[f"c{c}_crop"] = np.array([r["crop_box"] for r in recs], dtype=np.int64)
+        print(f"sam_generate case {c}: {len(recs)} records of {pps * pps * 3} proposals")
+    np.savez_compressed(f"{OUT}/sam_generate.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "producers":
         os.makedirs(OUT, exist_ok=True)
         patch_cuda_to_cpu()
         gen_producers()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sam":
+        os.makedirs(OUT, exist_ok=True)
+        gen_sam_generate()
     else:
         main()
         gen_producers()
+        gen_sam_generate()
