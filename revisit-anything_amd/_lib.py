@@ -90,6 +90,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
+    alt = os.environ.get("SEGVLAD_LIB_PATH")   # development only: another build of the same library (e.g. the timing-ablation build)
+    if alt:
+        path, build_if_missing = alt, False
     if build_if_missing and _build.needs_build():
         try:
             _build.build()

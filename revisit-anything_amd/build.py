@@ -29,17 +29,21 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, ablations: bool = False) -> str:
+    """ablations=True (development only): the build with the timing ablations (WRONG results) and the phase timers, as a
+    SECOND library next to the product's (lib/libsegvlad_hip_abl.so; load it with SEGVLAD_LIB_PATH)."""
+    ablations = ablations or bool(os.environ.get("SEGVLAD_BUILD_ABLATIONS"))
+    lib_path = LIB_PATH.replace(".so", "_abl.so") if ablations else LIB_PATH
+    if not ablations and not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIB_DIR, src.replace(".hip", "_abl.o" if ablations else ".o"))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
                "-c", os.path.join(CSRC, src), "-o", obj]
-        if os.environ.get("SEGVLAD_BUILD_ABLATIONS"):   # development only: timing ablations with WRONG results
+        if ablations:
             cmd.insert(1, "-DSEGVLAD_ABLATIONS")
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -51,12 +55,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablations="--ablations" in sys.argv))

@@ -178,6 +178,8 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   }
   if (!strcmp(key, "f16_cfg")) return as_int(&o.f16_cfg);
   if (!strcmp(key, "f16_gm")) return as_int(&o.f16_gm);
+  if (!strcmp(key, "f16_walk")) return as_int(&o.f16_walk);
+  if (!strcmp(key, "f16_epi")) return as_int(&o.f16_epi);
   if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);
   if (!strcmp(key, "x3_gm")) return as_int(&o.x3_gm);
   if (!strcmp(key, "search_stats")) return as_int(&o.search_stats);

@@ -91,6 +91,11 @@ struct SvOptions {
   int pca_fp32 = 0;       // 1: plain fp32-MFMA projection instead of the fp16x3 split GEMM
   int f16_cfg = -1;       // kNN fp16 filter tile configuration (-1 = chosen from the shape)
   int f16_gm = -1;        // tile-block height of the XCD-aware order (-1 = by the number of query tiles, 0 = plain tm-fastest order)
+  int f16_walk = -1;      // tile walk of the persistent fp16 filter: bit 0 = an XCD keeps its block of query tiles while it steps
+                          // through the database blocks, bit 1 = odd steps run their k-tiles backwards (-1 = default, see
+                          // launch_f16_filter); never changes a result
+  int f16_epi = -1;       // epilogue of the persistent biased fp16 filter: 0 = workgroup-level reservation (one global atomic per
+                          // row and tile, two workgroup barriers), 1 = wave-private (one global atomic per survivor, no barrier)
   int x3_tile = 0;        // PCA split GEMM tile (0 = from the shape, 128, 256)
   int x3_gm = -1;         // PCA split GEMM XCD-aware block height (-1 = default of the kernel, 0 = plain order)
   int search_stats = 0;   // 1: segvlad_search records list occupancies (synchronises once per chunk)

@@ -474,10 +474,10 @@ __device__ __forceinline__ float acc_elem(const f32x16& v, int r) {
 //      ahead of the tile (before the head DMA; PERSIST: before the previous tile's epilogue).  The running sums are up to
 //      1.5 x larger in magnitude, which sv_f16_c_eps accounts for.
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false>
+          bool BIAS = false, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
-    int seq_total,
+    int seq_total, int walk,
     float inv_scale, const float* __restrict__ qn, const float* __restrict__ rn, const float* __restrict__ thr,
     int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* __restrict__ cand_cnt,
     float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap, const float* __restrict__ inv_scale_dev) {
@@ -511,13 +511,34 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   const int ntiles = d / HBK;
   const int tiles_n = (N + BN - 1) / BN;
   auto swz = [](int r, int c) { return CH == 8 ? (c ^ ((r >> 1) & 7)) : (c ^ ((r >> 2) & 3)); };
+  // walk bit 0 ("query-block-resident"): an XCD keeps ONE block of gm query tiles while it steps through its share of the
+  // database blocks (blocks xcd, xcd + 8, ... -- the direction alternates from one query block to the next), instead of
+  // meeting a different query block at every step: the gm query tiles (gm x 512 KiB of fp16 rows at d = 1024) are then
+  // re-referenced by every step.  walk bit 1 ("serpentine k"): odd steps run their k-tiles from the END of the rows to the
+  // start.  Under an LRU-like L2 a cyclic re-reference of a working set larger than the cache (4 MiB of query tiles + 2 MiB
+  // of database tiles per step against 4 MiB of L2 per XCD) never hits; reversing the direction makes the most recently
+  // used half of the resident block hit (the filter's result does not depend on the accumulation order: the margin
+  // sv_f16_c_eps bounds ANY order).
   auto tile_of = [&](int sq, int& tm_, int& tn_) -> bool {   // sq: position in this XCD's sequence
-    const int xcd = blockIdx.x & 7, within = sq & 31, st = (sq >> 5) * 8 + xcd;
+    const int xcd = blockIdx.x & 7, within = sq & 31;
     const int gn = 32 / gm, sm_cnt = (tiles_m + gm - 1) / gm;
-    tm_ = (st % sm_cnt) * gm + within % gm;
-    tn_ = (st / sm_cnt) * gn + within / gm;
+    if (walk & 1) {
+      const int sn_cnt = (tiles_n + gn - 1) / gn, nbx = (sn_cnt + 7) >> 3;
+      const int s_ = sq >> 5, qb = s_ / nbx;
+      int j = s_ - qb * nbx;
+      if (qb & 1) j = nbx - 1 - j;
+      tm_ = qb * gm + within % gm;
+      tn_ = (j * 8 + xcd) * gn + within / gm;
+    } else {
+      const int st = (sq >> 5) * 8 + xcd;
+      tm_ = (st % sm_cnt) * gm + within % gm;
+      tn_ = (st / sm_cnt) * gn + within / gm;
+    }
     return tm_ < tiles_m && tn_ < tiles_n;
   };
+  // serpentine k: element offset of k-tile x of a step that runs backwards (wave-uniform)
+  auto rev_of = [&](int sq) -> bool { return (walk & 2) && ((sq >> 5) & 1); };
+  auto kofs = [&](bool rev_, int x) -> int { return (rev_ ? ntiles - 1 - x : x) * HBK; };
   int tm, tn;
   int seq = (int)(blockIdx.x >> 3);
   if (PERSIST) {
@@ -537,20 +558,21 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   auto b_off = [](int st_) { return PERSIST ? (st_ == 0 ? 4 * PA : (st_ == 1 ? 2 * PA : PA)) : 2 * PA + st_ * PB; };
   const int lrow_p = l / CH, lch = l % CH;
   // head of a tile: A(0), B(0) and (NB == 3) B(1), by global->LDS DMA
-  auto issue_head = [&](int tm_, int tn_) {
+  auto issue_head = [&](int tm_, int tn_, bool rev_) {
     const int64_t m0_ = (int64_t)tm_ * BM, n0_ = (int64_t)tn_ * BN;
+    const int k0_ = kofs(rev_, 0), k1_ = kofs(rev_, 1);
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const int row = (w * JA + j) * RP + lrow_p;
       const int64_t qa = (m0_ + row < M) ? (m0_ + row) : (int64_t)(M - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Qh + qa * d + 8 * swz(row, lch)), (lptr_t)(lds + a_off(0) + (w * JA + j) * 1024), 16,
+      __builtin_amdgcn_global_load_lds((gptr_t)(Qh + qa * d + 8 * swz(row, lch) + k0_), (lptr_t)(lds + a_off(0) + (w * JA + j) * 1024), 16,
                                        0, AUXA);
     }
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
       const int row = (w * JB + j) * RP + lrow_p;
       const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch)), (lptr_t)(lds + b_off(0) + (w * JB + j) * 1024), 16,
+      __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch) + k0_), (lptr_t)(lds + b_off(0) + (w * JB + j) * 1024), 16,
                                        0, AUXB);
     }
     if (NB == 3 && ntiles > 1) {
@@ -558,7 +580,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       for (int j = 0; j < JB; ++j) {
         const int row = (w * JB + j) * RP + lrow_p;
         const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch) + HBK),
+        __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch) + k1_),
                                          (lptr_t)(lds + b_off(1) + (w * JB + j) * 1024), 16, 0, AUXB);
       }
     }
@@ -573,7 +595,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     }
   };
   if (BIAS) load_cn(tn);
-  issue_head(tm, tn);
+  bool rev = PERSIST ? rev_of(seq) : false;   // (only the persistent walk has steps to alternate)
+  issue_head(tm, tn, rev);
   if (NB == 3 && ntiles > 1)
     wait_vm_lgkm0<JB>();
   else
@@ -617,7 +640,13 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // else would cover it): row tid's ||q||^2 and threshold, this lane's column norms
   static_assert(BM <= 64 * NW, "one thread per query row stages the epilogue's row record");
   float pre_q2 = 0.f, pre_thr = 0.f;
-  if (tid < BM && m0 + tid < M) {
+  if (EPI == 1) {   // wave-private epilogue: lane l stages row l of THIS wave's 64 query rows
+    const int64_t qrow = m0 + wm * (32 * TM) + l;
+    if (qrow < M) {
+      pre_q2 = qn[qrow];
+      pre_thr = thr[qrow * thr_ld];
+    }
+  } else if (tid < BM && m0 + tid < M) {
     pre_q2 = qn[m0 + tid];
     pre_thr = thr[(m0 + tid) * thr_ld];
   }
@@ -652,12 +681,12 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     if (ABL == 14 && piece >= JA) return;   // ablation: A only
     if (piece < JA) {
       if (kt + 1 < ntiles)
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[piece] + (kt + 1) * HBK),
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[piece] + kofs(rev, kt + 1)),
                                          (lptr_t)(lds + a_off(ia_next) + (w * JA + piece) * 1024), 16, 0, AUXA);
     } else {
       const int j = piece - JA;
       if (kt + BAHEAD < ntiles)
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + (kt + BAHEAD) * HBK),
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + kofs(rev, kt + BAHEAD)),
                                          (lptr_t)(lds + b_off(ib_next) + (w * JB + j) * 1024), 16, 0, AUXB);
     }
   };
@@ -897,6 +926,22 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     if (t == 12345.678f) cand_cnt[0] = 1;
     return;
   }
+  // The epilogue's row record {||q||^2, exact limit, screening bound} of this thread's row, in registers and BEFORE the next
+  // tile's head is requested: the compiler waits for the two global loads behind it (issued before the main loop, long
+  // since landed) with s_waitcnt vmcnt(0) at their first use -- placed behind the head's DMA instructions that wait sat out
+  // the head's whole flight (~2 us per tile, with nothing else to do: the very latency the early request is meant to hide).
+  //   v <= lim  <=>  acc - cn * half_scale >= (q2 - lim) * half_scale; the slack (relative 2^-17 of the largest possible
+  //   magnitude) makes rounding of this shortcut only ever ADD candidates
+  const float half_scale = 0.5f / inv_scale;
+  const float rmax_hs = rn_max * half_scale;
+  float st_q2 = 0.f, st_lim = -INFINITY, st_tau = INFINITY;
+  if (EPI == 1 ? (m0 + wm * (32 * TM) + l < M) : (tid < BM && m0 + tid < M)) {
+    st_q2 = pre_q2;
+    st_lim = pre_thr + eps_mult * c_eps * sqrtf(st_q2 * rn_max);
+    const float base = (st_q2 - st_lim) * half_scale;
+    st_tau = base - 7.7e-6f * (fabsf(base) + rmax_hs);
+  }
+  asm volatile("" : "+v"(st_q2), "+v"(st_lim), "+v"(st_tau));   // (keeps the computation -- and its wait -- on this side of the DMA issue)
   // PERSIST: the next tile of this workgroup; its head is requested now and lands under the epilogue
   int tm_next = 0, tn_next = 0, seq_next = seq_total;
   if (PERSIST) {
@@ -904,7 +949,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     while (seq_next < seq_total && !tile_of(seq_next, tm_next, tn_next)) seq_next += 32;
     if (seq_next < seq_total) {
       if (BIAS) load_cn(tn_next);
-      issue_head(tm_next, tn_next);
+      issue_head(tm_next, tn_next, rev_of(seq_next));
     }
   }
   // ---- epilogue: keep d2~ <= thr + eps_mult * eps(q) -----------------------------------------------------------
@@ -928,27 +973,122 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // records per wave: a quarter of its elements at most; PERSIST keeps the whole scratch inside LDS slots 0 and 1
   constexpr int LCAP = PERSIST ? 896 : ((TM * TN * 256 < 2048) ? TM * TN * 256 : 2048);
   static_assert(!PERSIST || (size_t)BM * 24 + (size_t)BN * 4 + (size_t)NW * (LCAP + 1) * 8 <= 2 * (size_t)PA, "epilogue scratch");
+  if constexpr (EPI == 1) {
+    // ---- wave-private epilogue (EPI = 1; persistent + biased kernels) ------------------------------------------------
+    // Nothing in it is shared between waves, so nothing in it waits for another wave: every wave stages the records of ITS
+    // 64 query rows, screens its 64 x 128 block into its own LDS list, tests the list densely and takes ONE returning global
+    // atomic per survivor (survivors are ~0.2 per row and tile: the per-row aggregation of EPI = 0 bought two workgroup
+    // barriers, an LDS atomic per survivor and a second walk of the list for nothing).  The ticket's round trip overlaps
+    // the wait for the next tile's head, which the wave has to sit out anyway; the stores are left in flight.  A block that
+    // fills its list (spatially coherent databases) flushes it and re-enters the screening pass where it stopped (a jump
+    // table: the 32 unrolled screening steps are the cases of a switch).
+    static_assert(PERSIST && BIAS && TM == 2 && TN == 4 && !ACC_A, "wave-private epilogue: 64 x 128 wave tiles of the biased persistent kernel");
+    constexpr int WSZ = (512 + 256 + (LCAP + 1) * 8 + 15) & ~15;
+    static_assert((size_t)NW * WSZ <= 2 * (size_t)PA, "epilogue scratch");
+    // Every LDS access between the head's DMA instructions and the wait inside the first flush is RAW (inline asm): the
+    // compiler cannot tell DMA'd LDS bytes from any other LDS address and puts s_waitcnt vmcnt(0) in front of every LDS
+    // instruction it can see while a DMA is pending -- the wave would sit out the head's flight before its first epilogue
+    // instruction (which is what EPI = 0 does).  One wave's LDS instructions execute in order, so a write followed by a read
+    // of the same bytes needs no wait in between; reads are waited for with explicit lgkmcnt.
+    const unsigned wb_a = (unsigned)(size_t)(lptr_t)(lds + (size_t)w * WSZ);   // [64] {||q||^2, exact limit} | +512: [64] screening
+    {                                                                          // bounds | +768: [LCAP + 1] hits {accumulator, row << 16 | column}
+      const float2 qr = make_float2(st_q2, st_lim);
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3 offset:512" ::"v"(wb_a + 8u * (unsigned)l), "v"(qr), "v"(wb_a + 4u * (unsigned)l), "v"(st_tau)
+                   : "memory");
+    }
+    SV_PHASE(2)
+    float4 tqw[2][4];
+    {
+      const unsigned ta = wb_a + 512u + 16u * (unsigned)kk;
+      asm volatile(
+          "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
+          "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\tds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(tqw[0][0]), "=&v"(tqw[0][1]), "=&v"(tqw[0][2]), "=&v"(tqw[0][3]), "=&v"(tqw[1][0]), "=&v"(tqw[1][1]), "=&v"(tqw[1][2]),
+            "=&v"(tqw[1][3])
+          : "v"(ta)
+          : "memory");
+    }
+    uint32_t wave_cnt = 0;   // wave-uniform
+    const uint32_t colbase = (uint32_t)(wn * (32 * TN) + i), rowsel = (uint32_t)(4 * kk);
+    const int64_t rowbase = m0 + wm * 64;
+    // dense exact test of the list: one returning global atomic per survivor, the stores left in flight
+    auto flush = [&]() {
+      const uint32_t n_w = wave_cnt;
+      bool first = true;
+      for (uint32_t tb = 0; first || tb < n_w; tb += 64u) {
+        const uint32_t t = tb + (uint32_t)l;
+        bool ok = false;
+        float v = 0.f;
+        int64_t row = 0;
+        uint32_t col = 0u;
+        if (t < n_w) {
+          uint2 rec;
+          float2 rr;
+          asm volatile("ds_read_b64 %0, %1 offset:768\n\ts_waitcnt lgkmcnt(0)" : "=v"(rec) : "v"(wb_a + 8u * t) : "memory");
+          const unsigned lrow = rec.y >> 16;
+          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(wb_a + 8u * lrow) : "memory");
+          v = __fmaf_rn(-2.f, __uint_as_float(rec.x) * inv_scale, rr.x);
+          ok = v <= rr.y && v < INFINITY;   // +inf: padding columns beyond N (admitted by the screen when thr = +inf)
+          row = rowbase + (int64_t)lrow;
+          col = rec.y & 0xffffu;
+        }
+        uint32_t slot = 0u;
+        if (ok) slot = atomicAdd(&cand_cnt[row], 1u);
+        // the ticket -- and, the first time round, this wave's DMA pieces of the next tile's head (requested before the
+        // screening pass; loads retire in order): the barrier at the top of the tile loop makes that true for every wave
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        first = false;
+        if (ok && slot < (uint32_t)cap) {
+          cand_d2[row * cap + slot] = v;
+          cand_id[row * cap + slot] = (uint32_t)((n0 + (int64_t)col) * b_stride);
+        }
+      }
+      wave_cnt = 0u;
+    };
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 tq4 = tqw[mt][r >> 2];
+        const float tau = (r & 3) == 0 ? tq4.x : (r & 3) == 1 ? tq4.y : (r & 3) == 2 ? tq4.z : tq4.w;
+        float best;
+        asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(acc[mt][0][r]), "v"(acc[mt][1][r]), "v"(acc[mt][2][r]));
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(acc[mt][3][r]));
+        if (__builtin_amdgcn_ballot_w64(best >= tau) != 0ull) {
+          const uint32_t rc = (((uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) + rowsel) << 16) | colbase;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const bool hit = acc[mt][nt][r] >= tau;
+            const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+            if (mk != 0ull) {
+              const uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+              if (hit) {
+                const uint2 rec = make_uint2(__float_as_uint(acc[mt][nt][r]), rc + (uint32_t)(nt * 32));
+                asm volatile("ds_write_b64 %0, %1 offset:768" ::"v"(wb_a + 8u * pos), "v"(rec) : "memory");
+              }
+              wave_cnt += (uint32_t)__popcll(mk);
+            }
+          }
+          // the next step could overflow the list (spatially coherent databases): flush it here and go on
+          if (wave_cnt > (uint32_t)(LCAP - 256)) flush();
+        }
+      }
+    SV_PHASE(3)
+    flush();
+    SV_PHASE(4)
+  }
+  if constexpr (EPI == 0) {
   float4* rrec = reinterpret_cast<float4*>(lds);                         // [BM] {||q||^2, exact limit, screening bound, -}
   uint32_t* rowcnt = reinterpret_cast<uint32_t*>(rrec + BM);             // [BM] survivors per row -> next free global slot
   float* cnl = reinterpret_cast<float*>(rowcnt + BM);                    // [BN] column norms
   float* taul = cnl + BN;                                                // [BM] screening bounds, contiguous (16-B reads)
   uint2* wlist = reinterpret_cast<uint2*>(taul + BM) + (size_t)w * (LCAP + 1);  // this wave's hit list (+1 dump slot)
-  const float half_scale = 0.5f / inv_scale;
-  const float rmax_hs = rn_max * half_scale;
   if (tid < BM) {
     const int j = tid;
-    float q2 = 0.f, lim = -INFINITY, tau = INFINITY;
-    if (m0 + j < M) {
-      q2 = pre_q2;
-      lim = pre_thr + eps_mult * c_eps * sqrtf(q2 * rn_max);
-      // v <= lim  <=>  acc - cn * half_scale >= (q2 - lim) * half_scale; the slack (relative 2^-17 of the largest
-      // possible magnitude) makes rounding of this shortcut only ever ADD candidates
-      const float base = (q2 - lim) * half_scale;
-      tau = base - 7.7e-6f * (fabsf(base) + rmax_hs);
-    }
-    rrec[j] = make_float4(q2, lim, tau, 0.f);
+    rrec[j] = make_float4(st_q2, st_lim, st_tau, 0.f);
     rowcnt[j] = 0u;
-    taul[j] = tau;
+    taul[j] = st_tau;
   }
   float cnh[TN];
 #pragma unroll
@@ -1100,16 +1240,18 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
   }
+  }   // EPI == 0
   SV_PHASE(5)  // reservation + pass 2b
   if (!PERSIST || seq_next >= seq_total) break;
   seq = seq_next;
   tm = tm_next;
   tn = tn_next;
+  rev = rev_of(seq);
   }   // tile loop
 }
 
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false>
+          bool BIAS = false, int EPI = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1123,11 +1265,14 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   int gm = ctx->opt.f16_gm >= 0 ? ctx->opt.f16_gm : (tiles_m >= 16 ? 8 : 4);
   if (PERSIST && gm <= 0) gm = 4;
   int seq_total = 0;
+  // tile walk of the persistent kernel (see the kernel): bit 0 = query-block-resident order, bit 1 = serpentine k
+  const int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 3) : 0) : 0;
   if (gm > 0) {
     gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
     while (gm > 1 && gm / 2 >= tiles_m) gm >>= 1;
     const int gn = 32 / gm;
-    const int64_t st = (int64_t)((tiles_m + gm - 1) / gm) * ((tiles_n + gn - 1) / gn);
+    int64_t st = (int64_t)((tiles_m + gm - 1) / gm) * ((tiles_n + gn - 1) / gn);
+    if (walk & 1) st = (int64_t)((tiles_m + gm - 1) / gm) * (((tiles_n + gn - 1) / gn + 7) / 8) * 8;   // per XCD: query blocks x its database blocks
     tiles = (st + 7) / 8 * 8 * 32;
     if (tiles / 8 > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
     seq_total = (int)(tiles / 8);
@@ -1141,11 +1286,11 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI>;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
-                     gm, seq_total, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap,
+                     gm, seq_total, walk, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap,
                      ctx->f16_scale_dev);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
@@ -1184,6 +1329,22 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 140: return launch_f16_filter<256, 256, 4, 2, 64, 3, 14>(SV_F16_ARGS);   // DMA only, A pieces only
     case 121: return launch_f16_filter<256, 256, 4, 2, 64, 3, 15>(SV_F16_ARGS);   // DMA only (no phase timing)
     case 160: return launch_f16_filter<256, 256, 4, 2, 64, 3, 16>(SV_F16_ARGS);   // DMA only, no epilogue
+    case 91:
+    case 92: {  // phase timing of the default batch kernel (persistent + ping-pong + bias), epilogue 0 / 1
+      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c8[8];
+      SV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sv_f16_phase_cycles), z, sizeof(z)));
+      ctx->f16_bias_ok = true;
+      const int rc = c == 91 ? launch_f16_filter<256, 256, 4, 2, 64, 3, 9, true, 0, 2, 0, true, 0>(SV_F16_ARGS)
+                             : launch_f16_filter<256, 256, 4, 2, 64, 3, 9, true, 0, 2, 0, true, 1>(SV_F16_ARGS);
+      SV_HIP(hipStreamSynchronize(ctx->stream));
+      SV_HIP(hipMemcpyFromSymbol(c8, HIP_SYMBOL(sv_f16_phase_cycles), sizeof(c8)));
+      double tot = 0;
+      for (int k = 0; k < 6; ++k) tot += (double)c8[k];
+      fprintf(stderr, "[f16 filter phases, cfg %d] M=%d n=%d: head-wait %.1f%% main %.1f%% stage %.1f%% pass1 %.1f%% pass2a %.1f%% rest %.1f%% (%.3g cycles/WG-sum)\n",
+              c, M, n_sample, 100 * c8[0] / tot, 100 * c8[1] / tot, 100 * c8[2] / tot, 100 * c8[3] / tot, 100 * c8[4] / tot,
+              100 * c8[5] / tot, tot);
+      return rc;
+    }
     case 90:
     case 120: {  // phase timing of config 0 (debug: synchronises and prints; 110 / 120 also ablate pass 1)
       unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c8[8];
@@ -1207,8 +1368,11 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 52: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 1>(SV_F16_ARGS);  // ping-pong, 1 phase per k-tile
     case 250:   // the default for batches: biased accumulators (see BIAS) when segvlad_search found the norms balanced enough
       if (!ctx->f16_bias_ok) goto unbiased_250;
-      if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
-        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true>(SV_F16_ARGS);        // persistent + ping-pong
+      if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024) {
+        if (ctx->opt.f16_epi == 0)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true>(SV_F16_ARGS);      // persistent + ping-pong
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1>(SV_F16_ARGS);     // + wave-private epilogue
+      }
       return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true>(SV_F16_ARGS);
     case 251:   // 250 without the bias (A/B; norms too unbalanced for the biased margin)
     unbiased_250:

@@ -243,7 +243,14 @@ def apply_pca_transform_from_pkl_numpy(data_np, pca_model_path):
 
 
 def normalizeFeat(rfts):
-    """func_vpr.py:1673-1676: returns a row-normalised COPY (the input is untouched); no epsilon."""
+    """func_vpr.py:1673-1676: returns a row-normalised COPY (the input is untouched); no epsilon; the result has the
+    input's floating type.
+
+    Deviation, on purpose: the reference divides in the input's own precision (fp64 descriptors stay fp64 until
+    faiss narrows them to fp32 inside ``index.add`` / ``search``, place_rec_main.py:53-60); here the rows are narrowed to
+    fp32 FIRST and normalised by the device kernel, and an fp64 input gets that fp32 result widened back.  The values
+    the search sees differ by one fp32 rounding of the norm (relative 6e-8), far inside the 1e-4 tolerance on the
+    similarities; what the caller gets back for fp64 input is fp32-accurate (1e-7), not fp64-accurate."""
     a = np.array(rfts).reshape([len(rfts), -1])
     out = engine().normalize_rows(np.ascontiguousarray(a, dtype=np.float32)).cpu().numpy()
     return out.astype(a.dtype if a.dtype in (np.float32, np.float64) else np.float64)

@@ -109,17 +109,19 @@ def default_dataset(name: str, width: int = 640, height: int = 480, mask_width: 
 
 
 def get_gt(dataset, cfg=None, workdir_data=None, ims1_r=None, ims2_q=None, func_vpr_module=None):
-    """The ground-truth rules that need no dataset files: 17places (gt.py:60-64: +-15 frames) and
-    AmsterTime (gt.py:66-69).  Everything else needs the dataset's own metadata (out of scope)."""
-    if dataset == "17places":
-        if ims2_q is None:
-            raise ValueError("ims2_q must be provided for the 17places dataset.")
-        loc_rad = 15
-        return [list(np.arange(i - loc_rad, i + loc_rad + 1)) for i in range(len(ims2_q))]
-    if dataset == "AmsterTime":
-        if ims1_r is None:
-            raise ValueError("ims1_r must be provided for the AmsterTime dataset.")
-        return [[i] for i in range(len(ims1_r))]
+    """The ground-truth rules that need no dataset files: 17places (gt.py:60-64: query frame i matches reference frames
+    i-15 .. i+15) and AmsterTime (gt.py:66-69: pair i matches pair i); VPAir reads its one metadata file.  Everything else
+    needs the dataset's own metadata (out of scope)."""
+    # (both rules only need the LENGTH of an image list; a missing list is the caller's error, as in gt.py)
+    rules = {"17places": ("ims2_q", ims2_q, 15), "AmsterTime": ("ims1_r", ims1_r, 0)}
+    if dataset in rules:
+        arg_name, images, radius = rules[dataset]
+        if images is None:
+            raise ValueError(f"{arg_name} is required for the {dataset} ground truth (frame i matches frames i-{radius}..i+{radius})")
+        window = np.arange(-radius, radius + 1)
+        # 17places: a list of numpy integers per query, out-of-range frames included (calc_recall only tests membership);
+        # AmsterTime: the plain index
+        return [list(i + window) if radius else [i] for i in range(len(images))]
     if dataset == "VPAir":
         # gt.py:71-73 -> dataloaders/vpair_dataloader.py:93-98: `vpair_gt.npy` holds, per query, a pair whose second
         # entry lists the soft-positive reference indices

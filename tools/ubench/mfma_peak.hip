@@ -72,9 +72,54 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, const unsigned c
   out[blockIdx.x * 512 + tid] = s;
 }
 
+// MODE 5: the same flops as MODE 0 through v_mfma_f32_16x16x32_f16 (4 x 4 accumulator tiles of 16 x 16; deeper k per
+// instruction: a quarter of the accumulator traffic per flop) -- does the power-limited rate depend on the MFMA shape?
+template <int RND>
+__global__ __launch_bounds__(512) void k16(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, l = tid & 63;
+  for (int j = tid; j < 65536 / 2; j += 512) {
+    unsigned h = (j * 2654435761u) ^ (blockIdx.x * 40503u);
+    h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    reinterpret_cast<_Float16*>(lds)[j] = RND ? (_Float16)(((int)(h & 2047) - 1024) * (1.f / 1024.f)) : (_Float16)(0.001f * (j & 15));
+  }
+  __syncthreads();
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc[4][4];
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+  f16x8 fa[4], fb[4];
+  const unsigned char* base = lds + (tid >> 6) * 8192 + l * 16;
+  for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const f16x8*>(base + t * 1024);
+  for (int t = 0; t < 4; ++t) fb[t] = *reinterpret_cast<const f16x8*>(base + 4096 + t * 1024);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 4; ++r) s += acc[a][b][r];
+  out[blockIdx.x * 512 + tid] = s;
+}
+template <int RND>
+void run16(const char* name, float* out, int iters, int blocks) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k16<RND>), dim3(blocks), dim3(512), 65536, 0, out, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k16<RND>), dim3(blocks), dim3(512), 65536, 0, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double flop = (double)blocks * 8 * iters * 16 * 16384.0;
+  printf("%-44s blocks=%d iters=%d: %.3f ms -> %.1f TFLOP/s\n", name, blocks, iters, ms, flop / ms / 1e9);
+}
+
 template <int MODE, int RND>
 void run(const char* name, float* out, int iters, int blocks, const unsigned char* src, size_t src_bytes, int foot = 0) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE, RND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const size_t ldsb = MODE >= 3 ? 65536 + 16384 : 65536;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -97,6 +142,7 @@ int main(int argc, char** argv) {
   for (int blocks : {256, 1024}) {
     run<0, 0>("mfma only (smooth data)", out, iters, blocks, src, src_bytes);
     run<0, 1>("mfma only (random data)", out, iters, blocks, src, src_bytes);
+    run16<1>("mfma 16x16x32 only (random data)", out, iters, blocks);
     run<1, 1>("mfma + 6 ds_read_b128 / 8 mfma (random)", out, iters, blocks, src, src_bytes);
     run<2, 1>("  + s_barrier / 32 mfma", out, iters, blocks, src, src_bytes);
     run<3, 1>("  + 8 DMA pieces / 32 mfma + vmcnt", out, iters, blocks, src, src_bytes);
