@@ -37,7 +37,11 @@ void sv_begin(segvlad_ctx* ctx) {
 }
 
 static DevBuf* next_stage(segvlad_ctx* ctx) {
-  if (ctx->stage_used >= (int)ctx->stage.size()) ctx->stage.resize(ctx->stage_used + 1);
+  if (ctx->stage_used >= (int)ctx->stage.size()) {
+    ctx->stage.resize(ctx->stage_used + 1);
+    ctx->stage.back().tag = "stage";
+    ctx->stage.back().guard = ctx->guard;
+  }
   return &ctx->stage[ctx->stage_used++];
 }
 
@@ -76,6 +80,66 @@ int sv_finish(segvlad_ctx* ctx) {
     SV_HIP(hipStreamSynchronize(ctx->stream));
     ctx->pending_out.clear();
   }
+  if (ctx->guard) return sv_guard_check(ctx);
+  return SEGVLAD_OK;
+}
+
+// ---- guard mode (ctx.h: DevBuf) -----------------------------------------------------------------------------------
+static hipError_t guard_fill(void* at) { return hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(at), (int)SV_GUARD_WORD, SV_GUARD_BYTES / 4); }
+
+// number of fence words that no longer hold the poison (0 = intact); < 0: a HIP error
+static int guard_words_hit(const void* at) {
+  uint32_t h[SV_GUARD_BYTES / 4];
+  if (hipMemcpy(h, at, SV_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  int bad = 0;
+  for (uint32_t w : h) bad += (w != SV_GUARD_WORD);
+  return bad;
+}
+
+hipError_t DevBuf::reserve_guarded(size_t bytes) {
+  // every earlier user of this buffer has finished (the fence may move INTO bytes an earlier, larger request used)
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return e;
+  if (!raw || bytes > cap) {
+    // (a trampled fence of the old allocation is caught by the check at the end of the call that trampled it)
+    if (raw) {
+      e = hipFree(raw);
+      if (e != hipSuccess) return e;
+      raw = nullptr;
+      p = nullptr;
+      cap = 0;
+    }
+    const size_t want = (bytes + 15) & ~(size_t)15;   // exact: no slack to absorb an overrun
+    e = hipMalloc(&raw, want + 2 * SV_GUARD_BYTES);
+    if (e != hipSuccess) return e;
+    p = static_cast<unsigned char*>(raw) + SV_GUARD_BYTES;
+    cap = want;
+    req = cap;   // (where the back fence of a `fixed` buffer goes, and stays)
+    e = guard_fill(raw);
+    if (e == hipSuccess) e = guard_fill(static_cast<unsigned char*>(p) + cap);
+    if (e != hipSuccess) return e;
+  }
+  if (!fixed) {
+    req = bytes;
+    e = guard_fill(static_cast<unsigned char*>(p) + fence_off());
+  }
+  return e;
+}
+
+int sv_guard_check(segvlad_ctx* ctx) {
+  if (!ctx->guard) return SEGVLAD_OK;
+  SV_HIP(hipDeviceSynchronize());
+  if (!ctx->guard_hit[0]) {
+    ctx->for_each_buf([&](DevBuf& b) {
+      if (!b.raw || ctx->guard_hit[0]) return;
+      const int front = guard_words_hit(b.raw), back = guard_words_hit(static_cast<unsigned char*>(b.p) + b.fence_off());
+      if (front)
+        snprintf(ctx->guard_hit, sizeof(ctx->guard_hit), "%s: %d words written BELOW the buffer", b.tag, front);
+      else if (back)
+        snprintf(ctx->guard_hit, sizeof(ctx->guard_hit), "%s: %d words written beyond the %zu bytes requested", b.tag, back, b.fixed ? b.cap : b.req);
+    });
+  }
+  if (ctx->guard_hit[0]) return ctx->fail(SEGVLAD_ERR_STATE, "guard: out-of-bounds write, buffer %s", ctx->guard_hit);
   return SEGVLAD_OK;
 }
 
@@ -136,6 +200,18 @@ int segvlad_create(segvlad_ctx** out, int device_id) {
                                             {"SEGVLAD_KNN_HEURISTIC", "knn_heuristic"}, {"SEGVLAD_PCA_PATH", "pca_path"}};
   for (auto& kv : env_keys)
     if (const char* v = getenv(kv[0])) (void)segvlad_set_option(c, kv[1], v);
+#define SV_TAG_P(n) c->n.tag = #n; c->n.fixed = true;
+#define SV_TAG_S(n) c->n.tag = #n;
+  SV_PERSISTENT_BUFS(SV_TAG_P)
+  SV_SCRATCH_BUFS(SV_TAG_S)
+#undef SV_TAG_P
+#undef SV_TAG_S
+  if (const char* v = getenv("SEGVLAD_GUARD")) {
+    if (v[0] && v[0] != '0') {
+      c->guard = true;
+      c->for_each_buf([](DevBuf& b) { b.guard = true; });
+    }
+  }
   if (const char* v = getenv("SEGVLAD_RCCL_LIB")) snprintf(sv_rccl_lib_override, sizeof(sv_rccl_lib_override), "%s", v);
   if (getenv("SEGVLAD_KNN_FP32")) (void)segvlad_set_option(c, "knn_filter", "fp32");
   if (getenv("SEGVLAD_PCA_FP32")) (void)segvlad_set_option(c, "pca_arith", "fp32");
@@ -180,6 +256,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "f16_gm")) return as_int(&o.f16_gm);
   if (!strcmp(key, "f16_walk")) return as_int(&o.f16_walk);
   if (!strcmp(key, "f16_epi")) return as_int(&o.f16_epi);
+  if (!strcmp(key, "f16_mf")) return as_int(&o.f16_mf);
   if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);
   if (!strcmp(key, "x3_gm")) return as_int(&o.x3_gm);
   if (!strcmp(key, "search_stats")) return as_int(&o.search_stats);
@@ -189,6 +266,22 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "pj_nw")) return as_int(&o.pj_nw);
   if (!strcmp(key, "small_plan")) return as_int(&o.small_plan);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
+  if (!strcmp(key, "guard_undersize")) {
+    // tests of the guard itself: "<buffer tag>:<bytes>" puts that scratch buffer's back fence <bytes> EARLY from its next
+    // reserve() on, so that a correct kernel writes into the fence (guard mode only; "" / "none" clears every shrink)
+    if (!ctx->guard) return ctx->fail(SEGVLAD_ERR_STATE, "set_option(guard_undersize): the context was not created under SEGVLAD_GUARD=1");
+    const char* colon = strchr(value, ':');
+    bool found = false;
+    ctx->for_each_buf([&](DevBuf& b) {
+      if (!colon) b.shrink = 0;
+      else if (strlen(b.tag) == (size_t)(colon - value) && !strncmp(b.tag, value, (size_t)(colon - value))) {
+        b.shrink = atoi(colon + 1);
+        found = true;
+      }
+    });
+    if (colon && !found) return ctx->fail(SEGVLAD_ERR_ARG, "set_option(guard_undersize): no buffer named like '%s'", value);
+    return SEGVLAD_OK;
+  }
   return ctx->fail(SEGVLAD_ERR_ARG, "set_option: unknown key '%s'", key);
 }
 
@@ -206,20 +299,7 @@ int segvlad_destroy(segvlad_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   sv_comm_release(ctx);
-  DevBuf* bufs[] = {&ctx->vocab,    &ctx->vocab_bt, &ctx->pca_mean, &ctx->pca_comps, &ctx->pca_scale, &ctx->db_rows,
-                    &ctx->db_norms, &ctx->db_img,   &ctx->s_xt,     &ctx->s_labels,  &ctx->s_rnorm,   &ctx->s_gap,
-                    &ctx->s_colmask, &ctx->s_gscale, &ctx->s_segimg, &ctx->s_segoff, &ctx->s_adjoff,  &ctx->s_dist,
-                    &ctx->s_qnorm,  &ctx->s_misc,   &ctx->s_minmax, &ctx->s_voteoff, &ctx->s_cand_cnt, &ctx->s_cand_d2,
-                    &ctx->s_cand_id, &ctx->s_thr_d2, &ctx->s_thr_idx, &ctx->s_flag,   &ctx->s_qh,     &ctx->s_ql,
-                    &ctx->s_ref_cnt, &ctx->s_ref_id, &ctx->db_hi,     &ctx->db_lo,    &ctx->db_f16,   &ctx->s_qf16,
-                    &ctx->pca_w1,    &ctx->pca_w2,   &ctx->s_xh1,     &ctx->s_xh2,    &ctx->s_desc,   &ctx->s_tokorder,
-                    &ctx->s_laboff,  &ctx->s_rnsorted, &ctx->s_ovf,   &ctx->s_fb_q,   &ctx->s_fb_d2,  &ctx->s_fb_idx,
-                    &ctx->s_fb_rows, &ctx->s_rd_rows, &ctx->s_rd_q,   &ctx->s_rd_d2,  &ctx->s_rd_idx, &ctx->s_rd_flags,
-                    &ctx->s_rd_p1,   &ctx->s_rd_p2,   &ctx->s_sel_todo, &ctx->s_vote_keys, &ctx->s_pz, &ctx->s_rowbase,
-                    &ctx->s_tilegrp, &ctx->s_bn,      &ctx->pca_cproj, &ctx->s_l0part, &ctx->s_ref_lim,
-                    &ctx->s_sh_d2,   &ctx->s_sh_idx,  &ctx->s_sh_rec,  &ctx->s_sh_all,  &ctx->s_sh_d2c, &ctx->s_sh_idc, &ctx->s_ref_keys, &ctx->s_ref_tick, &ctx->s_qscale};
-  for (DevBuf* b : bufs) b->release();
-  for (auto& b : ctx->stage) b.release();
+  ctx->for_each_buf([](DevBuf& b) { b.release(); });
   for (auto& kv : ctx->timers)
     for (hipEvent_t e : kv.second.ev)
       if (e) (void)hipEventDestroy(e);
@@ -238,7 +318,7 @@ int segvlad_set_stream(segvlad_ctx* ctx, void* hip_stream) {
 int segvlad_synchronize(segvlad_ctx* ctx) {
   CHECK_CTX();
   SV_HIP(hipStreamSynchronize(ctx->stream));
-  return SEGVLAD_OK;
+  return sv_guard_check(ctx);   // (guard mode only: SEGVLAD_ERR_STATE if a buffer's fence has been written)
 }
 
 int segvlad_set_profiling(segvlad_ctx* ctx, int on) {
@@ -772,6 +852,9 @@ int segvlad_db_add(segvlad_ctx* ctx, const float* R, int n, int d, const int32_t
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
     if (new_bytes <= b.cap) return hipSuccess;
     DevBuf nb;
+    nb.tag = b.tag;
+    nb.guard = b.guard;
+    nb.fixed = b.fixed;
     hipError_t e = nb.reserve(new_bytes + new_bytes / 2);
     if (e != hipSuccess) return e;
     if (old_bytes) {
@@ -932,6 +1015,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     rovf_rows = rovf_rows_in;
     ref_lim = ctx->s_ref_lim.as<float>();
   }
+  const uint32_t* poison_dev = nullptr;   // see sv_launch_refine_exact
   const int r0 = rank[0];
   {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
@@ -1007,7 +1091,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
         sc.count();
         if (last) {
           SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP,
-                                        k, out_d2, out_idx));
+                                        k, out_d2, out_idx, nullptr, fail_rows, fail_count, &poison_dev));
           sc.count();
         }
       }   // (the stage's stop event is recorded before the host waits below)
@@ -1015,9 +1099,11 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
         // one read-back per chunk: rows flagged for the redo / matrix-path fallback (handled by the caller) and rows whose
         // refine band outgrew the first-tier list.  The latter are refined here, straight from their candidate lists,
         // which the next chunk would overwrite.
-        uint32_t h_cnt[2] = {0, 0};
+        uint32_t h_cnt[2] = {0, 0}, h_poison = 0;
         SV_HIP(hipMemcpyAsync(&h_cnt[0], fail_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (poison_dev) SV_HIP(hipMemcpyAsync(&h_poison, poison_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
         SV_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_poison) SV_TRY(sv_refine_small_repair(ctx));   // a checked hand-over failed (its rows are flagged): fresh buffers
         if (n_fail_host) *n_fail_host = h_cnt[0];
         const uint32_t seen = n_rovf_seen ? *n_rovf_seen : 0u;
         if (n_rovf_seen) *n_rovf_seen = h_cnt[1];
@@ -1191,6 +1277,9 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   auto grow = [&](DevBuf& b, size_t old_bytes, size_t new_bytes) -> hipError_t {
     if (new_bytes <= b.cap) return hipSuccess;
     DevBuf nb;
+    nb.tag = b.tag;
+    nb.guard = b.guard;
+    nb.fixed = b.fixed;
     hipError_t e = nb.reserve(new_bytes + new_bytes / 4);
     if (e != hipSuccess) return e;
     if (old_bytes) {

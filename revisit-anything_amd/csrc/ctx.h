@@ -49,10 +49,28 @@ inline size_t sv_x3_off(int64_t row, int64_t k, int64_t Kd) {
 inline int64_t sv_x3_rows(int64_t n) { return (n + 255) & ~255ll; }
 
 // grow-only device buffer
+//
+// Guard mode (SEGVLAD_GUARD=1 at segvlad_create; development / test runs): every buffer sits between two fences of
+// SV_GUARD_BYTES poison bytes.  A grow-only buffer hides under-sized requests -- a request that an earlier, larger one
+// already covers never fails (round 3 found a real out-of-bounds write that way, only on a fresh context) -- so in guard
+// mode the BACK fence of a per-call scratch buffer sits right behind the bytes of the CURRENT request (re-placed by every
+// reserve(), after a device synchronisation), and every API call ends with a check of all fences (sv_finish;
+// segvlad_synchronize): a trampled fence fails the call with SEGVLAD_ERR_STATE and names the buffer.  Buffers whose
+// contents outlive a call (`fixed`: database, models, the refinement's hand-over words) keep their back fence at the end
+// of the allocation.
+constexpr size_t SV_GUARD_BYTES = 1024;
+constexpr uint32_t SV_GUARD_WORD = 0xA5C3F00Du;
 struct DevBuf {
   void* p = nullptr;
-  size_t cap = 0;
+  size_t cap = 0;          // usable bytes behind p
+  const char* tag = "";
+  bool guard = false;      // set by segvlad_create for every buffer of a guarded context
+  bool fixed = false;      // guard mode: contents persist across calls -> the back fence stays at p + cap
+  void* raw = nullptr;     // guard mode: the allocation (front fence | cap bytes | back fence)
+  size_t req = 0;          // guard mode: bytes of the current request (the back fence starts at p + round_up(req, 4))
+  int shrink = 0;          // guard mode, tests only (option "guard_undersize"): the fence is placed `shrink` bytes EARLY
   hipError_t reserve(size_t bytes) {
+    if (guard) return reserve_guarded(bytes);
     if (bytes <= cap) return hipSuccess;
     if (p) {
       hipError_t e = hipFree(p);
@@ -66,10 +84,15 @@ struct DevBuf {
     cap = want;
     return hipSuccess;
   }
+  hipError_t reserve_guarded(size_t bytes);   // api.hip
+  size_t fence_off() const { return fixed ? cap : ((req > (size_t)shrink ? req - (size_t)shrink : 0) + 3) & ~(size_t)3; }
   void release() {
-    if (p) (void)hipFree(p);
+    if (raw) (void)hipFree(raw);
+    else if (p) (void)hipFree(p);
+    raw = nullptr;
     p = nullptr;
     cap = 0;
+    req = 0;
   }
   template <class T>
   T* as() { return reinterpret_cast<T*>(p); }
@@ -94,6 +117,7 @@ struct SvOptions {
   int f16_walk = -1;      // tile walk of the persistent fp16 filter: bit 0 = an XCD keeps its block of query tiles while it steps
                           // through the database blocks, bit 1 = odd steps run their k-tiles backwards (-1 = default, see
                           // launch_f16_filter); never changes a result
+  int f16_mf = -1;        // MFMA shape of the persistent biased fp16 filter: 0 = 32 x 32 x 16, otherwise 16 x 16 x 32 (needs f16_epi != 0)
   int f16_epi = -1;       // epilogue of the persistent biased fp16 filter: 0 = workgroup-level reservation (one global atomic per
                           // row and tile, two workgroup barriers), 1 = wave-private (one global atomic per survivor, no barrier)
   int x3_tile = 0;        // PCA split GEMM tile (0 = from the shape, 128, 256)
@@ -162,28 +186,16 @@ struct segvlad_ctx {
   // vocabulary
   int K = 0, D = 0, Kpad = 0;
   float vocab_maxabs = 0.f;   // max |C_kd| (set_vocab): scale of the residual planes of the "project" form
-  DevBuf vocab;      // [K][D] raw centres
-  DevBuf vocab_bt;   // normalised centres in MFMA-B order [D/2][Kpad/32][64]
-
   // PCA model
   int P = 0, KD = 0, whiten = 0;
-  DevBuf pca_mean, pca_comps, pca_scale;  // scale = 1/sqrt(var) or 1
-  DevBuf pca_w1, pca_w2;                  // fp16 two-term split of comps * pca_w_scale (16-bit MFMA path)
   float pca_w_scale = 0.f, pca_mean_maxabs = 0.f;
-  DevBuf pca_cproj;                       // [P]: W mean ("project then aggregate"); rebuilt when stale
   bool pca_cproj_valid = false;           // cleared by segvlad_pca_set
-
   // database (exact kNN)
   int db_d = 0;
   int64_t db_n = 0;
-  DevBuf db_rows, db_norms, db_img;
   bool db_has_img = false;
-  // bf16 hi/lo planes of the rows (built lazily for the large-database search path) + max row norm^2
-  DevBuf db_hi, db_lo;
-  int64_t db_split_rows = 0;
-  // fp16 image of the rows, scaled by a power of two (single-product filter)
-  DevBuf db_f16;
-  int64_t db_f16_rows = 0;
+  int64_t db_split_rows = 0;              // rows covered by the bf16 hi/lo planes (built lazily for the large-database search path)
+  int64_t db_f16_rows = 0;                // rows covered by the fp16 image of the rows, scaled by a power of two (single-product filter)
   float db_f16_scale = 0.f, db_maxabs = 0.f;
   float db_rn_max = 0.f;
   int64_t db_rn_max_rows = 0;
@@ -191,16 +203,40 @@ struct segvlad_ctx {
   const float* f16_scale_dev = nullptr;   // set by segvlad_search for the duration of a single-image search (see above)
   bool db_heur_off = false;   // set when > 25 % of a search's queries needed the rigorous redo (until the index changes)
 
-  // scratch (grow-only, reused across calls)
-  DevBuf s_xt, s_labels, s_rnorm, s_gap, s_colmask, s_gscale, s_segimg, s_segoff, s_adjoff;
-  DevBuf s_dist, s_qnorm, s_misc, s_minmax, s_voteoff, s_cand_cnt, s_cand_d2, s_cand_id, s_thr_d2, s_thr_idx, s_flag,
-      s_qh, s_ql, s_ref_cnt, s_ref_id, s_ref_keys, s_ref_tick, s_qscale, s_qf16, s_xh1, s_xh2, s_desc, s_tokorder, s_laboff, s_rnsorted, s_ovf, s_fb_q, s_fb_d2,
-      s_fb_idx, s_fb_rows, s_rd_rows, s_rd_q, s_rd_d2, s_rd_idx, s_rd_flags, s_rd_p1, s_rd_p2, s_sel_todo, s_vote_keys, s_pz, s_rowbase, s_tilegrp, s_bn, s_l0part,
-      s_ref_lim;
-  // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time, the exchange buffers
+  // Device buffers, as X-macro lists (segvlad_create tags them, segvlad_destroy releases them, guard mode walks them).
+  //  persistent: contents outlive a call -- vocab: [K][D] raw centres; vocab_bt: normalised centres in MFMA-B order
+  //  [D/2][Kpad/32][64]; pca_scale = 1/sqrt(var) or 1; pca_w1 / pca_w2: fp16 two-term split of comps * pca_w_scale (16-bit MFMA
+  //  path); pca_cproj: [P] W mean ("project then aggregate"; rebuilt when stale); db_hi / db_lo / db_f16: 16-bit images of the rows;
+  //  s_ref_keys / s_ref_tick: hand-over words of refine_exact_small_kernel (all ones / all zero between launches)
+#define SV_PERSISTENT_BUFS(X)                                                                                                    \
+  X(vocab) X(vocab_bt) X(pca_mean) X(pca_comps) X(pca_scale) X(pca_w1) X(pca_w2) X(pca_cproj) X(db_rows) X(db_norms) X(db_img)    \
+  X(db_hi) X(db_lo) X(db_f16) X(s_ref_keys) X(s_ref_tick)
+  //  scratch: grow-only, reused across calls, nothing in them is read after the call that wrote it; s_sh_*: exchange buffers of
+  //  the row-sharded index (comm.hip)
+#define SV_SCRATCH_BUFS(X)                                                                                                       \
+  X(s_xt) X(s_labels) X(s_rnorm) X(s_gap) X(s_colmask) X(s_gscale) X(s_segimg) X(s_segoff) X(s_adjoff) X(s_dist) X(s_qnorm)      \
+  X(s_misc) X(s_minmax) X(s_voteoff) X(s_cand_cnt) X(s_cand_d2) X(s_cand_id) X(s_thr_d2) X(s_thr_idx) X(s_flag) X(s_qh) X(s_ql)  \
+  X(s_ref_cnt) X(s_ref_id) X(s_qscale) X(s_qf16) X(s_xh1) X(s_xh2) X(s_desc) X(s_tokorder) X(s_laboff) X(s_rnsorted) X(s_ovf)     \
+  X(s_fb_q) X(s_fb_d2) X(s_fb_idx) X(s_fb_rows) X(s_rd_rows) X(s_rd_q) X(s_rd_d2) X(s_rd_idx) X(s_rd_flags) X(s_rd_p1) X(s_rd_p2)  \
+  X(s_sel_todo) X(s_vote_keys) X(s_pz) X(s_rowbase) X(s_tilegrp) X(s_bn) X(s_l0part) X(s_ref_lim) X(s_sh_d2) X(s_sh_idx)          \
+  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc)
+#define SV_DECL_BUF(n) DevBuf n;
+  SV_PERSISTENT_BUFS(SV_DECL_BUF)
+  SV_SCRATCH_BUFS(SV_DECL_BUF)
+#undef SV_DECL_BUF
+  template <class F>
+  void for_each_buf(F&& f) {
+#define SV_VISIT_BUF(n) f(n);
+    SV_PERSISTENT_BUFS(SV_VISIT_BUF)
+    SV_SCRATCH_BUFS(SV_VISIT_BUF)
+#undef SV_VISIT_BUF
+    for (auto& b : stage) f(b);
+  }
+  bool guard = false;          // SEGVLAD_GUARD=1 at segvlad_create
+  char guard_hit[96] = {0};    // sticky: the first trampled fence found (buffer tag and which fence)
+  // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time
   void* comm = nullptr;   // ncclComm_t
   int comm_rank = 0, comm_world = 1;
-  DevBuf s_sh_d2, s_sh_idx, s_sh_rec, s_sh_all, s_sh_d2c, s_sh_idc;
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
@@ -224,8 +260,11 @@ bool sv_is_device_ptr(const void* p);
 int sv_in(segvlad_ctx* ctx, const void* p, size_t bytes, const void** dev);
 // returns a device pointer to write into; if p is host memory the D2H copy happens in sv_finish()
 int sv_out(segvlad_ctx* ctx, void* p, size_t bytes, void** dev);
-// flushes pending host outputs (synchronises the stream only if there are any) and resets staging
+// flushes pending host outputs (synchronises the stream only if there are any) and resets staging; guard mode: also
+// synchronises and checks every fence
 int sv_finish(segvlad_ctx* ctx);
+// guard mode: SEGVLAD_ERR_STATE if any fence of the context's buffers has been written (synchronises the device)
+int sv_guard_check(segvlad_ctx* ctx);
 void sv_begin(segvlad_ctx* ctx);
 
 struct StageScope {
@@ -302,9 +341,15 @@ int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, const float* c
 int sv_launch_refine2_compact(segvlad_ctx* ctx, const uint32_t* rovf_rows, const float* ref_lim, uint32_t* cand_cnt,
                               const float* cand_d2, uint32_t* cand_id, int nq, int cap);
 // only_rows != null: rows whose flag is clear are skipped (their outputs stay as they are)
+// fail_rows / fail_count / poison_dev (optional): the single-image refinement hands keys between workgroups through global
+// memory and CHECKS the hand-over (refine_exact_small_kernel): a query whose keys did not all arrive is flagged there like
+// a failed threshold check, and *poison_dev (set to a device word when that kernel ran, else to null) is non-zero afterwards;
+// the caller then calls sv_refine_small_repair before the buffers' next use.
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
-                           const uint32_t* only_rows = nullptr);
+                           const uint32_t* only_rows = nullptr, uint32_t* fail_rows = nullptr, uint32_t* fail_count = nullptr,
+                           const uint32_t** poison_dev = nullptr);
+int sv_refine_small_repair(segvlad_ctx* ctx);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);

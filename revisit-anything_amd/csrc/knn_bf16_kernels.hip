@@ -289,6 +289,7 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
 // The margin is ~24x wider than bf16x3's, which lets ~1.3-1.4x more candidates through (they are cheap: the
 // exact refinement only sees the ~k survivors) for one third of the MFMA work.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
@@ -473,8 +474,14 @@ __device__ __forceinline__ float acc_elem(const f32x16& v, int r) {
 //      seven VALU instructions per four elements) disappears; d2~ = ||q||^2 - 2 acc / scale.  The column norms are fetched
 //      ahead of the tile (before the head DMA; PERSIST: before the previous tile's epilogue).  The running sums are up to
 //      1.5 x larger in magnitude, which sv_f16_c_eps accounts for.
+// EPI : epilogue.  0 = workgroup-level (one global atomic per row and tile); 1 = wave-private (see the epilogue)
+// MF  : MFMA shape.  0 = v_mfma_f32_32x32x16_f16 (wave tile = TM x TN tiles of 32 x 32); 1 = v_mfma_f32_16x16x32_f16 (the same
+//      64 x 128 wave tile as 4 x 8 tiles of 16 x 16, a k-step of 32): the same flops, LDS fragment bytes and accumulator
+//      registers, but a QUARTER of the accumulator read-modify-write traffic per flop inside the matrix pipe.  The chip is
+//      power-limited on this kernel (tools/ubench/mfma_peak: random operands sustain 1.71-1.76 PF in the 32 x 32 x 16 shape
+//      and 1.92-2.01 PF in the 16 x 16 x 32 shape, MFMA only), so the shape that needs less energy per flop is the faster one.
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total, int walk,
@@ -586,11 +593,15 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     }
   };
   // BIAS: this lane's column norms of the (next) tile, requested BEFORE the tile's head so that the head's wait covers them
-  float cnn[TN];
+  static_assert(MF == 0 || (PP > 0 && BIAS && EPI == 1 && BM / (32 * WM) == 2 && BN / (32 * WN) == 4 && HBK == 64 && KBT == 0),
+                "16 x 16 x 32 MFMA: the biased ping-pong kernel with the wave-private epilogue, 64 x 128 wave tiles");
+  constexpr int CW = MF ? 16 : 32;                    // columns (and rows) per MFMA tile
+  constexpr int NCN = (BN / WN) / CW;                 // column tiles per wave = column norms per lane
+  float cnn[NCN];
   auto load_cn = [&](int tn_) {
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-      const int64_t colj = (int64_t)tn_ * BN + wn * (32 * TN) + nt * 32 + (threadIdx.x & 31);
+    for (int nt = 0; nt < NCN; ++nt) {
+      const int64_t colj = (int64_t)tn_ * BN + wn * (32 * TN) + nt * CW + (threadIdx.x & (CW - 1));
       cnn[nt] = (colj < N) ? rn[colj * b_stride] : INFINITY;  // +inf: columns beyond N never pass
     }
   };
@@ -612,20 +623,32 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   const int tid = lane_opaque, l = tid & 63, i = l & 31, kk = l >> 5;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
-  float cn[TN];
+  float cn[NCN];
   if (BIAS) {
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) cn[nt] = cnn[nt];
+    for (int nt = 0; nt < NCN; ++nt) cn[nt] = cnn[nt];
   }
-  f32x16 acc[TM][TN];
+  f32x16 acc[MF ? 1 : TM][MF ? 1 : TN];
+  f32x4v acc16[MF ? 4 : 1][MF ? 8 : 1];   // MF = 1: element j of tile (mt, nt) = row mt*16 + 4*(lane>>4) + j, column nt*16 + (lane&15)
+  if constexpr (MF == 0) {
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const float a0_ = BIAS ? -(cn[b] * (0.5f / inv_scale)) : 0.f;   // (the same product the epilogue forms: cnh)
+      for (int b = 0; b < TN; ++b) {
+        const float a0_ = BIAS ? -(cn[b] * (0.5f / inv_scale)) : 0.f;   // (the same product the epilogue forms: cnh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = a0_;
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = a0_;
+      }
+  } else {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const float a0_ = -(cn[b] * (0.5f / inv_scale));
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[a][b][r] = a0_;
     }
+  }
   f32x16 accb[KBT > 0 ? TM : 1][KBT > 0 ? TN : 1];   // blocked accumulation: the sum of the finished k-blocks
   if (KBT > 0) {
 #pragma unroll
@@ -650,7 +673,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     pre_q2 = qn[m0 + tid];
     pre_thr = thr[(m0 + tid) * thr_ld];
   }
-  if (!BIAS) {
+  if constexpr (!BIAS) {
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
       const int64_t colj = n0 + wn * (32 * TN) + nt * 32 + i;
@@ -694,7 +717,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 
   int ia = 0, ib = 0;
   const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
-  if (PP > 0) {
+  if constexpr (PP > 0) {
     constexpr int PPn = PP > 0 ? PP : 1;
     constexpr int PH = KS / PPn;            // MFMA k-steps per phase
     constexpr int DPP = (JA + JB) / PPn;    // DMA pieces per phase and wave
@@ -708,19 +731,37 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
       for (int ph = 0; ph < PPn; ++ph) {
         // ---- load segment: fragments of this phase's k-steps, this phase's share of the DMA pieces ----
-        f16x8 a[PH][TM], b[PH][TN];
+        f16x8 a[MF ? 1 : PH][MF ? 4 : TM], b[MF ? 1 : PH][MF ? 8 : TN];
+        if constexpr (MF == 0) {
 #pragma unroll
-        for (int k2 = 0; k2 < PH; ++k2) {
-          const int cl = 2 * (ph * PH + k2) + kk;
+          for (int k2 = 0; k2 < PH; ++k2) {
+            const int cl = 2 * (ph * PH + k2) + kk;
 #pragma unroll
-          for (int t = 0; t < TM; ++t) {
-            const int ra = fa0 + 32 * t;
-            a[k2][t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
+            for (int t = 0; t < TM; ++t) {
+              const int ra = fa0 + 32 * t;
+              a[k2][t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+              const int rb = fb0 + 32 * t;
+              b[k2][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
+            }
+          }
+        } else {
+          // one k-step of 32 per phase: lane l holds row / column (l & 15) of a 16-wide tile, k-chunk (l >> 4) of the step's four
+          // (the source-side swizzle of the 128-byte rows is conflict-free for this pattern too: a 16-lane ds_read_b128 group
+          //  covers rows {0-3, 12-15} of one chunk and rows {4-11} of the next, 16 distinct bank groups)
+          static_assert(MF == 0 || (PH == 2 && CH == 8), "a phase = 32 k of 128-byte rows");
+          const int cl = 4 * ph + (l >> 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int ra = wm * 64 + 16 * t + (l & 15);
+            a[0][t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
           }
 #pragma unroll
-          for (int t = 0; t < TN; ++t) {
-            const int rb = fb0 + 32 * t;
-            b[k2][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
+          for (int t = 0; t < 8; ++t) {
+            const int rb = wn * 128 + 16 * t + (l & 15);
+            b[0][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
           }
         }
 #pragma unroll
@@ -741,12 +782,20 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA segment ----
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MF == 0) {
 #pragma unroll
-        for (int k2 = 0; k2 < PH; ++k2)
+          for (int k2 = 0; k2 < PH; ++k2)
 #pragma unroll
-          for (int mt = 0; mt < TM; ++mt)
+            for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a[k2][mt], b[k2][nt], acc[mt][nt]);
+              for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a[k2][mt], b[k2][nt], acc[mt][nt]);
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+              acc16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][mt], b[0][nt], acc16[mt][nt], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -756,7 +805,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       ib = (ib + 1 >= NB) ? 0 : ib + 1;
     }
     if (!lag) __builtin_amdgcn_s_barrier();  // the leading half waits for the lagging half's last MFMA segment
-  } else if (PP < 0) {
+  } else if constexpr (PP < 0) {
     // One wave per SIMD (4 waves of 128 x 128: 0.5 LDS fragment reads per MFMA instead of 0.75): nothing else hides a
     // wave's LDS latency, so the loop is software-pipelined -- the fragments of k-step s+1 are read (into the other half
     // of a register double buffer) before the MFMAs of step s are issued, and the ONE barrier of a k-tile sits before
@@ -918,10 +967,17 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   if ((ABL >= 1 && ABL <= 3) || ABL == 16) {  // ablation: no epilogue (accumulators stay live; 16: DMA skeleton only)
     float t = 0.f;
     if (ABL != 16) {
+      if constexpr (MF == 0) {
 #pragma unroll
-      for (int mt = 0; mt < TM; ++mt)
+        for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) t += acc[mt][nt][0] + acc[mt][nt][15];
+          for (int nt = 0; nt < TN; ++nt) t += acc[mt][nt][0] + acc[mt][nt][15];
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) t += acc16[mt][nt][0] + acc16[mt][nt][3];
+      }
     }
     if (t == 12345.678f) cand_cnt[0] = 1;
     return;
@@ -997,20 +1053,30 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
                    : "memory");
     }
     SV_PHASE(2)
-    float4 tqw[2][4];
-    {
+    // this lane's screening bounds: 32 x 32 tiles: element r of tile mt is row mt*32 + 8*(r>>2) + 4*kk + (r&3) -- 8 groups of 4
+    // consecutive rows; 16 x 16 tiles: element j of tile mt is row mt*16 + 4*(lane>>4) + j -- 4 groups of 4
+    float4 tqw[MF ? 1 : 2][4];
+    if constexpr (MF == 0) {
       const unsigned ta = wb_a + 512u + 16u * (unsigned)kk;
       asm volatile(
           "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
           "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\tds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\t"
           "s_waitcnt lgkmcnt(0)"
-          : "=&v"(tqw[0][0]), "=&v"(tqw[0][1]), "=&v"(tqw[0][2]), "=&v"(tqw[0][3]), "=&v"(tqw[1][0]), "=&v"(tqw[1][1]), "=&v"(tqw[1][2]),
-            "=&v"(tqw[1][3])
+          : "=&v"(tqw[0][0]), "=&v"(tqw[0][1]), "=&v"(tqw[0][2]), "=&v"(tqw[0][3]), "=&v"(tqw[MF ? 0 : 1][0]), "=&v"(tqw[MF ? 0 : 1][1]),
+            "=&v"(tqw[MF ? 0 : 1][2]), "=&v"(tqw[MF ? 0 : 1][3])
+          : "v"(ta)
+          : "memory");
+    } else {
+      const unsigned ta = wb_a + 512u + 16u * (unsigned)(l >> 4);
+      asm volatile(
+          "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:192\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(tqw[0][0]), "=&v"(tqw[0][1]), "=&v"(tqw[0][2]), "=&v"(tqw[0][3])
           : "v"(ta)
           : "memory");
     }
     uint32_t wave_cnt = 0;   // wave-uniform
-    const uint32_t colbase = (uint32_t)(wn * (32 * TN) + i), rowsel = (uint32_t)(4 * kk);
+    const uint32_t colbase = (uint32_t)(wn * (32 * TN) + (MF ? (l & 15) : i)), rowsel = (uint32_t)(4 * (MF ? (l >> 4) : kk));
     const int64_t rowbase = m0 + wm * 64;
     // dense exact test of the list: one returning global atomic per survivor, the stores left in flight
     auto flush = [&]() {
@@ -1046,6 +1112,38 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       }
       wave_cnt = 0u;
     };
+    if constexpr (MF == 1) {
+      // 16 screening steps of 8 elements (one row of the wave tile across its 8 column tiles)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 tq4 = tqw[0][mt];
+          const float tau = j == 0 ? tq4.x : j == 1 ? tq4.y : j == 2 ? tq4.z : tq4.w;
+          float best;
+          asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(acc16[mt][0][j]), "v"(acc16[mt][1][j]), "v"(acc16[mt][2][j]));
+          asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(acc16[mt][3][j]), "v"(acc16[mt][4][j]));
+          asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(acc16[mt][5][j]), "v"(acc16[mt][6][j]));
+          asm volatile("v_max_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(acc16[mt][7][j]));
+          if (__builtin_amdgcn_ballot_w64(best >= tau) != 0ull) {
+            const uint32_t rc = (((uint32_t)(mt * 16 + j) + rowsel) << 16) | colbase;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+              const bool hit = acc16[mt][nt][j] >= tau;
+              const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+              if (mk != 0ull) {
+                const uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                if (hit) {
+                  const uint2 rec = make_uint2(__float_as_uint(acc16[mt][nt][j]), rc + (uint32_t)(nt * 16));
+                  asm volatile("ds_write_b64 %0, %1 offset:768" ::"v"(wb_a + 8u * pos), "v"(rec) : "memory");
+                }
+                wave_cnt += (uint32_t)__popcll(mk);
+              }
+            }
+            if (wave_cnt > (uint32_t)(LCAP - 512)) flush();   // (a step adds up to 8 x 64 records)
+          }
+        }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1074,6 +1172,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
           if (wave_cnt > (uint32_t)(LCAP - 256)) flush();
         }
       }
+    }
     SV_PHASE(3)
     flush();
     SV_PHASE(4)
@@ -1251,7 +1350,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 }
 
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1286,7 +1385,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF>;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -1330,12 +1429,14 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 121: return launch_f16_filter<256, 256, 4, 2, 64, 3, 15>(SV_F16_ARGS);   // DMA only (no phase timing)
     case 160: return launch_f16_filter<256, 256, 4, 2, 64, 3, 16>(SV_F16_ARGS);   // DMA only, no epilogue
     case 91:
-    case 92: {  // phase timing of the default batch kernel (persistent + ping-pong + bias), epilogue 0 / 1
+    case 92:
+    case 93: {  // phase timing of the default batch kernel (persistent + ping-pong + bias), epilogue 0 / 1 / 1 + 16x16x32 MFMA
       unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c8[8];
       SV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sv_f16_phase_cycles), z, sizeof(z)));
       ctx->f16_bias_ok = true;
-      const int rc = c == 91 ? launch_f16_filter<256, 256, 4, 2, 64, 3, 9, true, 0, 2, 0, true, 0>(SV_F16_ARGS)
-                             : launch_f16_filter<256, 256, 4, 2, 64, 3, 9, true, 0, 2, 0, true, 1>(SV_F16_ARGS);
+      const int rc = c == 91   ? launch_f16_filter<256, 256, 4, 2, 64, 3, 9, true, 0, 2, 0, true, 0>(SV_F16_ARGS)
+                     : c == 92 ? launch_f16_filter<256, 256, 4, 2, 64, 3, 9, true, 0, 2, 0, true, 1>(SV_F16_ARGS)
+                               : launch_f16_filter<256, 256, 4, 2, 64, 3, 9, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);
       SV_HIP(hipStreamSynchronize(ctx->stream));
       SV_HIP(hipMemcpyFromSymbol(c8, HIP_SYMBOL(sv_f16_phase_cycles), sizeof(c8)));
       double tot = 0;
@@ -1371,7 +1472,9 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024) {
         if (ctx->opt.f16_epi == 0)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true>(SV_F16_ARGS);      // persistent + ping-pong
-        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1>(SV_F16_ARGS);     // + wave-private epilogue
+        if (ctx->opt.f16_mf == 0)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1>(SV_F16_ARGS);   // + wave-private epilogue
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);  // + 16 x 16 x 32 MFMA
       }
       return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true>(SV_F16_ARGS);
     case 251:   // 250 without the bias (A/B; norms too unbalanced for the biased margin)
@@ -2250,12 +2353,14 @@ __global__ __launch_bounds__(256) void refine_exact_wide_kernel(const float* __r
 // reads them back, sorts them and writes the top k.  d % 1024 == 0.  tick[] is all zero before and after.
 // Measured (50 queries x ~240 rows, 1 M x 1024 index): 59 us -> 34-38 us; what is left is a chain of ~7 dependent memory
 // round trips (list length + ids, rows, key stores, ticket, key loads, results) around 5 us of arithmetic.
+constexpr int SV_TICK_ROWS = 128, SV_TICK_POISON = SV_TICK_ROWS;   // tick[0..127]: one ticket counter per query; [128]: sticky failure word
 __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d,
                                                                  const float* __restrict__ qn, const float* __restrict__ rn,
                                                                  const uint32_t* __restrict__ ref_cnt,
                                                                  const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
                                                                  float* __restrict__ d2_out, int64_t* __restrict__ idx_out, int parts,
-                                                                 uint64_t* __restrict__ gkeys, uint32_t* __restrict__ tick) {
+                                                                 uint64_t* __restrict__ gkeys, uint32_t* __restrict__ tick,
+                                                                 uint32_t* __restrict__ fail_rows, uint32_t* __restrict__ fail_count) {
   constexpr int ROWS = 32, KC = 512, LDR = KC + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);                  // [ROWS][LDR]
@@ -2339,10 +2444,17 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
   if (!last) return;
   int np2 = 2;
   while (np2 < n) np2 <<= 1;
-  // gkeys holds all ones wherever no key of THIS launch has landed (the launcher fills a new buffer so, the reader puts the
-  // fill back behind every key it takes; a key is never all ones: finite distance, 32-bit id).  A key that another XCD's
-  // workgroup stored before its ticket is visible here by the protocol above -- the check is a seat belt: a stale slot is
-  // re-read (a bounded number of times) instead of silently sorted.
+  // Ordering.  Every access to gkeys / tick is an agent-scope atomic (sc1: performed at the memory side, never served from
+  // an XCD's own L2), the writers wait for their key stores to be ACKNOWLEDGED (vmcnt(0)) before the barrier in front of the
+  // ticket, and the reader issues its loads after its ticket returned: on this hardware that is a release / acquire chain
+  // through the ticket.  The C++ model does not promise it for relaxed atomics, and a formal acq_rel ticket costs an L2
+  // write-back + invalidate per workgroup (see above) -- so the protocol is CHECKED instead of trusted: gkeys holds all ones
+  // wherever no key of this launch has landed (the launcher fills a new buffer so, the reader puts the fill back behind
+  // every key it takes; a key is never all ones: finite distance, 32-bit id); a slot still all ones is re-read a bounded
+  // number of times, and a slot that never fills FLAGS its query (fail_rows: the caller redoes flagged rows on another
+  // path, exactly) and raises the sticky word tick[SV_TICK_POISON], on which the host re-initialises both buffers before
+  // their next use (a key landing after the reader gave up would otherwise pass for a key of the next launch).
+  int holes = 0;
   for (int j = tid; j < np2; j += 256) {
     uint64_t v = ~0ull;
     if (j < n) {
@@ -2350,12 +2462,19 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
         v = __hip_atomic_load(&gkeys[row * rcap + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v != ~0ull) break;
       }
+      if (v == ~0ull) ++holes;
       __hip_atomic_store(&gkeys[row * rcap + j], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     a[j] = v;
   }
   if (tid == 0) __hip_atomic_store(&tick[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
+  if (__syncthreads_or(holes)) {   // (never observed; the row's output is left to the redo)
+    if (tid == 0) {
+      __hip_atomic_store(&tick[SV_TICK_POISON], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fail_rows && atomicExch(&fail_rows[row], 1u) == 0u) atomicAdd(fail_count, 1u);
+    }
+    return;
+  }
   bitonic64(a, np2, tid);
   for (int j = tid; j < k; j += 256) {
     float dd = INFINITY;
@@ -2369,17 +2488,25 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
   }
 }
 
+int sv_refine_small_repair(segvlad_ctx* ctx) {
+  // the hand-over buffers of refine_exact_small_kernel back to their initial state (all ones / all zero)
+  if (ctx->s_ref_tick.p) SV_HIP(hipMemsetAsync(ctx->s_ref_tick.p, 0, ctx->s_ref_tick.cap, ctx->stream));
+  if (ctx->s_ref_keys.p) SV_HIP(hipMemsetAsync(ctx->s_ref_keys.p, 0xff, ctx->s_ref_keys.cap, ctx->stream));
+  return SEGVLAD_OK;
+}
+
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
-                           const uint32_t* only_rows) {
+                           const uint32_t* only_rows, uint32_t* fail_rows, uint32_t* fail_count, const uint32_t** poison_dev) {
+  if (poison_dev) *poison_dev = nullptr;
   if (nq <= 0) return SEGVLAD_OK;
   int rpad = 2;
   while (rpad < rcap) rpad <<= 1;
   size_t lds = (size_t)d * 4 + (size_t)rpad * 8;
-  if (nq <= 128 && d % 1024 == 0 && rcap <= 1024 && rcap % 32 == 0 && !only_rows) {   // one query image: lists shared by workgroups
+  if (nq <= SV_TICK_ROWS && d % 1024 == 0 && rcap <= 1024 && rcap % 32 == 0 && !only_rows) {   // one query image: lists shared by workgroups
     const int parts = rcap / 32;
     const size_t tick_cap = ctx->s_ref_tick.cap;
-    SV_HIP(ctx->s_ref_tick.reserve((size_t)128 * 4));
+    SV_HIP(ctx->s_ref_tick.reserve((size_t)(SV_TICK_ROWS + 1) * 4));
     if (ctx->s_ref_tick.cap != tick_cap) SV_HIP(hipMemsetAsync(ctx->s_ref_tick.p, 0, ctx->s_ref_tick.cap, ctx->stream));
     const size_t keys_cap = ctx->s_ref_keys.cap;
     SV_HIP(ctx->s_ref_keys.reserve((size_t)nq * rcap * 8));
@@ -2387,8 +2514,9 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
     lds = (size_t)(32 * 516 + 1024) * 4 + (size_t)rpad * 8;
     if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_small_kernel), lds));
     hipLaunchKernelGGL(refine_exact_small_kernel, dim3(nq * parts), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
-                       rpad, k, d2_out, idx_out, parts, ctx->s_ref_keys.as<uint64_t>(), ctx->s_ref_tick.as<uint32_t>());
+                       rpad, k, d2_out, idx_out, parts, ctx->s_ref_keys.as<uint64_t>(), ctx->s_ref_tick.as<uint32_t>(), fail_rows, fail_count);
     SV_HIP(hipGetLastError());
+    if (poison_dev) *poison_dev = ctx->s_ref_tick.as<uint32_t>() + SV_TICK_POISON;
     return SEGVLAD_OK;
   }
 #define SV_REFINE_ARGS dim3(nq), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap, rpad, k, d2_out, idx_out, only_rows
