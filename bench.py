@@ -135,6 +135,8 @@ def mfma_ubench():
             out["mfma_only_smooth_tflops"] = tf
         elif name.startswith("mfma only (random"):
             out["mfma_only_random_tflops"] = tf
+        elif name.startswith("mfma 16x16x32 only (random"):
+            out["mfma16_only_random_tflops"] = tf
         elif name.startswith("mfma + 6 ds_read"):
             out["mfma_plus_lds_reads_tflops"] = tf
         elif name.startswith("+ 8 DMA pieces / 32"):
@@ -142,7 +144,8 @@ def mfma_ubench():
         elif name.startswith("+ 8 DMA pieces, streaming"):
             out["mfma_lds_barrier_dma_hbm_tflops"] = tf
     out["note"] = ("v_mfma_f32_32x32x16_f16, 256 workgroups x 8 waves, registers only / + 6 ds_read_b128 per 8 MFMA / + barrier + "
-                   "global->LDS DMA; random operands (smooth operands draw less power and clock higher)")
+                   "global->LDS DMA; random operands (smooth operands draw less power and clock higher); mfma16_*: the same flops "
+                   "through v_mfma_f32_16x16x32_f16, the shape the batch filter kernel uses since round 4 (less energy per flop)")
     return out or None
 
 
@@ -173,7 +176,7 @@ def parse():
                    "noise with its reference image's (1 = the reference image itself, 0 = indistinguishable from its 3 sibling images)")
     p.add_argument("--sweep-own", default=None, help="debug: comma-separated --query-own values; after the DB build print the device "
                    "Recall@1 for each (stderr) and exit")
-    p.add_argument("--verify-images", type=int, default=4, help="query images re-computed by the CPU oracle (fp64) and compared "
+    p.add_argument("--verify-images", type=int, default=20, help="query images re-computed by the CPU oracle (fp64) and compared "
                    "with the device's predictions (N=1 only; part of the cpu_baseline leg)")
     p.add_argument("--debug-timing", action="store_true", help="after the timed region, print a synchronised per-phase wall-clock breakdown of one step to stderr")
     p.add_argument("--group", type=int, default=4, help="reference images per 'same place' sibling group (4 = the headline workload; 31 = a "
@@ -186,7 +189,11 @@ def parse():
                    "(segvlad_search_sharded / segvlad_allgather_rows) instead of torch.distributed collectives")
     p.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="segvlad_set_option switches of the search context "
                    "(tuning A/B: e.g. --set batch_plan=1); recorded in the line")
-    p.add_argument("--no-ubench", action="store_true", help="skip the live MFMA ceiling micro-benchmark (tools/ubench/mfma_peak)")
+    p.add_argument("--no-ubench", action="store_true", help="skip the live MFMA ceiling micro-benchmark (tools/ubench/mfma_peak) and the "
+                   "same-shape plain-GEMM yardstick (tools/yardstick_gemm.py)")
+    p.add_argument("--shard-sim", type=int, default=8, help="N=1 line: emulate ONE rank of a row-sharded run over this many GPUs on the one "
+                   "GPU (a 1/W shard of the database, ALL query segments searched k_vote deep, 1/W of the query images described, the "
+                   "W-way merge and the vote; no collective) -> the 'shard_sim' sub-record; 0 = skip")
     return p.parse_args()
 
 
@@ -453,6 +460,32 @@ def run(a, top=True):
                      "note": "describe of batch i+1 on its own context + stream under the search of batch i (bench.py --pipeline "
                              "makes this the timed mode); the search's persistent filter kernel leaves the describe kernels few "
                              "CUs, and both draw on the same power budget"}
+    sstats = eng.search_stats()   # (of the timed run's last search: before any sub-measurement searches again)
+    fp32_rec = None
+    if top and world == 1 and not a.no_sub_records and not a.sweep_own and FILTER_KIND != "fp32":
+        # The SAME workload with the same-arithmetic filter (option knn_filter=fp32: fp32 MFMA distances in every level, no
+        # 16-bit product anywhere): what the line's fp16 pruning buys, and the evidence that it changes nothing -- the
+        # searches' (d2, idx) must be BIT-identical and the predictions identical.
+        qd_chk = pipe.describe(q_tok, q_msk, q_off_local)
+        d2_a, idx_a = eng.search(qd_chk, 200)
+        eng.set_option("knn_filter", "fp32")
+        out_f = step()
+        fence()
+        tf0 = time.perf_counter()
+        n_f = 2
+        for _ in range(n_f):
+            out_f = step()
+        fence()
+        dtf = time.perf_counter() - tf0
+        d2_b, idx_b = eng.search(qd_chk, 200)
+        fp32_rec = {"ms_per_step": dtf / n_f * 1e3, "value": nQ * n_f / dtf, "steps": n_f, "filter": eng.search_stats()["filter"],
+                    "predictions_identical": bool(torch.equal(out_f[0], out[0])),
+                    "d2_idx_bit_identical": bool(torch.equal(d2_a, d2_b) and torch.equal(idx_a, idx_b)),
+                    "speedup_of_the_timed_run": (dtf / n_f) / (dt / a.steps),
+                    "note": "same steps, option knn_filter=fp32 (every filter level on fp32 MFMA, peak 157.3 TFLOP/s); the timed run's "
+                            "fp16 product only prunes, under a proven error bound, and its survivors are re-evaluated in fp32"}
+        eng.set_option("knn_filter", "auto")
+        del qd_chk, d2_a, idx_a, d2_b, idx_b, out_f
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -490,7 +523,6 @@ def run(a, top=True):
                 stages[s] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps}
             except Exception:
                 pass
-    sstats = eng.search_stats()
     per_rank = None
     if world > 1:   # every rank's stage times travel to rank 0 (the slowest rank sets the step time)
         mine = {k: round(v["ms_per_step"], 4) for k, v in stages.items()}
@@ -556,9 +588,11 @@ def run(a, top=True):
             ub = mfma_ubench()
             if ub:
                 roof["ubench"] = ub
-                if ub.get("mfma_only_random_tflops"):
-                    roof["mfma_only_ceiling_ms"] = flops_step * eng_filter_products() / (ub["mfma_only_random_tflops"] * 1e12) * 1e3
-                    roof["frac_of_mfma_only_ceiling"] = ach / ub["mfma_only_random_tflops"]
+                ceil_tf = ub.get("mfma16_only_random_tflops") if key == "knn_gemm" else None   # the filter's own MFMA shape
+                ceil_tf = ceil_tf or ub.get("mfma_only_random_tflops")
+                if ceil_tf:
+                    roof["mfma_only_ceiling_ms"] = flops_step * eng_filter_products() / (ceil_tf * 1e12) * 1e3
+                    roof["frac_of_mfma_only_ceiling"] = ach / ceil_tf
                 if ub.get("mfma_plus_lds_reads_tflops"):
                     roof["mfma_plus_lds_reads_ceiling_ms"] = flops_step * eng_filter_products() / (ub["mfma_plus_lds_reads_tflops"] * 1e12) * 1e3
     elif dom is not None:
@@ -669,7 +703,7 @@ def run(a, top=True):
                        "the hip_event figures are per-step HIP events on the issuing stream (SURVEY 8d)",
         "mode": "pipelined (describe i+1 on its own context/stream under search i)" if a.pipeline else "serial",
         "options": a.set or None,
-        "pipelined": pipelined,
+        "pipelined": pipelined, "fp32_filter": fp32_rec,
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "filter_dtype": FILTER_KIND, "pca_gemm_dtype": "f16x3" if eng_pca_products(K * D, P) == 3 else "f32",
         "dtype_note": "every reported distance / similarity / descriptor is fp32-class: the fp16 MFMA product of the kNN stage only "
@@ -746,7 +780,121 @@ def main():
         res["config2"] = sub_record(a, no_pca=True, db_images=1000, search_stats=True)
         # a 17places-like temporally redundant database (gt.py:60-64): sibling groups of 31 near-duplicate frames
         res["redundant_db"] = sub_record(a, group=31, search_stats=True)
+    if world == 1 and a.shard_sim > 1 and not a.no_sub_records and not a.no_pca and not a.sweep_own:
+        try:
+            res["shard_sim"] = shard_sim(a, a.shard_sim)
+        except Exception as e:
+            res["shard_sim"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not a.no_ubench and res.get("roofline") and res["roofline"].get("dominant_stage", "").startswith("knn"):
+        # an independent yardstick for `frac`: a PLAIN fp16 GEMM of the filter's shape through torch.matmul (hipBLASLt /
+        # rocBLAS), measured now on this box -- measurement only, never the product path
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("yardstick_gemm", os.path.join(ROOT, "tools", "yardstick_gemm.py"))
+            yg = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(yg)
+            y = yg.measure(a.query_images * a.segments, a.db_images * a.segments, a.pca_dim)
+            res["roofline"]["yardstick_gemm_tflops"] = y["yardstick_gemm_tflops"]
+            res["roofline"]["yardstick_gemm"] = y
+            res["roofline"]["achieved_vs_yardstick"] = res["roofline"]["achieved"] / y["yardstick_gemm_tflops"]
+        except Exception as e:
+            res["roofline"]["yardstick_gemm"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(res))
+
+
+def shard_sim(a, W):
+    """ONE rank of a W-way row-sharded run, emulated on the one GPU (no node with W GPUs is available to the builder): the
+    rank's 1/W shard of the database, its 1/W slice of the query images to describe, ALL query segments searched k_vote deep
+    against the shard (sharded.py: retrieve), the W-way merge of the exchanged lists and the vote.  The two collectives --
+    the query-descriptor all-gather (nQ*S*P*4 bytes in total) and the packed top-k record all-gather (nQ*S*k_vote*12 bytes per
+    rank) -- are NOT executed: their byte counts and an xGMI estimate are reported beside the compute."""
+    S, K, D, H, W_, P = a.segments, a.clusters, a.dim, a.height, a.width, a.pca_dim
+    N, Hm, Wm = (H // 14) * (W_ // 14), H // 2, W_ // 2
+    nQ, nR = a.query_images, a.db_images
+    nR_l, nQ_l = nR // W, max(1, nQ // W)
+    dev = torch.device("cuda:0")
+    eng = SegVLADEngine(0)
+    C_np = synth.make_vocab(K, D, seed=1000)
+    eng.set_vocab(C_np)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5000)
+    comps = torch.randn(P, K * D, device=dev, generator=g) / (K * D) ** 0.5
+    mean = torch.randn(K * D, device=dev, generator=g) * (0.2 / (K * D) ** 0.5)
+    eng.pca_set(mean, comps, torch.logspace(-3, -6, P, device=dev), whiten=True)
+    del comps
+    eng.set_option("pca_path", "project")
+    pipe = SegVLADPipeline(eng, H, W_, 14, order=a.order, use_pca=True)
+    fac = ImageFactory(dev, torch.from_numpy(C_np).to(dev), N, S, Hm, Wm, a.query_own, a.group)
+    bb = a.build_batch
+    tok = torch.empty(bb, D, N, device=dev)
+    msk = torch.empty(bb * S, Hm, Wm, dtype=torch.uint8, device=dev)
+
+    def describe_images(ids, maker):
+        out = torch.empty(len(ids) * S, P, device=dev)
+        for b0 in range(0, len(ids), bb):
+            nb = min(bb, len(ids) - b0)
+            for j in range(nb):
+                t, m = maker(ids[b0 + j])
+                tok[j] = t
+                msk[j * S:(j + 1) * S] = m
+            out[b0 * S:(b0 + nb) * S] = pipe.describe(tok[:nb], msk[:nb * S], (np.arange(nb + 1) * S).astype(np.int32))
+        return out
+
+    rows = describe_images(list(range(nR_l)), fac.reference)                    # rank 0's shard: reference images [0, nR / W)
+    tau = np.random.Generator(np.random.PCG64(4000)).integers(0, nR, size=nQ)
+    qd_all = describe_images(list(range(nQ)), lambda qi: fac.query(int(tau[qi]), qi))   # stands for the gathered descriptors
+    q_tok = torch.empty(nQ_l, D, N, device=dev)
+    q_msk = torch.empty(nQ_l * S, Hm, Wm, dtype=torch.uint8, device=dev)
+    for j in range(nQ_l):
+        t, m = fac.query(int(tau[j]), j)
+        q_tok[j] = t
+        q_msk[j * S:(j + 1) * S] = m
+    eng.db_add(rows, None)
+    img_of_seg = torch.arange(nR, device=dev, dtype=torch.int32).repeat_interleave(S)   # the global map every rank holds
+    q_off_l, q_off_all = (np.arange(nQ_l + 1) * S).astype(np.int32), (np.arange(nQ + 1) * S).astype(np.int32)
+    kv = 50
+
+    def rank_step():
+        pipe.describe(q_tok, q_msk, q_off_l)                                     # this rank's slice of the query images
+        d2, idx = eng.search(qd_all, kv)                                         # all query segments against the shard
+        # the other ranks' lists: this rank's own, with ids moved into their shards (distinct ids, same merge work)
+        d2c = d2.repeat(1, W)
+        idc = torch.cat([idx + r * (nR_l * S) for r in range(W)], dim=1)
+        md, mi = eng.merge_topk(d2c, idc, W, kv)
+        sims, m = eng.sims_from_d2(md, mi, kv)
+        return eng.vote(m, sims, q_off_all, n_top=5, img_of_seg=img_of_seg)
+
+    for _ in range(2):
+        rank_step()
+    eng.set_profiling(True)
+    eng.profile_reset()
+    torch.cuda.synchronize()
+    n_it = 5
+    t0 = time.perf_counter()
+    for _ in range(n_it):
+        rank_step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n_it * 1e3
+    stages = {}
+    for st in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "vote"):
+        try:
+            stages[st] = round(eng.stage_ms(st)[0] / n_it, 4)
+        except Exception:
+            pass
+    gather_bytes, rec_bytes = nQ * S * P * 4, nQ * S * kv * 12
+    # ring all-gather over xGMI: every rank receives (W-1)/W of the total through its links; one link ~ 50 GB/s effective
+    # per direction is the conservative planning figure (7 links x ~153 GB/s peak per GPU, MI355X_MICROARCH.md)
+    est_comm_ms = (gather_bytes * (W - 1) / W + rec_bytes * (W - 1)) / 50e9 * 1e3
+    eng.close()
+    torch.cuda.empty_cache()
+    return {"world": W, "per_rank_ms": ms, "stages_ms": stages, "shard_rows": nR_l * S, "query_images_described": nQ_l,
+            "implied_upper_bound_images_per_s": nQ / (ms * 1e-3),
+            "implied_upper_bound_with_comm_estimate_images_per_s": nQ / ((ms + est_comm_ms) * 1e-3),
+            "collectives_not_executed": {"query_descriptor_allgather_bytes_total": gather_bytes, "topk_record_allgather_bytes_per_rank": rec_bytes,
+                                         "estimate_ms_at_50GBs_per_link": est_comm_ms},
+            "note": "one rank's compute of a W-way run on ONE GPU (host-side torch glue of the emulation included in per_rank_ms): an "
+                    "UPPER bound on the W-GPU rate -- collectives, their synchronisation and load imbalance come on top; "
+                    "the strong-scaling efficiency this implies against the N=1 line is value_bound / (W x N=1 value)"}
 
 
 def cpu_baseline(a, db_rows, fac, tau, C_np, use_pca, P, N, S, K, D, H, W, pipe, index, q_tok, q_msk):

@@ -1208,8 +1208,15 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   SV_TRY(sv_out(ctx, d2_out, (size_t)nq * k * 4, &dd2));
   SV_TRY(sv_out(ctx, idx_out, (size_t)nq * k * 8, &didx));
   SV_HIP(ctx->s_qnorm.reserve((size_t)nq * 4));
-  SV_TRY(sv_launch_row_sumsq(ctx, (const float*)dq, nq, d, ctx->s_qnorm.as<float>()));
   const float* qn = ctx->s_qnorm.as<float>();
+  // the queries' squared norms: a launch of their own -- except on the single-image fp16 path, whose query-preparation kernel
+  // computes them too (one dependent launch less in a pass that is a chain of them)
+  bool qn_done = false;
+  auto ensure_qn = [&]() -> int {
+    if (!qn_done) SV_TRY(sv_launch_row_sumsq(ctx, (const float*)dq, nq, d, ctx->s_qnorm.as<float>()));
+    qn_done = true;
+    return SEGVLAD_OK;
+  };
   ctx->sstats = SvSearchStats();
   ctx->sstats.n_queries = nq;
 
@@ -1235,6 +1242,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     }
   }
   if (pl.levels == 0 || n / pl.stride0 < 4 * (int64_t)k) {
+    SV_TRY(ensure_qn());
     SV_TRY(search_matrix(ctx, (const float*)dq, nq, n, d, k, qn, (float*)dd2, (int64_t*)didx));
     return sv_finish(ctx);
   }
@@ -1334,11 +1342,14 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       // was ~45 us of a ~600 us call).  One workgroup reads the block twice: up to 1 MiB of queries (128 x 2048 floats);
       // deeper rows (raw K*D descriptors) keep the many-workgroup kernels and their read-back.
       SV_HIP(ctx->s_qscale.reserve(16));
+      const bool fuse_qn = !qn_done && (reinterpret_cast<uintptr_t>(dq) & 15) == 0;   // (d % 64 == 0 on this path)
       SV_TRY(sv_launch_query_f16_small(ctx, (const float*)dq, (int64_t)nq * d, ctx->db_f16_scale, ctx->s_qf16.as<uint16_t>(),
-                                       ctx->s_qscale.as<float>()));
+                                       ctx->s_qscale.as<float>(), fuse_qn ? ctx->s_qnorm.as<float>() : nullptr, nq, d));
+      if (fuse_qn) qn_done = true;
       ctx->f16_scale_dev = ctx->s_qscale.as<float>();
       pl.inv_scale = 0.f;   // (unused: the kernels read s_qscale[1])
     } else {
+      SV_TRY(ensure_qn());
       float qmax = 0.f;
       SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
       qscale = pow2_scale(qmax);
@@ -1378,6 +1389,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_HIP(ctx->s_ql.reserve((size_t)nq * d * 2));
     SV_TRY(sv_launch_split_bf16(ctx, (const float*)dq, (int64_t)nq * d, ctx->s_qh.as<uint16_t>(), ctx->s_ql.as<uint16_t>()));
   }
+  SV_TRY(ensure_qn());   // (every path that has not produced the norms on its way)
   SV_HIP(ctx->s_cand_cnt.reserve(mrows * 4));
   SV_HIP(ctx->s_cand_d2.reserve(mrows * SV_CAP * 4));
   SV_HIP(ctx->s_cand_id.reserve(mrows * SV_CAP * 4));

@@ -33,18 +33,30 @@ __device__ __forceinline__ float sv_d2(float q2, float r2, float dot) { return _
 #endif
 
 // Layout of the fp16 operand planes of the split projection GEMM (gemm_f16x3_kernel): [row / 128][k / 32][128 rows][32 k],
-// the four 16-byte chunks of a row stored at chunk ^ ((row >> 2) & 3).  One (128-row, 32-k) block is 8 KiB of CONTIGUOUS
+// the four 16-byte chunks of a row stored at chunk ^ sv_x3_swz(row).  One (128-row, 32-k) block is 8 KiB of CONTIGUOUS
 // memory that is, byte for byte, the bank-conflict-free LDS image the MFMA fragment reads expect: the global->LDS DMA
 // of a k-tile is a linear copy of whole 128-byte lines.  (Row-major planes made every DMA piece touch 16 half-lines
 // 196 KiB apart; each line was fetched twice, one k-tile apart, and the XCD's L2 -- 4 MiB against 4 MiB of such
 // half-used lines in flight -- kept nothing for the workgroups sharing a tile: 26 GB fetched for 4.4 GB of operands.)
 // Rows are padded to a multiple of 256 (the pad rows hold garbage: they only feed output rows / columns that are never stored).
+//
+// The swizzle term.  The fragments are read for v_mfma_f32_16x16x32_f16 (round 4: the shape that needs less energy per flop):
+// lane l holds row (l & 15) of a 16-row tile and chunk (l >> 4) of the 64-byte row.  A ds_read_b128 is served in four groups of
+// 16 lanes, {0-3, 12-15, 20-27} being one: rows 0-3 and 12-15 with chunk c, rows 4-11 with chunk c + 1; bank group (16-byte
+// unit mod 16) of row r, physical chunk p = 4 (r & 3) + p.  With p = c ^ a[(r >> 2) & 3] the sixteen lanes of every group hit
+// sixteen different bank groups iff {a0, a3, 1 ^ a1, 1 ^ a2} and {a1, a2, 1 ^ a0, 1 ^ a3} are both {0, 1, 2, 3}:
+// a = (0, 3, 2, 1), i.e. (-(r >> 2)) & 3.  (Rounds 1-3 read 32-row fragments -- lane l: row l & 31, chunk l >> 5 -- for which
+// a = (0, 1, 2, 3) was the conflict-free choice; that one is 2-way conflicted for the 16-row pattern.)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int sv_x3_swz(int64_t row) { return (int)((0 - (row >> 2)) & 3); }
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline size_t sv_x3_off(int64_t row, int64_t k, int64_t Kd) {
   return ((size_t)(row >> 7) * (size_t)(Kd >> 5) + (size_t)(k >> 5)) * 4096 + (size_t)(row & 127) * 32 +
-         (size_t)((((k & 31) >> 3) ^ ((row >> 2) & 3)) << 3) + (size_t)(k & 7);
+         (size_t)((((k & 31) >> 3) ^ sv_x3_swz(row)) << 3) + (size_t)(k & 7);
 }
 inline int64_t sv_x3_rows(int64_t n) { return (n + 255) & ~255ll; }
 
@@ -369,7 +381,9 @@ int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* w
 int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out);
 // single-image searches: the query plane and its scales without a host round trip (scales_dev[0] = query scale,
 // [1] = 1 / (query scale x db_scale)); ctx->f16_scale_dev != null makes the filter kernel read [1] instead of its argument
-int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev);
+// qn_out != null (needs d % 4 == 0, 16-byte aligned rows): also the rows' squared norms, bit for bit sv_launch_row_sumsq's
+int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev,
+                              float* qn_out = nullptr, int nq = 0, int d = 0);
 int sv_launch_to_f16_devscale(segvlad_ctx* ctx, const float* X, int64_t n_elems, const float* scales_dev, uint16_t* out);
 int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,

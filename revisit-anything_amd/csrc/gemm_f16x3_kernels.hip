@@ -2,8 +2,9 @@
 //
 // fp32 MFMA runs at 1/16 of the fp16 rate.  Each fp32 operand is scaled by a power of two and split into TWO
 // fp16 values, x*s = h1 + h2 + e with |e| <= 2^-22 |x*s| (two 11-bit significands), and the product is
-// accumulated as h2.g1 + h1.g2 + h1.g1 on v_mfma_f32_32x32x16_f16 (fp16 x fp16 products are exact in fp32, the
-// accumulator is fp32).  The dropped terms are <= 3*2^-22 ||a|| ||b||: BELOW the fp32 chain's own accumulation
+// accumulated as h2.g1 + h1.g2 + h1.g1 on v_mfma_f32_16x16x32_f16 (fp16 x fp16 products are exact in fp32, the
+// accumulator is fp32; rounds 1-3 used the 32 x 32 x 16 shape: the chip is power limited on these kernels and the 16 x 16 x 32
+// shape needs ~12 % less energy per flop -- tools/ubench/mfma_peak, knn_f16_filter_kernel).  The dropped terms are <= 3*2^-22 ||a|| ||b||: BELOW the fp32 chain's own accumulation
 // error for K = 98304 (sqrt(K) 2^-24 typical), i.e. the result is at least as accurate as the fp32-MFMA GEMM it
 // replaces, at 3/16 of the matrix-pipe time.  (The kNN filter can afford a single product because it only needs
 // a rigorous bound; here the value itself is the output, hence the two-term split.)
@@ -16,11 +17,11 @@
 
 #include "ctx.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ X, int64_t n_rows, int d,
                                                           const float* __restrict__ sub, float scale,
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
                                                                   float* __restrict__ C, int64_t ldc,
                                                                   const int32_t* __restrict__ tile_group, int nkb_b) {
   constexpr int NW = WM * WN;
-  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);   // 16 x 16 MFMA tiles per wave (4 x 8 for the 64 x 128 wave tile)
+  static_assert(TM == 4 && (TN == 8 || TN == 4), "wave tiles of 64 rows, 128 or 64 columns");
   constexpr int HBK = 32, RB = 64, RP = 16;           // 64-B rows per plane and k-tile, 16 rows per 1-KiB DMA piece
   constexpr int PA = BM * RB, PB = BN * RB;            // one plane
   constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and PLANE
@@ -126,21 +128,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
     if (group < 0) return;
   }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-  const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int tid = threadIdx.x, l = tid & 63, i = l & 15, kq = l >> 4;   // lane: row / column i of a 16-wide tile, k-chunk kq
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / WN, wn = w % WN;
   const int kbeg = split * k_per_split;
   const int kend = (kbeg + k_per_split < Kd) ? kbeg + k_per_split : Kd;
   const int ntiles = (kend - kbeg) / HBK;
-  auto swz = [](int r, int c) { return c ^ ((r >> 2) & 3); };
+  auto swz = [](int r, int c) { return c ^ sv_x3_swz(r); };
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];   // element j of tile (mt, nt): row mt*16 + 4*kq + j, column nt*16 + i
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
   // Element offsets of this lane's 16-B chunk in the blocked planes (ctx.h: sv_x3_off): piece p of a tile = rows
   // 16 p .. 16 p + 15, which are 1 KiB of contiguous memory inside their (128-row, 32-k) block, already in the swizzled
@@ -179,39 +181,40 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
   wait_vm_lgkm0_<0>();
   __builtin_amdgcn_s_barrier();
   int cur = 0;
-  const int fa0 = wm * (32 * TM) + i, fb0 = wn * (32 * TN) + i;
+  const int fa0 = wm * (16 * TM) + i, fb0 = wn * (16 * TN) + i;
   for (int kt = 0; kt < ntiles; ++kt) {
     if (kt + 1 < ntiles) dma_tile(kt + 1, cur ^ 1);  // lands while tile kt is multiplied
     const unsigned char* S = lds + cur * STAGE;
+    // the k-tile of 32 is ONE k-step of the 16 x 16 x 32 MFMA: chunk kq of every row
+    f16x8 a1[TM], a2[TM];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int cl = 2 * ks + kk;
-      f16x8 a1[TM], a2[TM], b1[TN], b2[TN];
+    for (int t = 0; t < TM; ++t) {
+      const int ra = fa0 + 16 * t;
+      a1[t] = *reinterpret_cast<const f16x8*>(S + ra * RB + swz(ra, kq) * 16);
+      a2[t] = *reinterpret_cast<const f16x8*>(S + PA + ra * RB + swz(ra, kq) * 16);
+    }
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        const int ra = fa0 + 32 * t;
-        a1[t] = *reinterpret_cast<const f16x8*>(S + ra * RB + swz(ra, cl) * 16);
-        a2[t] = *reinterpret_cast<const f16x8*>(S + PA + ra * RB + swz(ra, cl) * 16);
+    for (int h = 0; h < TN / 4; ++h) {   // four column tiles at a time (16 fragment registers per plane)
+      f16x8 b1[4], b2[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rb = fb0 + 16 * (4 * h + t);
+        b1[t] = *reinterpret_cast<const f16x8*>(S + 2 * PA + rb * RB + swz(rb, kq) * 16);
+        b2[t] = *reinterpret_cast<const f16x8*>(S + 2 * PA + PB + rb * RB + swz(rb, kq) * 16);
       }
-#pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const int rb = fb0 + 32 * t;
-        b1[t] = *reinterpret_cast<const f16x8*>(S + 2 * PA + rb * RB + swz(rb, cl) * 16);
-        b2[t] = *reinterpret_cast<const f16x8*>(S + 2 * PA + PB + rb * RB + swz(rb, cl) * 16);
-      }
-      // small terms first; the TM*TN accumulators are independent, so consecutive MFMAs never wait on each other
+      // small terms first; the accumulators are independent, so consecutive MFMAs never wait on each other
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a2[mt], b1[nt], acc[mt][nt]);
+        for (int nt = 0; nt < 4; ++nt) acc[mt][4 * h + nt] = MFMA_F16(a2[mt], b1[nt], acc[mt][4 * h + nt]);
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a1[mt], b2[nt], acc[mt][nt]);
+        for (int nt = 0; nt < 4; ++nt) acc[mt][4 * h + nt] = MFMA_F16(a1[mt], b2[nt], acc[mt][4 * h + nt]);
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a1[mt], b1[nt], acc[mt][nt]);
+        for (int nt = 0; nt < 4; ++nt) acc[mt][4 * h + nt] = MFMA_F16(a1[mt], b1[nt], acc[mt][4 * h + nt]);
     }
     wait_vm_lgkm0_<0>();
     __builtin_amdgcn_s_barrier();
@@ -221,14 +224,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16x3_kernel(const uint16_t
   if (n_splits > 1) C += (int64_t)split * M * ldc;
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt) {
-    const int64_t col = n0 + wn * (32 * TN) + nt * 32 + i;
+    const int64_t col = n0 + wn * (16 * TN) + nt * 16 + i;
     if (col >= N) continue;
     const float cs = (n_splits > 1) ? 1.f : out_scale * (col_scale ? col_scale[col] : 1.f);
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * (32 * TM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * (16 * TM) + mt * 16 + 4 * kq + r;
         if (row < M) C[row * ldc + col] = acc[mt][nt][r] * cs;
       }
   }

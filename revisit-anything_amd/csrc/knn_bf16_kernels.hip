@@ -333,11 +333,33 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float* __restrict__ X
 // A handful of query rows (<= 128 x d floats): largest magnitude, the power-of-two scale that puts it in [8192, 16384) --
 // the host's pow2_scale, bit for bit -- and the fp16 plane, in ONE workgroup and one launch; the scales stay on the device
 // (scales[0] = query scale, scales[1] = 1 / (query scale x db_scale)): no memset, no atomics, no host round trip.
+// qn_out != null: the rows' squared norms as well (one wave per row, 16 rows in flight: the arithmetic of row_sumsq_kernel,
+// gemm_kernels.hip, operation for operation -- lane j sums the squares of float4 j, j + 64, ... with fmaf, then the xor
+// butterfly -- so that the single-image pass sees the very bits the batch path computes), instead of a launch of its own in
+// front of this one.
 __global__ __launch_bounds__(1024) void query_f16_small_kernel(const float* __restrict__ X, int64_t n4, float db_scale,
-                                                               _Float16* __restrict__ out, float* __restrict__ scales) {
+                                                               _Float16* __restrict__ out, float* __restrict__ scales,
+                                                               float* __restrict__ qn_out, int nq, int d) {
   __shared__ uint32_t wmax[16];
   __shared__ float s_scale;
   const int tid = threadIdx.x;
+  if (qn_out) {
+    const int lane = tid & 63;
+    for (int row = tid >> 6; row < nq; row += 16) {
+      const float4* x4 = reinterpret_cast<const float4*>(X + (int64_t)row * d);
+      float s = 0.f;
+      for (int j = lane; j < (d >> 2); j += 64) {
+        const float4 v = x4[j];
+        s = fmaf(v.x, v.x, s);
+        s = fmaf(v.y, v.y, s);
+        s = fmaf(v.z, v.z, s);
+        s = fmaf(v.w, v.w, s);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) qn_out[row] = s;
+    }
+  }
   uint32_t m = 0;
   for (int64_t j = tid; j < n4; j += 1024) {
     const float4 v = reinterpret_cast<const float4*>(X)[j];
@@ -374,9 +396,10 @@ __global__ __launch_bounds__(1024) void query_f16_small_kernel(const float* __re
   }
 }
 
-int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev) {
+int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev,
+                              float* qn_out, int nq, int d) {
   hipLaunchKernelGGL(query_f16_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, X, n_elems / 4, db_scale,
-                     reinterpret_cast<_Float16*>(out), scales_dev);
+                     reinterpret_cast<_Float16*>(out), scales_dev, qn_out, nq, d);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
           const bool real = dvalid && j < n;
           // sv_x3_off(grow0 + j, dcol, D) with the lane / chunk constants of this 128-column chunk taken out of the loop
           const unsigned rr = (unsigned)(grow0 + j);
-          const size_t ob = real ? ((size_t)(rr >> 7) * nkb_d + kb_dc) * 4096 + (size_t)(((rr & 127u) << 5) + (((lane_c ^ ((rr >> 2) & 3u)) << 3) | lane_o))
+          const size_t ob = real ? ((size_t)(rr >> 7) * nkb_d + kb_dc) * 4096 + (size_t)(((rr & 127u) << 5) + (((lane_c ^ (unsigned)sv_x3_swz(rr)) << 3) | lane_o))
                                  : ob_dummy;
           *reinterpret_cast<h4*>(h1 + ob) = p1;
           *reinterpret_cast<h4*>(h2 + ob) = p2;

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Guard mode for the whole GPU run (csrc/ctx.h: DevBuf; tests/test_gpu_guard.py): fenced, exact-size device buffers whose
+# fences are checked after every API call -- the driver's `pytest -m gpu` shares one context per module, and a grow-only
+# scratch buffer sized by an earlier, larger call hides an under-sized request (commit 987adcb) unless the fence moves with
+# the request.  SEGVLAD_GUARD=0 in the environment switches it off (timing runs; bench.py's own subprocesses do that).
+os.environ.setdefault("SEGVLAD_GUARD", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

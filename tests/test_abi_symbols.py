@@ -69,21 +69,29 @@ def test_product_never_imports_the_oracle():
 
 
 def test_every_context_buffer_is_released_by_destroy():
-    """segvlad_destroy must free every grow-only device buffer the context declares (four were missing)."""
+    """segvlad_destroy must free every grow-only device buffer the context declares (four were missing).  Since
+    round 4 the buffers are declared through two X-macro lists that segvlad_create (tags, guard mode), the guard check and
+    segvlad_destroy all walk: no buffer may be declared outside them, and destroy must release through the walk."""
     import re
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ctx = open(os.path.join(root, "revisit-anything_amd", "csrc", "ctx.h")).read()
     body = ctx[ctx.index("struct segvlad_ctx {"):]
     body = body[:body.index("int fail(")]
-    declared = set()
-    for decl in re.findall(r"DevBuf\s+([^;]+);", body):
-        declared.update(n.strip() for n in re.sub(r"//[^\n]*", "", decl).split(","))
-    declared = {n for n in declared if n}
+    stray = [d for d in re.findall(r"^\s*DevBuf\s+([^;(]+);", body, flags=re.M) if d.strip() != "n"]
+    assert stray == [], f"DevBuf members declared outside SV_PERSISTENT_BUFS / SV_SCRATCH_BUFS: {stray}"
+    listed = re.findall(r"X\((\w+)\)", body)
+    assert len(listed) > 60 and len(set(listed)) == len(listed)
+    assert "SV_PERSISTENT_BUFS(SV_VISIT_BUF)" in body and "SV_SCRATCH_BUFS(SV_VISIT_BUF)" in body and "for (auto& b : stage) f(b);" in body
     api = open(os.path.join(root, "revisit-anything_amd", "csrc", "api.hip")).read()
     dtor = api[api.index("int segvlad_destroy("):api.index("const char* segvlad_last_error")]
-    released = set(re.findall(r"&ctx->(\w+)", dtor))
-    assert declared - released == set(), f"not released by segvlad_destroy: {sorted(declared - released)}"
+    assert "for_each_buf([](DevBuf& b) { b.release(); })" in dtor
+    # every buffer some translation unit uses is one of the listed ones
+    used = set()
+    d = os.path.join(root, "revisit-anything_amd", "csrc")
+    for f in os.listdir(d):
+        used.update(re.findall(r"ctx->((?:s|db|pca|vocab)\w*)\.(?:reserve|as<|p\b|cap\b)", open(os.path.join(d, f)).read()))
+    assert used - set(listed) == set(), sorted(used - set(listed))
 
 
 def test_hot_entry_points_never_read_the_environment():
