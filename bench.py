@@ -523,6 +523,23 @@ def run(a, top=True):
                 stages[s] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps}
             except Exception:
                 pass
+    b2b = None
+    if top and world == 1 and not a.sweep_own:
+        # the same searches back to back, without a describe stage in between (a diagnostic: the filter kernel is power
+        # limited, and what runs before it -- and what its operands look like -- moves its clock)
+        qd_b = pipe.describe(q_tok, q_msk, q_off_local)
+        eng.search(qd_b, 200)
+        eng.set_profiling(True)
+        eng.profile_reset()
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(5):
+            eng.search(qd_b, 200)
+        torch.cuda.synchronize()
+        b2b = {"ms_per_search": (time.perf_counter() - tb0) / 5 * 1e3, "knn_gemm_ms": eng.stage_ms("knn_gemm")[0] / 5,
+               "knn_select_ms": eng.stage_ms("knn_select")[0] / 5}
+        eng.set_profiling(False)
+        del qd_b
     per_rank = None
     if world > 1:   # every rank's stage times travel to rank 0 (the slowest rank sets the step time)
         mine = {k: round(v["ms_per_step"], 4) for k, v in stages.items()}
@@ -703,7 +720,7 @@ def run(a, top=True):
                        "the hip_event figures are per-step HIP events on the issuing stream (SURVEY 8d)",
         "mode": "pipelined (describe i+1 on its own context/stream under search i)" if a.pipeline else "serial",
         "options": a.set or None,
-        "pipelined": pipelined, "fp32_filter": fp32_rec,
+        "pipelined": pipelined, "fp32_filter": fp32_rec, "search_back_to_back": b2b,
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "filter_dtype": FILTER_KIND, "pca_gemm_dtype": "f16x3" if eng_pca_products(K * D, P) == 3 else "f32",
         "dtype_note": "every reported distance / similarity / descriptor is fp32-class: the fp16 MFMA product of the kNN stage only "

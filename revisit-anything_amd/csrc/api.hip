@@ -266,6 +266,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "pj_nw")) return as_int(&o.pj_nw);
   if (!strcmp(key, "small_plan")) return as_int(&o.small_plan);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
+  if (!strcmp(key, "debug_fail_search")) return as_int(&o.debug_fail_search);
   if (!strcmp(key, "guard_undersize")) {
     // tests of the guard itself: "<buffer tag>:<bytes>" puts that scratch buffer's back fence <bytes> EARLY from its next
     // reserve() on, so that a correct kernel writes into the fence (guard mode only; "" / "none" clears every shrink)
@@ -1199,6 +1200,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   if (nq == 0) return SEGVLAD_OK;
   if (!Q || !d2_out || !idx_out) return ctx->fail(SEGVLAD_ERR_ARG, "search: null pointer");
   if (ctx->db_d == 0) return ctx->fail(SEGVLAD_ERR_STATE, "search: the index is empty and has no dimension yet");
+  if (ctx->opt.debug_fail_search) return ctx->fail(SEGVLAD_ERR_STATE, "search: failing on request (option debug_fail_search)");
   const int d = ctx->db_d;
   const int64_t n = ctx->db_n;
   ctx->f16_scale_dev = nullptr;

@@ -8,7 +8,26 @@
 // dependency on it, and a process that already carries an RCCL (PyTorch-ROCm ships one) shares that copy instead of
 // loading a second.  Every failure is an error code (SEGVLAD_ERR_COMM) with the RCCL message in segvlad_last_error.
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// No RCCL headers on the build machine: the handful of declarations the run-time binding needs (RCCL keeps NCCL's ABI:
+// a 128-byte unique id, an opaque communicator, the result / data-type enumerations below), so that the single-GPU build
+// really has no dependency on RCCL -- neither at link time nor at compile time.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <mutex>
 
@@ -22,6 +41,7 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -73,6 +93,7 @@ const char* rccl_load() {
   SV_SYM(GetUniqueId, "ncclGetUniqueId")
   SV_SYM(CommInitRank, "ncclCommInitRank")
   SV_SYM(CommDestroy, "ncclCommDestroy")
+  SV_SYM(CommAbort, "ncclCommAbort")
   SV_SYM(AllGather, "ncclAllGather")
   SV_SYM(GetErrorString, "ncclGetErrorString")
 #undef SV_SYM
@@ -100,18 +121,23 @@ __global__ __launch_bounds__(256) void pack_topk_kernel(const float* __restrict_
 }
 
 // gathered records [world][nq][k] (rank-major) -> the merge's layout [nq][world * k] (shard-major within a row)
+// A rank's block is its nq * k records followed by ONE trailer record {local status, 0, 0} (see segvlad_search_sharded); the
+// trailers' status words are collected into flags[world].
 __global__ __launch_bounds__(256) void unpack_topk_kernel(const uint32_t* __restrict__ rec, int world, int nq, int k,
-                                                          float* __restrict__ d2c, int64_t* __restrict__ idc) {
+                                                          float* __restrict__ d2c, int64_t* __restrict__ idc,
+                                                          uint32_t* __restrict__ flags) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)world * nq * k;
+  const int64_t per = (int64_t)nq * k, total = (int64_t)world * per;
+  if (j < world) flags[j] = rec[3 * ((j + 1) * (per + 1) - 1)];
   if (j >= total) return;
-  const int r = (int)(j / ((int64_t)nq * k));
-  const int64_t rem = j - (int64_t)r * nq * k;
+  const int r = (int)(j / per);
+  const int64_t rem = j - (int64_t)r * per;
   const int64_t q = rem / k;
   const int c = (int)(rem - q * k);
   const int64_t o = q * ((int64_t)world * k) + (int64_t)r * k + c;
-  d2c[o] = __uint_as_float(rec[3 * j]);
-  idc[o] = (int64_t)((uint64_t)rec[3 * j + 1] | ((uint64_t)rec[3 * j + 2] << 32));
+  const int64_t src = 3 * (j + r);   // r trailers lie in front of rank r's records
+  d2c[o] = __uint_as_float(rec[src]);
+  idc[o] = (int64_t)((uint64_t)rec[src + 1] | ((uint64_t)rec[src + 2] << 32));
 }
 
 }  // namespace
@@ -167,17 +193,32 @@ int segvlad_comm_info(segvlad_ctx* ctx, int* rank_out, int* world_out, char* ori
   return SEGVLAD_OK;
 }
 
+// A collective must be ENTERED by every rank or by none.  Argument / state errors (the same on every rank of a correct
+// program) return before it; a failure only THIS rank can have -- out of memory for the exchange buffers -- cannot join the
+// collective any more and aborts the communicator instead (ncclCommAbort: the peers' pending collective fails instead of
+// waiting for ever; the communicator is gone on this rank, segvlad_comm_init makes a new one).
+static int comm_abort_local(segvlad_ctx* ctx, const char* what, int rc) {
+  char why[400];
+  snprintf(why, sizeof(why), "%s", ctx->err);
+  if (ctx->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(reinterpret_cast<ncclComm_t>(ctx->comm));
+  ctx->comm = nullptr;
+  ctx->comm_rank = 0;
+  ctx->comm_world = 1;
+  return ctx->fail(rc, "%s: local failure before the collective (%s); the communicator was aborted", what, why);
+}
+
 int segvlad_allgather_rows(segvlad_ctx* ctx, const float* local_rows, int n_local, int d, float* all_rows) {
   if (!ctx) return SEGVLAD_ERR_ARG;
   sv_begin(ctx);
   if (!ctx->comm) return ctx->fail(SEGVLAD_ERR_STATE, "allgather_rows: call segvlad_comm_init first");
   if (n_local < 0 || d <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "allgather_rows: bad shape");
-  if (n_local == 0) return SEGVLAD_OK;
+  if (n_local == 0) return SEGVLAD_OK;   // (n_local is the same on every rank: segvlad.h)
   if (!local_rows || !all_rows) return ctx->fail(SEGVLAD_ERR_ARG, "allgather_rows: null pointer");
   const void* din;
   void* dout;
-  SV_TRY(sv_in(ctx, local_rows, (size_t)n_local * d * 4, &din));
-  SV_TRY(sv_out(ctx, all_rows, (size_t)ctx->comm_world * n_local * d * 4, &dout));
+  int rc = sv_in(ctx, local_rows, (size_t)n_local * d * 4, &din);
+  if (rc == SEGVLAD_OK) rc = sv_out(ctx, all_rows, (size_t)ctx->comm_world * n_local * d * 4, &dout);
+  if (rc != SEGVLAD_OK) return comm_abort_local(ctx, "allgather_rows", rc);
   SV_RCCL(g_rccl.AllGather(din, dout, (size_t)n_local * d, ncclFloat, reinterpret_cast<ncclComm_t>(ctx->comm), ctx->stream));
   return sv_finish(ctx);
 }
@@ -191,37 +232,54 @@ int segvlad_search_sharded(segvlad_ctx* ctx, const float* Q, int nq, int k, int6
   if (!Q || !d2_out || !idx_out) return ctx->fail(SEGVLAD_ERR_ARG, "search_sharded: null pointer");
   const int world = ctx->comm_world;
   const int64_t total = (int64_t)nq * k;
-  // local lists, the packed records of this rank and of all ranks, the merge's operands
-  SV_HIP(ctx->s_sh_d2.reserve((size_t)total * 4));
-  SV_HIP(ctx->s_sh_idx.reserve((size_t)total * 8));
-  SV_HIP(ctx->s_sh_rec.reserve((size_t)total * 12));
-  SV_HIP(ctx->s_sh_all.reserve((size_t)world * total * 12));
-  SV_HIP(ctx->s_sh_d2c.reserve((size_t)world * total * 4));
-  SV_HIP(ctx->s_sh_idc.reserve((size_t)world * total * 8));
+  // local lists, the packed records of this rank (+ its trailer record) and of all ranks, the merge's operands, the flags
+  hipError_t he = ctx->s_sh_d2.reserve((size_t)total * 4);
+  if (he == hipSuccess) he = ctx->s_sh_idx.reserve((size_t)total * 8);
+  if (he == hipSuccess) he = ctx->s_sh_rec.reserve((size_t)(total + 1) * 12);
+  if (he == hipSuccess) he = ctx->s_sh_all.reserve((size_t)world * (total + 1) * 12);
+  if (he == hipSuccess) he = ctx->s_sh_d2c.reserve((size_t)world * total * 4);
+  if (he == hipSuccess) he = ctx->s_sh_idc.reserve((size_t)world * total * 8 + (size_t)world * 4);
+  if (he != hipSuccess) {
+    (void)ctx->fail(SEGVLAD_ERR_NOMEM, "exchange buffers: %s", hipGetErrorString(he));
+    return comm_abort_local(ctx, "search_sharded", SEGVLAD_ERR_NOMEM);
+  }
   float* ld2 = ctx->s_sh_d2.as<float>();
   int64_t* lidx = ctx->s_sh_idx.as<int64_t>();
+  uint32_t* flags = reinterpret_cast<uint32_t*>(ctx->s_sh_idc.as<int64_t>() + (size_t)world * total);
+  // The local search may fail on THIS rank only (its shard, its memory).  The rank then still enters the all-gather -- with
+  // (inf, -1) records, which never win a merge, and its status in the trailer record -- so that every rank leaves the
+  // collective and every rank returns an error (the failing rank its own, the others SEGVLAD_ERR_COMM naming it).
+  int local_rc = SEGVLAD_OK;
+  char local_err[sizeof(ctx->err)] = {0};
   if (ctx->db_n > 0) {
     // (segvlad_search resets the staging state: Q is handed over as it came -- host or device)
-    SV_TRY(segvlad_search(ctx, Q, nq, k, ld2, lidx));
+    local_rc = segvlad_search(ctx, Q, nq, k, ld2, lidx);
+    if (local_rc != SEGVLAD_OK) snprintf(local_err, sizeof(local_err), "%s", ctx->err);
     sv_begin(ctx);
-  } else {   // an empty shard contributes (inf, -1)
+  }
+  if (ctx->db_n <= 0 || local_rc != SEGVLAD_OK) {   // an empty (or failed) shard contributes (inf, -1)
     SV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ld2), 0x7f800000, (size_t)total, ctx->stream));
     SV_HIP(hipMemsetAsync(lidx, 0xff, (size_t)total * 8, ctx->stream));
   }
   void *od, *oi;
-  SV_TRY(sv_out(ctx, d2_out, (size_t)total * 4, &od));
-  SV_TRY(sv_out(ctx, idx_out, (size_t)total * 8, &oi));
+  int rc_out = sv_out(ctx, d2_out, (size_t)total * 4, &od);
+  if (rc_out == SEGVLAD_OK) rc_out = sv_out(ctx, idx_out, (size_t)total * 8, &oi);
+  if (rc_out != SEGVLAD_OK) return comm_abort_local(ctx, "search_sharded", rc_out);
+  std::vector<uint32_t> hflags((size_t)world, 0u);
   {
     StageScope sc(ctx, "shard_exchange");
     hipLaunchKernelGGL(pack_topk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ld2, lidx, total, id_base,
                        ctx->s_sh_rec.as<uint32_t>());
     SV_HIP(hipGetLastError());
-    SV_RCCL(g_rccl.AllGather(ctx->s_sh_rec.p, ctx->s_sh_all.p, (size_t)total * 12, ncclUint8, reinterpret_cast<ncclComm_t>(ctx->comm),
+    SV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->s_sh_rec.as<uint32_t>() + 3 * total), local_rc != SEGVLAD_OK ? 1 : 0, 3,
+                             ctx->stream));   // the trailer record: {status, status, status}
+    SV_RCCL(g_rccl.AllGather(ctx->s_sh_rec.p, ctx->s_sh_all.p, (size_t)(total + 1) * 12, ncclUint8, reinterpret_cast<ncclComm_t>(ctx->comm),
                              ctx->stream));
     const int64_t all = (int64_t)world * total;
     hipLaunchKernelGGL(unpack_topk_kernel, dim3((unsigned)((all + 255) / 256)), dim3(256), 0, ctx->stream, ctx->s_sh_all.as<uint32_t>(),
-                       world, nq, k, ctx->s_sh_d2c.as<float>(), ctx->s_sh_idc.as<int64_t>());
+                       world, nq, k, ctx->s_sh_d2c.as<float>(), ctx->s_sh_idc.as<int64_t>(), flags);
     SV_HIP(hipGetLastError());
+    SV_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)world * 4, hipMemcpyDeviceToHost, ctx->stream));
     sc.count(3);
   }
   {
@@ -229,7 +287,12 @@ int segvlad_search_sharded(segvlad_ctx* ctx, const float* Q, int nq, int k, int6
     SV_TRY(sv_launch_merge_topk(ctx, ctx->s_sh_d2c.as<float>(), ctx->s_sh_idc.as<int64_t>(), nq, world * k, k, (float*)od, (int64_t*)oi));
     sc.count();
   }
-  return sv_finish(ctx);
+  SV_HIP(hipStreamSynchronize(ctx->stream));   // the status words of all ranks (4 bytes each)
+  const int rc_fin = sv_finish(ctx);
+  if (local_rc != SEGVLAD_OK) return ctx->fail(local_rc, "search_sharded: this rank's local search failed: %s", local_err);
+  for (int r = 0; r < world; ++r)
+    if (hflags[(size_t)r]) return ctx->fail(SEGVLAD_ERR_COMM, "search_sharded: rank %d failed its local search (every rank returns an error)", r);
+  return rc_fin;
 }
 
 }  // extern "C"

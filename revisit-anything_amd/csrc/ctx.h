@@ -138,6 +138,7 @@ struct SvOptions {
   int knn_heuristic = 1;  // 1: low-rank (verified) thresholds in the level scheme; 0: rigorous k-th-rank thresholds only
   int assign_narrow = 0;  // 1: force the narrow assignment kernel
   int agg_kpb = 4;        // clusters per aggregation workgroup
+  int debug_fail_search = 0;   // tests only: segvlad_search fails at once (SEGVLAD_ERR_STATE) -- the sharded entry's error path
   int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises); 7: token_norms_kernel waits for every
                           //    outstanding memory operation at every step (verification of its counted waits: same bits)
   int small_plan = 1;     // <= 128 queries (one query image per pass): one filter level behind an exact sample of 2048..4096

@@ -1056,23 +1056,29 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     // ---- wave-private epilogue (EPI = 1; persistent + biased kernels) ------------------------------------------------
     // Nothing in it is shared between waves, so nothing in it waits for another wave: every wave stages the records of ITS
     // 64 query rows, screens its 64 x 128 block into its own LDS list, tests the list densely and takes ONE returning global
-    // atomic per survivor (survivors are ~0.2 per row and tile: the per-row aggregation of EPI = 0 bought two workgroup
-    // barriers, an LDS atomic per survivor and a second walk of the list for nothing).  The ticket's round trip overlaps
-    // the wait for the next tile's head, which the wave has to sit out anyway; the stores are left in flight.  A block that
-    // fills its list (spatially coherent databases) flushes it and re-enters the screening pass where it stopped (a jump
-    // table: the 32 unrolled screening steps are the cases of a switch).
+    // atomic per ROW WITH SURVIVORS (ranks inside a row from a wave-private LDS counter): the reservation's round trip
+    // overlaps the wait for the next tile's head, which the wave has to sit out anyway, and the stores are left in flight.
+    // A block that fills its list (spatially coherent databases: the 50 segments of a query image against the 200 rows of the
+    // same place are thousands of hits in ONE 64 x 128 block) flushes it in place and goes on screening -- still one round
+    // trip per flush.  (First version: one returning global atomic per survivor, 64 at a time -- fine at ~6 survivors per
+    // block, 150 round trips for such a block.  A re-entrant screening pass -- flush, then jump back in -- turns the pass
+    // into a loop whose invariants the compiler hoists and spills: 80 dwords.)
     static_assert(PERSIST && BIAS && TM == 2 && TN == 4 && !ACC_A, "wave-private epilogue: 64 x 128 wave tiles of the biased persistent kernel");
-    constexpr int WSZ = (512 + 256 + (LCAP + 1) * 8 + 15) & ~15;
+    constexpr int LCAPE = 864;   // records per wave list
+    constexpr int WSZ = (1024 + (LCAPE + 1) * 8 + 15) & ~15;
     static_assert((size_t)NW * WSZ <= 2 * (size_t)PA, "epilogue scratch");
     // Every LDS access between the head's DMA instructions and the wait inside the first flush is RAW (inline asm): the
     // compiler cannot tell DMA'd LDS bytes from any other LDS address and puts s_waitcnt vmcnt(0) in front of every LDS
     // instruction it can see while a DMA is pending -- the wave would sit out the head's flight before its first epilogue
     // instruction (which is what EPI = 0 does).  One wave's LDS instructions execute in order, so a write followed by a read
     // of the same bytes needs no wait in between; reads are waited for with explicit lgkmcnt.
-    const unsigned wb_a = (unsigned)(size_t)(lptr_t)(lds + (size_t)w * WSZ);   // [64] {||q||^2, exact limit} | +512: [64] screening
-    {                                                                          // bounds | +768: [LCAP + 1] hits {accumulator, row << 16 | column}
+    // per wave: [64] {||q||^2, exact limit} | +512: [64] screening bounds | +768: [64] survivors per row, then the row's first
+    // global slot | +1024: [LCAPE + 1] hits {accumulator bits -> d2~, row << 16 | rank in the row << 8 | column}
+    const unsigned wb_a = (unsigned)(size_t)(lptr_t)(lds + (size_t)w * WSZ);
+    {
       const float2 qr = make_float2(st_q2, st_lim);
-      asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3 offset:512" ::"v"(wb_a + 8u * (unsigned)l), "v"(qr), "v"(wb_a + 4u * (unsigned)l), "v"(st_tau)
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3 offset:512\n\tds_write_b32 %2, %4 offset:768" ::"v"(wb_a + 8u * (unsigned)l), "v"(qr),
+                   "v"(wb_a + 4u * (unsigned)l), "v"(st_tau), "v"(0u)
                    : "memory");
     }
     SV_PHASE(2)
@@ -1101,38 +1107,56 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     uint32_t wave_cnt = 0;   // wave-uniform
     const uint32_t colbase = (uint32_t)(wn * (32 * TN) + (MF ? (l & 15) : i)), rowsel = (uint32_t)(4 * (MF ? (l >> 4) : kk));
     const int64_t rowbase = m0 + wm * 64;
-    // dense exact test of the list: one returning global atomic per survivor, the stores left in flight
+    // dense exact test of the list, one returning global atomic per row with survivors, the stores left in flight
     auto flush = [&]() {
       const uint32_t n_w = wave_cnt;
-      bool first = true;
-      for (uint32_t tb = 0; first || tb < n_w; tb += 64u) {
+      for (uint32_t tb = 0; tb < n_w; tb += 64u) {   // exact test; a survivor draws its rank inside its row
         const uint32_t t = tb + (uint32_t)l;
-        bool ok = false;
-        float v = 0.f;
-        int64_t row = 0;
-        uint32_t col = 0u;
         if (t < n_w) {
           uint2 rec;
           float2 rr;
-          asm volatile("ds_read_b64 %0, %1 offset:768\n\ts_waitcnt lgkmcnt(0)" : "=v"(rec) : "v"(wb_a + 8u * t) : "memory");
+          asm volatile("ds_read_b64 %0, %1 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(rec) : "v"(wb_a + 8u * t) : "memory");
           const unsigned lrow = rec.y >> 16;
           asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(wb_a + 8u * lrow) : "memory");
-          v = __fmaf_rn(-2.f, __uint_as_float(rec.x) * inv_scale, rr.x);
-          ok = v <= rr.y && v < INFINITY;   // +inf: padding columns beyond N (admitted by the screen when thr = +inf)
-          row = rowbase + (int64_t)lrow;
-          col = rec.y & 0xffffu;
-        }
-        uint32_t slot = 0u;
-        if (ok) slot = atomicAdd(&cand_cnt[row], 1u);
-        // the ticket -- and, the first time round, this wave's DMA pieces of the next tile's head (requested before the
-        // screening pass; loads retire in order): the barrier at the top of the tile loop makes that true for every wave
-        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        first = false;
-        if (ok && slot < (uint32_t)cap) {
-          cand_d2[row * cap + slot] = v;
-          cand_id[row * cap + slot] = (uint32_t)((n0 + (int64_t)col) * b_stride);
+          const float v = __fmaf_rn(-2.f, __uint_as_float(rec.x) * inv_scale, rr.x);
+          if (v <= rr.y && v < INFINITY) {   // +inf: padding columns beyond N (admitted by the screen when thr = +inf)
+            uint32_t rank;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:768\n\ts_waitcnt lgkmcnt(0)" : "=v"(rank) : "v"(wb_a + 4u * lrow), "v"(1u) : "memory");
+            rec.x = __float_as_uint(v);
+            rec.y |= rank << 8;              // (< 128 survivors per row and block; the column keeps bits 0-7)
+          } else {
+            rec.y = 0xffffffffu;             // screened in by the slack only
+          }
+          asm volatile("ds_write_b64 %0, %1 offset:1024" ::"v"(wb_a + 8u * t), "v"(rec) : "memory");
         }
       }
+      uint32_t c;
+      asm volatile("ds_read_b32 %0, %1 offset:768\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(wb_a + 4u * (unsigned)l) : "memory");
+      uint32_t base = 0u;
+      if (c) base = atomicAdd(&cand_cnt[rowbase + l], c);   // (rows >= M screen with +inf: no survivors)
+      // the reservations -- and, the first time round, this wave's DMA pieces of the next tile's head (requested before the
+      // screening pass; loads retire in order): the barrier at the top of the tile loop makes that true for every wave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("ds_write_b32 %0, %1 offset:768" ::"v"(wb_a + 4u * (unsigned)l), "v"(base) : "memory");
+      for (uint32_t tb = 0; tb < n_w; tb += 64u) {
+        const uint32_t t = tb + (uint32_t)l;
+        if (t < n_w) {
+          uint2 rec;
+          asm volatile("ds_read_b64 %0, %1 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(rec) : "v"(wb_a + 8u * t) : "memory");
+          if (rec.y != 0xffffffffu) {
+            const unsigned lrow = rec.y >> 16;
+            uint32_t b0;
+            asm volatile("ds_read_b32 %0, %1 offset:768\n\ts_waitcnt lgkmcnt(0)" : "=v"(b0) : "v"(wb_a + 4u * lrow) : "memory");
+            const uint32_t slot = b0 + ((rec.y >> 8) & 0xffu);
+            if (slot < (uint32_t)cap) {
+              const int64_t row = rowbase + (int64_t)lrow;
+              cand_d2[row * cap + slot] = __uint_as_float(rec.x);
+              cand_id[row * cap + slot] = (uint32_t)((n0 + (int64_t)(rec.y & 0xffu)) * b_stride);
+            }
+          }
+        }
+      }
+      asm volatile("ds_write_b32 %0, %1 offset:768" ::"v"(wb_a + 4u * (unsigned)l), "v"(0u) : "memory");
       wave_cnt = 0u;
     };
     if constexpr (MF == 1) {
@@ -1158,12 +1182,12 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
                 const uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
                 if (hit) {
                   const uint2 rec = make_uint2(__float_as_uint(acc16[mt][nt][j]), rc + (uint32_t)(nt * 16));
-                  asm volatile("ds_write_b64 %0, %1 offset:768" ::"v"(wb_a + 8u * pos), "v"(rec) : "memory");
+                  asm volatile("ds_write_b64 %0, %1 offset:1024" ::"v"(wb_a + 8u * pos), "v"(rec) : "memory");
                 }
                 wave_cnt += (uint32_t)__popcll(mk);
               }
             }
-            if (wave_cnt > (uint32_t)(LCAP - 512)) flush();   // (a step adds up to 8 x 64 records)
+            if (wave_cnt > (uint32_t)(LCAPE - 512)) flush();   // (a step adds up to 8 x 64 records)
           }
         }
     } else {
@@ -1186,13 +1210,13 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
               const uint32_t pos = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
               if (hit) {
                 const uint2 rec = make_uint2(__float_as_uint(acc[mt][nt][r]), rc + (uint32_t)(nt * 32));
-                asm volatile("ds_write_b64 %0, %1 offset:768" ::"v"(wb_a + 8u * pos), "v"(rec) : "memory");
+                asm volatile("ds_write_b64 %0, %1 offset:1024" ::"v"(wb_a + 8u * pos), "v"(rec) : "memory");
               }
               wave_cnt += (uint32_t)__popcll(mk);
             }
           }
           // the next step could overflow the list (spatially coherent databases): flush it here and go on
-          if (wave_cnt > (uint32_t)(LCAP - 256)) flush();
+          if (wave_cnt > (uint32_t)(LCAPE - 256)) flush();
         }
       }
     }

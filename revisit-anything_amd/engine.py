@@ -137,11 +137,12 @@ class SegVLADEngine:
         self._check(self.lib.segvlad_comm_info(self._h, C.byref(r), C.byref(w), o, 256), "comm_info")
         return {"rank": r.value, "world": w.value, "rccl": o.value.decode(errors="replace")}
 
-    def allgather_rows(self, x) -> torch.Tensor:
-        """[n_local, d] of every rank -> [world * n_local, d] in rank order (equal slices), one RCCL all-gather."""
+    def allgather_rows(self, x, world: Optional[int] = None) -> torch.Tensor:
+        """[n_local, d] fp32 of every rank -> [world * n_local, d] in rank order (equal slices), one RCCL all-gather.
+        ``world``: the communicator's size if the caller knows it (saves a C call per gather)."""
         t = _as(x, np.float32, torch.float32)
         n, d = int(t.shape[0]), int(t.shape[1])
-        out = self._empty((self.comm_info()["world"] * n, d), torch.float32)
+        out = self._empty(((int(world) if world else self.comm_info()["world"]) * n, d), torch.float32)
         self._stream()
         self._check(self.lib.segvlad_allgather_rows(self._h, _ptr(t), n, d, _ptr(out)), "allgather_rows")
         self._keep = [t]

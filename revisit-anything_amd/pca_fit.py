@@ -157,14 +157,19 @@ def _chol_qr2_cols(Y, shift_tries: int = 3):
 
 
 def fit_pca_device(engine, X, n_components: int = 1024, *, n_oversamples: int = 32, n_iter: int = 8, seed: int = 0,
-                   timings: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+                   timings: Optional[dict] = None, stats: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """``fit_pca`` with everything but two q x q factorisations on the device: X [n, KD] fp32 stays in HBM (50 000 x 98 304 =
     19.7 GB, + its transpose), the two tall products of every half step run on the C-ABI's projection GEMM
     (segvlad_pca_apply: three fp16 MFMA products of a two-term split, fp32-class) in TWO contexts -- one keeps ``X^T`` as
     its "components" for the whole fit, the other receives the current basis -- and the re-orthonormalisation is
     CholeskyQR2 (Gram matrices in fp64 on the device, q x q Cholesky on the host).  The Rayleigh-Ritz step diagonalises the
     q x q Gram matrix of X_c V instead of taking an SVD of the [n, q] block.  Same conventions / return value as fit_pca.
-    (Host QR of the [98 304, 1056] and [50 000, 1056] blocks was > 90 % of the round-2 fit.)"""
+    (Host QR of the [98 304, 1056] and [50 000, 1056] blocks was > 90 % of the round-2 fit.)
+
+    ``engine`` only names the device: both products run in contexts of the fit's own, so the caller's engine -- its PCA model
+    in particular -- is left exactly as it was (round 3 left the last iteration basis in it).  ``stats`` (optional dict)
+    receives ``total_variance``: the sum of the columns' sample variances, which sklearn's own fit derives
+    ``explained_variance_ratio_`` and ``noise_variance_`` from (to_sklearn_pca)."""
     import time
 
     import torch
@@ -190,13 +195,21 @@ def fit_pca_device(engine, X, n_components: int = 1024, *, n_oversamples: int = 
     eng_t = SegVLADEngine(dev)                                                      # comps = X^T, set once
     eng_t.pca_set(None, Xt, None, whiten=False)
     del Xt
+    eng_v = SegVLADEngine(dev)                                                      # comps = the current basis, set every half step
+    if stats is not None:   # sum of the columns' sample variances, in fp64, a block of rows at a time
+        tv = torch.zeros((), dtype=torch.float64, device=dev)
+        for r0 in range(0, n, 2048):
+            blk = X[r0:r0 + 2048].double() - mean64[None, :]
+            tv += (blk * blk).sum()
+            del blk
+        stats["total_variance"] = float(tv.item()) / max(n - 1, 1)
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed))
     Vt = _chol_qr2_cols(torch.randn(kd, q, device=dev, generator=g)).t().contiguous()          # [q, KD], orthonormal rows
 
     def xc_v(Vt_):       # X_c V = X V - 1 (mean^T V): [n, q]
-        engine.pca_set(None, Vt_, None, whiten=False)
-        Y = engine.pca_apply(X, l2norm=False)
+        eng_v.pca_set(None, Vt_, None, whiten=False)
+        Y = eng_v.pca_apply(X, l2norm=False)
         return Y - (Vt_.double() @ mean64).float()[None, :]
 
     def xct_u_t(U):      # (X_c^T U)^T = U^T X - (U^T 1) mean^T: [q, KD]
@@ -226,6 +239,7 @@ def fit_pca_device(engine, X, n_components: int = 1024, *, n_oversamples: int = 
     comps = (comps * signs[:, None]).float().cpu().numpy()
     var = (s2 / (n - 1)).astype(np.float32)
     eng_t.close()
+    eng_v.close()
     if timings is not None:
         torch.cuda.synchronize()
         t_end = time.perf_counter()
@@ -234,9 +248,13 @@ def fit_pca_device(engine, X, n_components: int = 1024, *, n_oversamples: int = 
     return mean64.float().cpu().numpy(), comps, var
 
 
-def to_sklearn_pca(mean, components, explained_variance, n_samples: int, whiten: bool = True):
+def to_sklearn_pca(mean, components, explained_variance, n_samples: int, whiten: bool = True, total_variance: Optional[float] = None):
     """A ``sklearn.decomposition.PCA`` carrying the fitted model -- what the reference pickles (place_rec_pca.py:403-411) and
-    what its ``apply_pca_transform_from_pkl`` (func_vpr.py:1419-1443) unpickles and calls ``.transform`` on."""
+    what its ``apply_pca_transform_from_pkl`` (func_vpr.py:1419-1443) unpickles and calls ``.transform`` on.
+    ``total_variance`` (fit_pca_device's ``stats``): the data's total variance, from which ``explained_variance_ratio_`` and
+    ``noise_variance_`` get the values sklearn's own fit gives them (sklearn/decomposition/_pca.py: ratio = variance / total,
+    noise = (total - retained) / (min(n_samples, n_features) - n_components)); without it the two attributes are left as
+    NaN rather than filled with numbers a reader could mistake for sklearn's (``.transform`` needs neither)."""
     from sklearn.decomposition import PCA
 
     comps = np.asarray(components, dtype=np.float32)
@@ -246,11 +264,16 @@ def to_sklearn_pca(mean, components, explained_variance, n_samples: int, whiten:
     m.components_ = comps
     m.explained_variance_ = var
     m.singular_values_ = np.sqrt(var.astype(np.float64) * max(int(n_samples) - 1, 1)).astype(np.float32)
-    m.explained_variance_ratio_ = var / max(float(var.sum()), 1e-30)    # (relative to the RETAINED variance: the total is not formed)
     m.n_components_ = int(comps.shape[0])
     m.n_features_in_ = int(comps.shape[1])
     m.n_samples_ = int(n_samples)
-    m.noise_variance_ = 0.0
+    if total_variance is not None and total_variance > 0:
+        m.explained_variance_ratio_ = (var.astype(np.float64) / float(total_variance)).astype(np.float32)
+        rest = min(int(n_samples), int(comps.shape[1])) - int(comps.shape[0])
+        m.noise_variance_ = max(float(total_variance) - float(var.astype(np.float64).sum()), 0.0) / rest if rest > 0 else 0.0
+    else:
+        m.explained_variance_ratio_ = np.full(var.shape, np.nan, dtype=np.float32)
+        m.noise_variance_ = float("nan")
     return m
 
 
@@ -305,8 +328,9 @@ def fit_from_store(dino_in, masks_in, image_keys, pipeline, out_pkl: Optional[st
         raise ValueError("no segments sampled")
     X = torch.cat(kept)
     del kept
-    mean, comps, var = fit_pca_device(pipeline.eng, X, n_components=n_components, n_iter=n_iter, seed=seed, timings=timings)
+    st = {}
+    mean, comps, var = fit_pca_device(pipeline.eng, X, n_components=n_components, n_iter=n_iter, seed=seed, timings=timings, stats=st)
     if out_pkl:
         with open(out_pkl, "wb") as f:
-            pickle.dump(to_sklearn_pca(mean, comps, var, n_samples=int(X.shape[0]), whiten=True), f)
+            pickle.dump(to_sklearn_pca(mean, comps, var, n_samples=int(X.shape[0]), whiten=True, total_variance=st.get("total_variance")), f)
     return mean, comps, var

@@ -101,8 +101,9 @@ class ShardedSegmentIndex:
             return local_rows
         mx = max(rows_per_rank)
         x = local_rows.contiguous()
-        if self.native and min(rows_per_rank) == mx and x.dim() == 2:
-            return self.be.allgather_rows(x)
+        if self.native and min(rows_per_rank) == mx and x.dim() == 2 and x.dtype == torch.float32:
+            # (the C-ABI gathers fp32 rows; any other type keeps torch.distributed's collective and its dtype)
+            return self.be.allgather_rows(x, world=self.world)
         if min(rows_per_rank) == mx:   # equal slices (the usual case): ONE all_gather_into_tensor, no padding, no trimming
             out = torch.empty((self.world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             dist.all_gather_into_tensor(out, x, group=self.group)

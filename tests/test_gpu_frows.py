@@ -95,10 +95,21 @@ def test_pca_fit_on_the_device_at_a_reduced_real_shape_and_the_pickle_flow(eng, 
     spec = torch.logspace(0, -1.5, r, device=dev)
     X = (torch.randn(n, r, device=dev, generator=g) * spec) @ (torch.randn(r, kd, device=dev, generator=g) / kd ** 0.5)
     X = X + 0.003 * torch.randn(n, kd, device=dev, generator=g) + 0.02 * torch.randn(kd, device=dev, generator=g) / kd ** 0.5
-    tm = {}
-    mean, comps, var = pca_fit.fit_pca_device(eng, X, n_components=p, n_iter=6, seed=3, timings=tm)
+    tm, st = {}, {}
+    # the caller's engine keeps ITS model through the fit (round 3 left the last iteration basis in it: ADVICE r03)
+    marker = torch.eye(8, 64, device=dev)
+    eng.pca_set(None, marker, None, whiten=False)
+    probe = torch.arange(64, device=dev, dtype=torch.float32)[None, :].contiguous()
+    before = eng.pca_apply(probe, l2norm=False).clone()
+    mean, comps, var = pca_fit.fit_pca_device(eng, X, n_components=p, n_iter=6, seed=3, timings=tm, stats=st)
+    assert torch.equal(eng.pca_apply(probe, l2norm=False), before)
     Xh = X.cpu().numpy()
     ref = PCA(n_components=p, whiten=True, svd_solver="full").fit(Xh.astype(np.float64))
+    # the attributes sklearn's own fit derives from the total variance
+    mdl = pca_fit.to_sklearn_pca(mean, comps, var, n_samples=n, whiten=True, total_variance=st["total_variance"])
+    assert np.allclose(mdl.explained_variance_ratio_, ref.explained_variance_ratio_, rtol=1e-3)
+    assert np.isclose(mdl.noise_variance_, ref.noise_variance_, rtol=1e-3)
+    assert np.isnan(pca_fit.to_sklearn_pca(mean, comps, var, n_samples=n).noise_variance_)   # unknown total: not a made-up number
     assert np.abs(mean - ref.mean_).max() < 1e-6
     assert np.allclose(var, ref.explained_variance_, rtol=5e-4)
     sv = np.linalg.svd(comps.astype(np.float64) @ ref.components_.T, compute_uv=False)

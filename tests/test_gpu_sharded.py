@@ -214,6 +214,16 @@ def test_cabi_sharded_entry_world_1(tmp_path):
     assert bool((pids[:, 5:] == -1).all()) and bool(torch.isinf(pd2[:, 5:]).all()) and bool((pids[:, :5] >= 1000).all())
     e2.comm_destroy()
     assert e2.comm_info()["world"] == 0
+    # a rank whose LOCAL search fails still enters the all-gather (with (inf, -1) records and its status in the trailer
+    # record): it returns its own error AFTER the collective, nobody is left waiting, and the communicator stays usable
+    from revisit_anything_amd._lib import SEGVLAD_ERR_STATE, SegVLADError
+    eng.set_option("debug_fail_search", 1)
+    with pytest.raises(SegVLADError) as ei:
+        eng.search_sharded(Q, 60, id_base=0)
+    assert ei.value.code == SEGVLAD_ERR_STATE and "local search failed" in str(ei.value)
+    eng.set_option("debug_fail_search", 0)
+    sd2b, sidsb = eng.search_sharded(Q, 60, id_base=123456789012)
+    assert torch.equal(sd2b, d2) and torch.equal(sidsb, ids + 123456789012)
     eng.comm_destroy()
     # the sharded index with native_comm (single rank): same results as without
     from revisit_anything_amd.sharded import ShardedSegmentIndex

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(512) void k16(float* out, int iters) {
   for (int j = tid; j < 65536 / 2; j += 512) {
     unsigned h = (j * 2654435761u) ^ (blockIdx.x * 40503u);
     h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
-    reinterpret_cast<_Float16*>(lds)[j] = RND ? (_Float16)(((int)(h & 2047) - 1024) * (1.f / 1024.f)) : (_Float16)(0.001f * (j & 15));
+    // RND 2: random values with the low 3 mantissa bits zero (8 significant bits): does the power-limited rate depend on the
+    // operands' mantissa width?
+    reinterpret_cast<_Float16*>(lds)[j] = RND == 2 ? (_Float16)(((int)(h & 2040) - 1024) * (1.f / 1024.f))
+                                        : RND ? (_Float16)(((int)(h & 2047) - 1024) * (1.f / 1024.f)) : (_Float16)(0.001f * (j & 15));
   }
   __syncthreads();
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -101,6 +104,55 @@ __global__ __launch_bounds__(512) void k16(float* out, int iters) {
   for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 4; ++r) s += acc[a][b][r];
   out[blockIdx.x * 512 + tid] = s;
 }
+// fp32 MFMA, the two shapes (assignment scores, masked aggregation, P-space aggregation, the fp32 filter): same flops per
+// iteration (8 x 32x32x2 = 16 x 16x16x4 = 32768 flop per wave-iteration... x 2)
+template <int SHAPE>
+__global__ __launch_bounds__(512) void kf32(float* out, int iters) {
+  const int tid = threadIdx.x;
+  unsigned h = (tid * 2654435761u) ^ (blockIdx.x * 40503u);
+  h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+  float fa[4], fb[4];
+  for (int t = 0; t < 4; ++t) { fa[t] = ((int)((h >> (t * 3)) & 2047) - 1024) * (1.f / 1024.f); fb[t] = ((int)((h >> (t * 5 + 1)) & 2047) - 1024) * (1.f / 1024.f); }
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  float s = 0.f;
+  if (SHAPE == 0) {
+    f32x16 acc[2][4];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+  } else {
+    f32x4 acc[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 4; ++r) s += acc[a][b][r];
+  }
+  out[blockIdx.x * 512 + tid] = s;
+}
+template <int SHAPE>
+void runf32(const char* name, float* out, int iters, int blocks) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((kf32<SHAPE>), dim3(blocks), dim3(512), 0, 0, out, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((kf32<SHAPE>), dim3(blocks), dim3(512), 0, 0, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double flop = (double)blocks * 8 * iters * (SHAPE == 0 ? 8 * 4096.0 : 16 * 2048.0);
+  printf("%-44s blocks=%d iters=%d: %.3f ms -> %.1f TFLOP/s\n", name, blocks, iters, ms, flop / ms / 1e9);
+}
+
 template <int RND>
 void run16(const char* name, float* out, int iters, int blocks) {
   hipEvent_t e0, e1;
@@ -143,6 +195,9 @@ int main(int argc, char** argv) {
     run<0, 0>("mfma only (smooth data)", out, iters, blocks, src, src_bytes);
     run<0, 1>("mfma only (random data)", out, iters, blocks, src, src_bytes);
     run16<1>("mfma 16x16x32 only (random data)", out, iters, blocks);
+    run16<2>("mfma 16x16x32 only (random, 8-bit mantissas)", out, iters, blocks);
+    runf32<0>("fp32 mfma 32x32x2 only (random data)", out, iters / 8, blocks);
+    runf32<1>("fp32 mfma 16x16x4 only (random data)", out, iters / 8, blocks);
     run<1, 1>("mfma + 6 ds_read_b128 / 8 mfma (random)", out, iters, blocks, src, src_bytes);
     run<2, 1>("  + s_barrier / 32 mfma", out, iters, blocks, src, src_bytes);
     run<3, 1>("  + 8 DMA pieces / 32 mfma + vmcnt", out, iters, blocks, src, src_bytes);
