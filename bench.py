@@ -899,16 +899,20 @@ def shard_sim(a, W):
         except Exception:
             pass
     gather_bytes, rec_bytes = nQ * S * P * 4, nQ * S * kv * 12
-    # ring all-gather over xGMI: every rank receives (W-1)/W of the total through its links; one link ~ 50 GB/s effective
-    # per direction is the conservative planning figure (7 links x ~153 GB/s peak per GPU, MI355X_MICROARCH.md)
-    est_comm_ms = (gather_bytes * (W - 1) / W + rec_bytes * (W - 1)) / 50e9 * 1e3
+    # all-gather over xGMI (fully connected inside a node, 7 links per GPU, ~153 GB/s peak each: MI355X_MICROARCH.md): every
+    # rank receives (W-1)/W of the total, one peer per link, all links at once; 50 GB/s per link is a conservative planning
+    # figure for a collective of this size, the one-link serial figure is the pessimistic bound
+    bytes_in = gather_bytes * (W - 1) / W + rec_bytes * (W - 1)
+    est_comm_ms = bytes_in / (min(W - 1, 7) * 50e9) * 1e3
+    est_comm_ms_one_link = bytes_in / 50e9 * 1e3
     eng.close()
     torch.cuda.empty_cache()
     return {"world": W, "per_rank_ms": ms, "stages_ms": stages, "shard_rows": nR_l * S, "query_images_described": nQ_l,
             "implied_upper_bound_images_per_s": nQ / (ms * 1e-3),
             "implied_upper_bound_with_comm_estimate_images_per_s": nQ / ((ms + est_comm_ms) * 1e-3),
             "collectives_not_executed": {"query_descriptor_allgather_bytes_total": gather_bytes, "topk_record_allgather_bytes_per_rank": rec_bytes,
-                                         "estimate_ms_at_50GBs_per_link": est_comm_ms},
+                                         "estimate_ms_at_50GBs_per_link_all_links": est_comm_ms,
+                                         "estimate_ms_at_50GBs_one_link": est_comm_ms_one_link},
             "note": "one rank's compute of a W-way run on ONE GPU (host-side torch glue of the emulation included in per_rank_ms): an "
                     "UPPER bound on the W-GPU rate -- collectives, their synchronisation and load imbalance come on top; "
                     "the strong-scaling efficiency this implies against the N=1 line is value_bound / (W x N=1 value)"}

@@ -257,6 +257,8 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "f16_walk")) return as_int(&o.f16_walk);
   if (!strcmp(key, "f16_epi")) return as_int(&o.f16_epi);
   if (!strcmp(key, "f16_mf")) return as_int(&o.f16_mf);
+  if (!strcmp(key, "f16_deep_cfg")) return as_int(&o.f16_deep_cfg);
+  if (!strcmp(key, "f16_pp")) return as_int(&o.f16_pp);
   if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);
   if (!strcmp(key, "x3_gm")) return as_int(&o.x3_gm);
   if (!strcmp(key, "search_stats")) return as_int(&o.search_stats);
@@ -1363,7 +1365,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     // its margin: bias_mult = 1 + max||r|| / (2 min||q||), 1.5 for unit vectors
     float bias_mult = 1.f;
     ctx->f16_bias_ok = false;
-    if (nq > 128 && (ctx->opt.f16_cfg < 0 || ctx->opt.f16_cfg == 250) && !sv_f16_kblock(ctx->opt, d)) {
+    if (nq > 128 && (ctx->opt.f16_cfg < 0 || ctx->opt.f16_cfg == 250 || ctx->opt.f16_cfg == 300)) {   // (deep rows too: round 4)
       float q2min = 0.f;
       SV_TRY(sv_row_norm_min(ctx, qn, nq, &q2min));
       if (q2min > 0.f && pl.rn_max > 0.f) {

@@ -130,6 +130,10 @@ struct SvOptions {
                           // through the database blocks, bit 1 = odd steps run their k-tiles backwards (-1 = default, see
                           // launch_f16_filter); never changes a result
   int f16_mf = -1;        // MFMA shape of the persistent biased fp16 filter: 0 = 32 x 32 x 16, otherwise 16 x 16 x 32 (needs f16_epi != 0)
+  int f16_deep_cfg = -1;  // deep rows (blocked accumulation): -1 / 4 = 8 waves of 64 x 64 on 256 x 128 tiles, 16 x 16 x 32 MFMA, plain loop;
+                          // 0 = 4 waves of 64 x 64 on 128 x 128 tiles, 32 x 32 x 16 MFMA (rounds 2-3); 1, 2, 3: measured variants
+                          // (sv_launch_f16_filter)
+  int f16_pp = -1;        // main batch kernel: 0 = plain loop instead of the ping-pong loop (A/B)
   int f16_epi = -1;       // epilogue of the persistent biased fp16 filter: 0 = workgroup-level reservation (one global atomic per
                           // row and tile, two workgroup barriers), 1 = wave-private (one global atomic per survivor, no barrier)
   int x3_tile = 0;        // PCA split GEMM tile (0 = from the shape, 128, 256)

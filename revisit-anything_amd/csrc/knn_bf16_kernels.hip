@@ -518,14 +518,14 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   constexpr int AUXA = (POL & 2) ? 2 : 0, AUXB = (POL & 1) ? 2 : 0;   // aux = 2: "nt" (streaming) hint
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr bool ACC_A = TM * TN > 8;   // 256 accumulator registers per lane: they live in AGPRs (see acc_elem)
-  static_assert(KBT == 0 || (PP == 0 && !ACC_A), "blocked accumulation: plain loop, two accumulator sets in VGPRs");
+  static_assert(KBT == 0 || ((PP == 0 || MF == 1) && !ACC_A), "blocked accumulation: two accumulator sets in VGPRs; plain loop, or the 16 x 16 x 32 loops");
   constexpr int RB = HBK * 2;            // row bytes per k-tile
   constexpr int CH = RB / 16;            // 16-B chunks per row (4 or 8)
   constexpr int RP = 1024 / RB;          // rows per 1-KiB DMA piece
   constexpr int KS = HBK / 16;           // MFMA k-steps per tile
   constexpr int PA = BM * RB, PB = BN * RB;
   constexpr int JA = BM / RP / NW, JB = BN / RP / NW;  // DMA pieces per wave and operand
-  static_assert(JA * RP * NW == BM && JB * RP * NW == BN && (JA + JB) % KS == 0, "tile/wave geometry");
+  static_assert(JA * RP * NW == BM && JB * RP * NW == BN && (PP > 0 || (JA + JB) % (MF ? 2 : KS) == 0), "tile/wave geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned long long phase_t0 = (ABL == 9 || ABL == 12) ? __builtin_amdgcn_s_memtime() : 0ull;
   // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2); the 32
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // PERSIST: 8 x 32 workgroups stay resident and walk their XCD's sequence 32 positions at a time; the head of the next
   // tile (A(0), B(0), B(1)) is requested before the epilogue of the current one, which hides the ~2 us a fresh
   // workgroup spends waiting for its first operands (6 % of the kernel: one workgroup per CU, nothing else covers it).
-  const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS DMA bases live in M0
   const int wm = w / WN, wn = w % WN;
   const int64_t ldb = (int64_t)d * b_stride;
@@ -616,8 +616,9 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     }
   };
   // BIAS: this lane's column norms of the (next) tile, requested BEFORE the tile's head so that the head's wait covers them
-  static_assert(MF == 0 || (PP > 0 && BIAS && EPI == 1 && BM / (32 * WM) == 2 && BN / (32 * WN) == 4 && HBK == 64 && KBT == 0),
-                "16 x 16 x 32 MFMA: the biased ping-pong kernel with the wave-private epilogue, 64 x 128 wave tiles");
+  static_assert(MF == 0 || (PP >= 0 && BIAS && EPI == 1 && BM / (32 * WM) == 2 && (BN / (32 * WN) == 4 || BN / (32 * WN) == 2) && HBK == 64),
+                "16 x 16 x 32 MFMA: the biased kernels with the wave-private epilogue, wave tiles of 64 rows x 128 or 64 columns");
+  constexpr int TN16 = (BN / WN) / 16;                // MF = 1: column tiles of 16 per wave (8, or 4 with blocked accumulation)
   constexpr int CW = MF ? 16 : 32;                    // columns (and rows) per MFMA tile
   constexpr int NCN = (BN / WN) / CW;                 // column tiles per wave = column norms per lane
   float cnn[NCN];
@@ -652,7 +653,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     for (int nt = 0; nt < NCN; ++nt) cn[nt] = cnn[nt];
   }
   f32x16 acc[MF ? 1 : TM][MF ? 1 : TN];
-  f32x4v acc16[MF ? 4 : 1][MF ? 8 : 1];   // MF = 1: element j of tile (mt, nt) = row mt*16 + 4*(lane>>4) + j, column nt*16 + (lane&15)
+  f32x4v acc16[MF ? 4 : 1][MF ? TN16 : 1];   // MF = 1: element j of tile (mt, nt) = row mt*16 + 4*(lane>>4) + j, column nt*16 + (lane&15)
+  f32x4v accb16[(MF && KBT > 0) ? 4 : 1][(MF && KBT > 0) ? TN16 : 1];   // blocked accumulation: the sum of the finished k-blocks (+ the bias)
   if constexpr (MF == 0) {
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -664,12 +666,19 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       }
   } else {
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < TN16; ++b) {
       const float a0_ = -(cn[b] * (0.5f / inv_scale));
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc16[a][b][r] = a0_;
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (KBT > 0) {   // the bias lives in the sum of the blocks; every block starts at zero
+            accb16[a][b][r] = a0_;
+            acc16[a][b][r] = 0.f;
+          } else {
+            acc16[a][b][r] = a0_;
+          }
+        }
     }
   }
   f32x16 accb[KBT > 0 ? TM : 1][KBT > 0 ? TN : 1];   // blocked accumulation: the sum of the finished k-blocks
@@ -754,7 +763,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
       for (int ph = 0; ph < PPn; ++ph) {
         // ---- load segment: fragments of this phase's k-steps, this phase's share of the DMA pieces ----
-        f16x8 a[MF ? 1 : PH][MF ? 4 : TM], b[MF ? 1 : PH][MF ? 8 : TN];
+        f16x8 a[MF ? 1 : PH][MF ? 4 : TM], b[MF ? 1 : PH][MF ? TN16 : TN];
         if constexpr (MF == 0) {
 #pragma unroll
           for (int k2 = 0; k2 < PH; ++k2) {
@@ -782,8 +791,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
             a[0][t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
           }
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const int rb = wn * 128 + 16 * t + (l & 15);
+          for (int t = 0; t < TN16; ++t) {
+            const int rb = wn * (16 * TN16) + 16 * t + (l & 15);
             b[0][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
           }
         }
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
+            for (int nt = 0; nt < TN16; ++nt)
               acc16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][mt], b[0][nt], acc16[mt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -826,6 +835,19 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       }
       ia ^= 1;
       ib = (ib + 1 >= NB) ? 0 : ib + 1;
+      if constexpr (MF == 1 && KBT > 0) {   // close a k-block (this wave's registers only: no synchronisation; wave-uniform)
+        if ((kt + 1) % (KBT > 0 ? KBT : 1) == 0 || kt + 1 == ntiles) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN16; ++nt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                accb16[mt][nt][r] += acc16[mt][nt][r];
+                acc16[mt][nt][r] = (kt + 1 == ntiles) ? accb16[mt][nt][r] : 0.f;   // last block: acc = the total
+              }
+        }
+      }
     }
     if (!lag) __builtin_amdgcn_s_barrier();  // the leading half waits for the lagging half's last MFMA segment
   } else if constexpr (PP < 0) {
@@ -930,6 +952,55 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #undef SV_RD1
 #undef SV_RD4
 #undef SV_WAIT_FRAGS
+  } else if constexpr (MF == 1) {
+    // the plain loop (one barrier per k-tile) on the 16 x 16 x 32 shape: two k-steps of 32 per k-tile
+    static_assert(MF == 0 || PP != 0 || (KS == 4 && (JA + JB) % 2 == 0), "two k-steps of 32 per 64-deep k-tile");
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
+      const unsigned char* SA = lds + a_off(ia);
+      const unsigned char* SB = lds + b_off(ib);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int cl = 4 * k2 + (l >> 4);
+        f16x8 a[4], b[TN16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ra = wm * 64 + 16 * t + (l & 15);
+          a[t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < TN16; ++t) {
+          const int rb = wn * (16 * TN16) + 16 * t + (l & 15);
+          b[t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
+        }
+#pragma unroll
+        for (int pz = 0; pz < (JA + JB) / 2; ++pz) dma_piece(k2 * ((JA + JB) / 2) + pz, kt, ia ^ 1, ibn);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN16; ++nt) acc16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[nt], acc16[mt][nt], 0, 0, 0);
+      }
+      if (NB == 3 && kt + 2 < ntiles)
+        wait_vm_lgkm0<JB>();
+      else
+        wait_vm_lgkm0<0>();
+      __builtin_amdgcn_s_barrier();
+      ia ^= 1;
+      ib = (ib + 1 >= NB) ? 0 : ib + 1;
+      if constexpr (KBT > 0) {
+        if ((kt + 1) % (KBT > 0 ? KBT : 1) == 0 || kt + 1 == ntiles) {   // close a k-block (wave-uniform)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN16; ++nt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                accb16[mt][nt][r] += acc16[mt][nt][r];
+                acc16[mt][nt][r] = (kt + 1 == ntiles) ? accb16[mt][nt][r] : 0.f;   // last block: acc = the total
+              }
+        }
+      }
+    }
   } else {
   for (int kt = 0; kt < ntiles; ++kt) {
       const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
@@ -999,7 +1070,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt) t += acc16[mt][nt][0] + acc16[mt][nt][3];
+          for (int nt = 0; nt < TN16; ++nt) t += acc16[mt][nt][0] + acc16[mt][nt][3];
       }
     }
     if (t == 12345.678f) cand_cnt[0] = 1;
@@ -1063,10 +1134,10 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     // trip per flush.  (First version: one returning global atomic per survivor, 64 at a time -- fine at ~6 survivors per
     // block, 150 round trips for such a block.  A re-entrant screening pass -- flush, then jump back in -- turns the pass
     // into a loop whose invariants the compiler hoists and spills: 80 dwords.)
-    static_assert(PERSIST && BIAS && TM == 2 && TN == 4 && !ACC_A, "wave-private epilogue: 64 x 128 wave tiles of the biased persistent kernel");
+    static_assert(BIAS && TM == 2 && (TN == 4 || (MF == 1 && TN == 2)) && !ACC_A, "wave-private epilogue: 64-row wave tiles of the biased kernels");
     constexpr int LCAPE = 864;   // records per wave list
     constexpr int WSZ = (1024 + (LCAPE + 1) * 8 + 15) & ~15;
-    static_assert((size_t)NW * WSZ <= 2 * (size_t)PA, "epilogue scratch");
+    static_assert((size_t)NW * WSZ <= (PERSIST ? 2 * (size_t)PA : 2 * (size_t)PA + (size_t)NB * PB), "epilogue scratch");
     // Every LDS access between the head's DMA instructions and the wait inside the first flush is RAW (inline asm): the
     // compiler cannot tell DMA'd LDS bytes from any other LDS address and puts s_waitcnt vmcnt(0) in front of every LDS
     // instruction it can see while a DMA is pending -- the wave would sit out the head's flight before its first epilogue
@@ -1169,13 +1240,17 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
           const float tau = j == 0 ? tq4.x : j == 1 ? tq4.y : j == 2 ? tq4.z : tq4.w;
           float best;
           asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(acc16[mt][0][j]), "v"(acc16[mt][1][j]), "v"(acc16[mt][2][j]));
-          asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(acc16[mt][3][j]), "v"(acc16[mt][4][j]));
-          asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(acc16[mt][5][j]), "v"(acc16[mt][6][j]));
-          asm volatile("v_max_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(acc16[mt][7][j]));
+          if constexpr (TN16 == 8) {
+            asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(acc16[mt][3][j]), "v"(acc16[mt][TN16 == 8 ? 4 : 0][j]));
+            asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(acc16[mt][TN16 == 8 ? 5 : 0][j]), "v"(acc16[mt][TN16 == 8 ? 6 : 0][j]));
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(acc16[mt][TN16 == 8 ? 7 : 0][j]));
+          } else {
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(acc16[mt][3][j]));
+          }
           if (__builtin_amdgcn_ballot_w64(best >= tau) != 0ull) {
             const uint32_t rc = (((uint32_t)(mt * 16 + j) + rowsel) << 16) | colbase;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < TN16; ++nt) {
               const bool hit = acc16[mt][nt][j] >= tau;
               const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
               if (mk != 0ull) {
@@ -1187,7 +1262,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
                 wave_cnt += (uint32_t)__popcll(mk);
               }
             }
-            if (wave_cnt > (uint32_t)(LCAPE - 512)) flush();   // (a step adds up to 8 x 64 records)
+            if (wave_cnt > (uint32_t)(LCAPE - 64 * TN16)) flush();   // (a step adds up to TN16 x 64 records)
           }
         }
     } else {
@@ -1459,8 +1534,22 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   // filter's error margin -- and with it the refine band -- as tight as at d = 1024 (sv_f16_c_eps)
   const int c = sv_f16_kblock(ctx->opt, d) ? 300 : ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : M > 64 ? 63 : 62);
   switch (c) {
-    case 300:   // 4 waves of 64 x 64, two accumulator sets, a k-block of SV_F16_KBLOCK = 16 k-tiles of 64
+    case 300:   // blocked accumulation (deep rows): two accumulator sets, a k-block of SV_F16_KBLOCK = 16 k-tiles of 64
       static_assert(SV_F16_KBLOCK == 16 * 64, "k-block = KBT x HBK");
+      // round 4: 8 waves of 64 x 64 on a 256 x 128 tile, 16 x 16 x 32 MFMA, the plain loop (one barrier per k-tile), biased
+      // accumulators (the bias sits in the block-sum set), wave-private epilogue -- 1.5 x the operand bytes per flop of the
+      // 256 x 256 kernel instead of 2 x, two waves per SIMD instead of one.  Measured, 10 000 x 50 000 x 98 304 (filter launches):
+      // rounds 2-3's 4 waves of 64 x 64 on 128 x 128 tiles with the 32 x 32 x 16 shape 147 ms (f16_deep_cfg = 0; also the
+      // fallback when the norms are too unbalanced for the bias), this kernel 126 ms; the same with the ping-pong loop 165 ms
+      // (1: half the MFMAs per phase of the 64 x 128 wave tiles behind the same barriers), 128 x 128 tiles with the 16 x 16 x 32
+      // shape 234 ms ping-pong / 198 ms plain (2 / 3: one wave per SIMD)
+      if (ctx->f16_bias_ok && ctx->opt.f16_mf != 0 && ctx->opt.f16_epi != 0 && M > 128) {
+        if (ctx->opt.f16_deep_cfg < 0 || ctx->opt.f16_deep_cfg == 4)   // the default: 780 vs 667 TF algorithmic at 10 000 x 50 000 x 98 304
+          return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1>(SV_F16_ARGS);
+        if (ctx->opt.f16_deep_cfg == 1) return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 2, 16, true, 1, 1>(SV_F16_ARGS);
+        if (ctx->opt.f16_deep_cfg == 2) return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 2, 16, true, 1, 1>(SV_F16_ARGS);
+        if (ctx->opt.f16_deep_cfg == 3) return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1>(SV_F16_ARGS);   // plain loop
+      }
       return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 0, 16>(SV_F16_ARGS);
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
     case 200:   // persistent workgroups that request the next tile's head before their epilogue
@@ -1521,6 +1610,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true>(SV_F16_ARGS);      // persistent + ping-pong
         if (ctx->opt.f16_mf == 0)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1>(SV_F16_ARGS);   // + wave-private epilogue
+        if (ctx->opt.f16_pp == 0)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 0, 0, true, 1, 1>(SV_F16_ARGS);   // plain loop (A/B)
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);  // + 16 x 16 x 32 MFMA
       }
       return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true>(SV_F16_ARGS);
@@ -1948,7 +2039,7 @@ __global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ c
   constexpr int PER = 32;   // 8192 keys: the candidate lists' capacity (SV_CAP)
   __shared__ uint32_t xs[2][4];
   __shared__ uint32_t s_n;
-  const int tid = threadIdx.x, w = tid >> 6;
+  const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];
   const uint32_t flagged = ovf_rows[row];

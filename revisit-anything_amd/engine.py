@@ -227,15 +227,17 @@ class SegVLADEngine:
                                          "(duplicate or co-circular centroids): the Delaunay triangulation is not unique")
         return out
 
-    def adjacency_flagged(self, centroids, seg_offsets, order: int):
-        """adjacency() plus one flag byte per image (NumPy uint8 [B]; ONE B-byte read-back): bit 0 = empty mask in the image,
-        bit 1 = non-generic centroid configuration (segvlad_adjacency_flagged).  Never raises on either."""
+    def adjacency_flagged(self, centroids, seg_offsets, order: int, device_flags: bool = False):
+        """adjacency() plus one flag byte per image: bit 0 = empty mask in the image, bit 1 = non-generic centroid
+        configuration (segvlad_adjacency_flagged).  Never raises on either.  The flags come back as a NumPy uint8 [B] (ONE
+        B-byte read-back, i.e. a host synchronisation) -- or, with ``device_flags``, as a device tensor the caller reads when it
+        suits it (e.g. after it has enqueued the kernels that consume the adjacency)."""
         c = _as(centroids, np.float64, torch.float64)
         so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
         B = len(so) - 1
         total = int(((so[1:] - so[:-1]).astype(np.int64) ** 2).sum())
         out = self._empty((total,), torch.uint8)
-        flags = np.zeros(max(B, 1), np.uint8)
+        flags = self._empty((max(B, 1),), torch.uint8) if device_flags else np.zeros(max(B, 1), np.uint8)
         self._stream()
         self._check(self.lib.segvlad_adjacency_flagged(self._h, _ptr(c), _ptr(so), B, int(order), _ptr(out), _ptr(flags)),
                     "adjacency_flagged")

@@ -63,6 +63,7 @@ class SegVLADPipeline:
         adj: precomputed concatenated adjacency (uint8) or None to derive it (order>0) from the masks.
         Returns [S_tot, P] (PCA'd, row-normalised when l2norm) or [S_tot, K*D]."""
         eng = self.eng
+        lazy = None   # (device flags, centroids) of a device adjacency whose per-image flags have not been looked at yet
         if self.order and adj is None:
             bits, cent = eng.incidence_centroids(masks, self.H, self.W, self.patch)   # one pass over the mask bytes
             if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)
@@ -70,14 +71,11 @@ class SegVLADPipeline:
             else:                     # device kernel: no host round trip (check_empty: one flag byte per image comes back)
                 try:
                     if self.check_empty and hasattr(eng, "adjacency_flagged"):
-                        adj, flags = eng.adjacency_flagged(cent, seg_offsets, self.order)
-                        if (flags & 1).any():
-                            raise ValueError(f"{int((flags & 1).sum())} image(s) with an empty mask: centroid undefined")
-                        bad = np.nonzero(flags & 2)[0]
-                        if len(bad):
-                            # non-generic centroid configurations (duplicate / co-circular centroids: the triangulation is
-                            # Qhull's tie-breaking): the reference's own Qhull path for exactly these images
-                            adj = self._patch_with_qhull(adj, cent, np.asarray(seg_offsets), bad)
+                        # The flags are READ after the kernels that consume the adjacency have been enqueued (below): reading
+                        # them here is a host synchronisation in the middle of the describe stage, with an idle device behind
+                        # it.  A flagged image (rare) is patched afterwards and the batch described again.
+                        adj, flags_dev = eng.adjacency_flagged(cent, seg_offsets, self.order, device_flags=True)
+                        lazy = (flags_dev, cent)
                     else:
                         adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
                 except SegVLADError as e:
@@ -92,6 +90,21 @@ class SegVLADPipeline:
             bits = eng.incidence(masks, self.H, self.W, self.patch)
             if not self.order:
                 adj = None
+        out = self._describe_with(tokens, bits, seg_offsets, adj, l2norm)
+        if lazy is not None:
+            flags = lazy[0].cpu().numpy()
+            if (flags & 1).any():
+                raise ValueError(f"{int((flags & 1).sum())} image(s) with an empty mask: centroid undefined")
+            bad = np.nonzero(flags & 2)[0]
+            if len(bad):
+                # non-generic centroid configurations (duplicate / co-circular centroids: the triangulation is Qhull's
+                # tie-breaking): the reference's own Qhull path for exactly these images, then the batch once more
+                adj = self._patch_with_qhull(adj, lazy[1], np.asarray(seg_offsets), bad)
+                out = self._describe_with(tokens, bits, seg_offsets, adj, l2norm)
+        return out
+
+    def _describe_with(self, tokens, bits, seg_offsets, adj, l2norm):
+        eng = self.eng
         if self.use_pca and self.fuse_pca:   # aggregation feeds the projection GEMM directly (segvlad_images_pca)
             return eng.seg_vlad_pca(tokens, bits, seg_offsets, adj, l2norm=l2norm)["out"]
         desc = eng.seg_vlad(tokens, bits, seg_offsets, adj)["out"]
