@@ -127,7 +127,7 @@ struct SvOptions {
   int f16_cfg = -1;       // kNN fp16 filter tile configuration (-1 = chosen from the shape)
   int f16_gm = -1;        // tile-block height of the XCD-aware order (-1 = by the number of query tiles, 0 = plain tm-fastest order)
   int f16_walk = -1;      // tile walk of the persistent fp16 filter: bit 0 = an XCD keeps its block of query tiles while it steps
-                          // through the database blocks, bit 1 = odd steps run their k-tiles backwards (-1 = default, see
+                          // through the database blocks, bit 1 = odd steps run their k-tiles backwards (-1 = default = 3, see
                           // launch_f16_filter); never changes a result
   int f16_mf = -1;        // MFMA shape of the persistent biased fp16 filter: 0 = 32 x 32 x 16, otherwise 16 x 16 x 32 (needs f16_epi != 0)
   int f16_deep_cfg = -1;  // deep rows (blocked accumulation): -1 / 4 = 8 waves of 64 x 64 on 256 x 128 tiles, 16 x 16 x 32 MFMA, plain loop;

@@ -553,12 +553,25 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const int xcd = blockIdx.x & 7, within = sq & 31;
     const int gn = 32 / gm, sm_cnt = (tiles_m + gm - 1) / gm;
     if (walk & 1) {
-      const int sn_cnt = (tiles_n + gn - 1) / gn, nbx = (sn_cnt + 7) >> 3;
-      const int s_ = sq >> 5, qb = s_ / nbx;
-      int j = s_ - qb * nbx;
-      if (qb & 1) j = nbx - 1 - j;
+      // sn_cnt database blocks = 8 nbf + rem: every XCD sweeps nbf of them per query block; the sm_cnt x rem left-over
+      // (query block, database block) pairs are dealt round-robin to the XCDs at the end of the sequence (all of a query
+      // block's left-overs on XCD 0 would lengthen that XCD's sequence by sm_cnt steps: +0.7 % on the bench shape)
+      const int sn_cnt = (tiles_n + gn - 1) / gn, nbf = sn_cnt >> 3, rem = sn_cnt - 8 * nbf;
+      const int s_ = sq >> 5;
+      int qb, nb;
+      if (s_ < sm_cnt * nbf) {
+        qb = s_ / nbf;
+        int j = s_ - qb * nbf;
+        if (qb & 1) j = nbf - 1 - j;
+        nb = j * 8 + xcd;
+      } else {
+        const int idx = (s_ - sm_cnt * nbf) * 8 + xcd;
+        if (rem == 0 || idx >= sm_cnt * rem) return false;
+        qb = idx / rem;
+        nb = 8 * nbf + (idx - qb * rem);
+      }
       tm_ = qb * gm + within % gm;
-      tn_ = (j * 8 + xcd) * gn + within / gm;
+      tn_ = nb * gn + within / gm;
     } else {
       const int st = (sq >> 5) * 8 + xcd;
       tm_ = (st % sm_cnt) * gm + within % gm;
@@ -1487,13 +1500,19 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   if (PERSIST && gm <= 0) gm = 4;
   int seq_total = 0;
   // tile walk of the persistent kernel (see the kernel): bit 0 = query-block-resident order, bit 1 = serpentine k
-  const int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 3) : 0) : 0;
+  // default 3: measured on 10 000 x 1 M x 1024 (rocprofv3 FETCH_SIZE, calibrated; tools/pmc_walk.sh): L2 fills of the full-level
+  // launch 42.7 GB (walk 0) / 45.1 GB (2: serpentine alone) / 26.3 GB (3), at the same speed (18.39 / 18.34 ms per search's filter
+  // launches, interleaved A/B)
+  const int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 3) : 3) : 0;
   if (gm > 0) {
     gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
     while (gm > 1 && gm / 2 >= tiles_m) gm >>= 1;
     const int gn = 32 / gm;
     int64_t st = (int64_t)((tiles_m + gm - 1) / gm) * ((tiles_n + gn - 1) / gn);
-    if (walk & 1) st = (int64_t)((tiles_m + gm - 1) / gm) * (((tiles_n + gn - 1) / gn + 7) / 8) * 8;   // per XCD: query blocks x its database blocks
+    if (walk & 1) {   // per XCD: query blocks x its share of the database blocks, + its share of the left-over pairs (see the kernel)
+      const int64_t smc = (tiles_m + gm - 1) / gm, snc = (tiles_n + gn - 1) / gn, nbf = snc / 8, rem = snc - 8 * nbf;
+      st = (smc * nbf + (smc * rem + 7) / 8) * 8;
+    }
     tiles = (st + 7) / 8 * 8 * 32;
     if (tiles / 8 > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
     seq_total = (int)(tiles / 8);
