@@ -1087,7 +1087,19 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       }
     }
     if (t == 12345.678f) cand_cnt[0] = 1;
-    return;
+    if (!PERSIST) return;
+    // persistent ablations: on to the workgroup's next tile (its head requested here, waited for at once)
+    int tm_n = 0, tn_n = 0, sq_n = seq + 32;
+    while (sq_n < seq_total && !tile_of(sq_n, tm_n, tn_n)) sq_n += 32;
+    if (sq_n >= seq_total) return;
+    if (BIAS) load_cn(tn_n);
+    if (ABL != 3) issue_head(tm_n, tn_n, rev_of(sq_n));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    seq = sq_n;
+    tm = tm_n;
+    tn = tn_n;
+    rev = rev_of(seq);
+    continue;
   }
   // The epilogue's row record {||q||^2, exact limit, screening bound} of this thread's row, in registers and BEFORE the next
   // tile's head is requested: the compiler waits for the two global loads behind it (issued before the main loop, long
@@ -1583,6 +1595,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 140: return launch_f16_filter<256, 256, 4, 2, 64, 3, 14>(SV_F16_ARGS);   // DMA only, A pieces only
     case 121: return launch_f16_filter<256, 256, 4, 2, 64, 3, 15>(SV_F16_ARGS);   // DMA only (no phase timing)
     case 160: return launch_f16_filter<256, 256, 4, 2, 64, 3, 16>(SV_F16_ARGS);   // DMA only, no epilogue
+    case 94: ctx->f16_bias_ok = true; return launch_f16_filter<256, 256, 4, 2, 64, 3, 1, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);   // default kernel, no epilogue
+    case 95: ctx->f16_bias_ok = true; return launch_f16_filter<256, 256, 4, 2, 64, 3, 3, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);   // + no DMA in the loop
     case 91:
     case 92:
     case 93: {  // phase timing of the default batch kernel (persistent + ping-pong + bias), epilogue 0 / 1 / 1 + 16x16x32 MFMA

@@ -55,7 +55,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   # same command under the kernel trace (the CPU-baseline leg launches no kernels)
   # (--no-ubench: the micro-benchmark is a child process, rocprofv3 would trace it into a second set of files)
   rm -rf /tmp/prof_kt
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python $REPO/bench.py --no-cpu-baseline --no-ubench \
+  timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python $REPO/bench.py --no-cpu-baseline --no-ubench --shard-sim 0 \
      > $OUT/${TAG}_bench_n1_under_rocprof.json 2> /tmp/prof_kt.err
   f=$(ls -S $(find /tmp/prof_kt -name '*kernel_stats.csv') 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_n1_kernel_stats.csv
   # the single-image streaming pass (roofline_knn_stream): per-kernel durations of 50 passes
@@ -66,4 +66,6 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   cd $REPO
   # micro-benchmarks behind the ceilings quoted in DESIGN.md (MFMA rate under the power cap; gather bandwidth vs bytes in flight)
   { timeout 120 ./tools/ubench/mfma_peak 20000; timeout 120 ./tools/ubench/gather_bw; } > $OUT/${TAG}_ubench.txt 2>&1
+  # the plain same-shape GEMM yardstick (torch.matmul fp16, result written) on its own
+  timeout 120 python tools/yardstick_gemm.py > $OUT/${TAG}_yardstick_gemm.json 2>/dev/null
 fi
