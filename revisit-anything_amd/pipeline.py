@@ -55,6 +55,7 @@ class SegVLADPipeline:
         # check_empty the device adjacency reports it (one 4-byte read-back per batch) and describe() raises ValueError
         self.check_empty = check_empty
         self.N = (H // patch) * (W // patch)
+        self._eager_flags = 0   # > 0: read the adjacency flags BEFORE describing (set after a batch that needed a Qhull patch)
 
     # ---- a2..a9: images -> (normalised) segment descriptors ------------------------------------------
     def describe(self, tokens: torch.Tensor, masks: torch.Tensor, seg_offsets: np.ndarray, adj=None,
@@ -73,9 +74,15 @@ class SegVLADPipeline:
                     if self.check_empty and hasattr(eng, "adjacency_flagged"):
                         # The flags are READ after the kernels that consume the adjacency have been enqueued (below): reading
                         # them here is a host synchronisation in the middle of the describe stage, with an idle device behind
-                        # it.  A flagged image (rare) is patched afterwards and the batch described again.
+                        # it.  A flagged image is patched afterwards and the batch described AGAIN -- twice the work, so a
+                        # batch that needed it switches the next 16 batches back to reading the flags first (data whose
+                        # centroids are non-generic again and again: axis-aligned synthetic masks; real SAM masks are not).
                         adj, flags_dev = eng.adjacency_flagged(cent, seg_offsets, self.order, device_flags=True)
-                        lazy = (flags_dev, cent)
+                        if self._eager_flags > 0:
+                            self._eager_flags -= 1
+                            adj = self._check_flags(flags_dev, adj, cent, seg_offsets)
+                        else:
+                            lazy = (flags_dev, cent)
                     else:
                         adj = eng.adjacency(cent, seg_offsets, self.order, check_empty=self.check_empty)
                 except SegVLADError as e:
@@ -92,16 +99,23 @@ class SegVLADPipeline:
                 adj = None
         out = self._describe_with(tokens, bits, seg_offsets, adj, l2norm)
         if lazy is not None:
-            flags = lazy[0].cpu().numpy()
-            if (flags & 1).any():
-                raise ValueError(f"{int((flags & 1).sum())} image(s) with an empty mask: centroid undefined")
-            bad = np.nonzero(flags & 2)[0]
-            if len(bad):
-                # non-generic centroid configurations (duplicate / co-circular centroids: the triangulation is Qhull's
-                # tie-breaking): the reference's own Qhull path for exactly these images, then the batch once more
-                adj = self._patch_with_qhull(adj, lazy[1], np.asarray(seg_offsets), bad)
-                out = self._describe_with(tokens, bits, seg_offsets, adj, l2norm)
+            patched = self._check_flags(lazy[0], adj, lazy[1], seg_offsets)
+            if patched is not adj:
+                self._eager_flags = 16
+                out = self._describe_with(tokens, bits, seg_offsets, patched, l2norm)
         return out
+
+    def _check_flags(self, flags_dev, adj, cent, seg_offsets):
+        """Reads the per-image flags of a device adjacency (a host synchronisation): raises on an empty mask; images with a
+        non-generic centroid configuration (duplicate / co-circular centroids: the triangulation is Qhull's tie-breaking) get
+        the reference's own Qhull path.  Returns ``adj`` itself when nothing was flagged, else the patched adjacency."""
+        flags = flags_dev.cpu().numpy()
+        if (flags & 1).any():
+            raise ValueError(f"{int((flags & 1).sum())} image(s) with an empty mask: centroid undefined")
+        bad = np.nonzero(flags & 2)[0]
+        if len(bad):
+            return self._patch_with_qhull(adj.clone(), cent, np.asarray(seg_offsets), bad)
+        return adj
 
     def _describe_with(self, tokens, bits, seg_offsets, adj, l2norm):
         eng = self.eng
