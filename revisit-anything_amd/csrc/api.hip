@@ -1020,14 +1020,31 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   }
   const uint32_t* poison_dev = nullptr;   // see sv_launch_refine_exact
   const int r0 = rank[0];
+  bool l0_fused = false;
   {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
       StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
-      SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
-      sc.count();
+      if (m <= 128 && n0 <= 4096 && pl.kind != 3) {
+        // one query image per pass: the K split's reduction and the rank select in ONE launch (l0_reduce_rank_kernel)
+        const float* parts = nullptr;
+        int splits = 1;
+        SV_TRY(sv_launch_l2_strided_parts(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, &parts, &splits));
+        sc.count();
+        if (splits > 1) {
+          SV_TRY(sv_launch_l0_reduce_rank(ctx, parts, splits, m, (int)n0, ld0, qn, rn, (int)pl.stride0, r0, thr,
+                                          ctx->s_cand_cnt.as<uint32_t>(), fail_rows));
+          sc.count();
+          l0_fused = true;
+        }
+      } else {
+        SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
+        sc.count();
+      }
     }
     StageScope sc(ctx, "knn_select");
-    if (n0 <= 4096 && pl.kind != 3) {
+    if (l0_fused) {
+      // (thr[q] is in place)
+    } else if (n0 <= 4096 && pl.kind != 3) {
       // a short sample row: only its r0-th smallest distance is needed -- the wave-per-query register select of the
       // candidate lists (mode 0: thr[q] = rank-th smallest), the distance block standing in for a list of n0 entries
       SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_dist.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
@@ -1036,7 +1053,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     } else {
       SV_TRY(sv_launch_select_topk(ctx, ctx->s_dist.as<float>(), ld0, m, n0, r0, thr, ctx->s_thr_idx.as<int64_t>(), r0, 0));
     }
-    sc.count();
+    if (!l0_fused) sc.count();
   }
   const bool l0_small = n0 <= 4096 && pl.kind != 3;
   const float* thr_ptr = l0_small ? thr : thr + (r0 - 1);

@@ -331,6 +331,16 @@ int sv_launch_gemm_nt(segvlad_ctx* ctx, int mode, const float* A, const float* B
 // `dist` is sample j
 int sv_launch_l2_strided(segvlad_ctx* ctx, const float* Q, const float* R, float* dist, int M, int n_sample, int Kd,
                          int64_t ldc, const float* qn, const float* rn, int b_stride, bool split_ok = false);
+// the same launch with the K split's reduction left to the caller: *splits > 1 -> *parts = the partial dot products
+// [*splits][M][ldc] (slices to be added in index order, then sv_d2 with the norms); *splits == 1 -> `dist` is finished
+int sv_launch_l2_strided_parts(segvlad_ctx* ctx, const float* Q, const float* R, float* dist, int M, int n_sample, int Kd,
+                               int64_t ldc, const float* qn, const float* rn, int b_stride, const float** parts, int* splits);
+// the reduction of such a block fused with the rank select of every row (<= 4096 columns, <= 128 rows): thr_out[row] = the
+// rank-th smallest distance of the row -- what splitk_reduce_d2_kernel + sv_launch_select_approx(mode 0, fixed_cnt) compute,
+// value for value, in one launch instead of two (the single-image pass is a chain of dependent launches); also zeroes
+// cand_cnt[row]; a row already flagged in fail_rows gets -inf
+int sv_launch_l0_reduce_rank(segvlad_ctx* ctx, const float* parts, int splits, int M, int n_sample, int64_t ldc, const float* qn,
+                             const float* rn, int b_stride, int rank, float* thr_out, uint32_t* cand_cnt, const uint32_t* fail_rows);
 // same distances, but entries <= thr[m*thr_ld] are appended to (cand_d2, cand_id)[m][0..cap) via cand_cnt[m]
 int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M, int n_sample, int Kd, const float* qn,
                         const float* rn, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,

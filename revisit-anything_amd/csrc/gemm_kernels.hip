@@ -264,10 +264,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_d2_kernel(const float* __re
   out[j] = sv_d2(row_add[row], col_add[col * b_stride], s);
 }
 
+// parts_out != null (mode 1 with a K split only): the reduction of the partial sums is left to the caller, who gets the
+// partial-sum block [splits][M][ldc] and the split count (sv_launch_l2_strided_parts: the single-image pass reduces and
+// ranks in one kernel); *splits_out = 1 means nothing was split and C holds the finished distances.
 static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* Bm, float* C, int M, int N, int Kd,
                        int64_t ldc, const float* a_sub, const float* col_scale, const float* row_add,
                        const float* col_add, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
-                       float* cand_d2, uint32_t* cand_id, int cap, bool split_d2 = false) {
+                       float* cand_d2, uint32_t* cand_id, int cap, bool split_d2 = false, const float** parts_out = nullptr,
+                       int* splits_out = nullptr) {
   if (M <= 0 || N <= 0) return SEGVLAD_OK;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
@@ -310,6 +314,11 @@ static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* 
     hipLaunchKernelGGL(gemm_nt_kernel<2>, SV_GEMM_ARGS);
 #undef SV_GEMM_ARGS
   SV_HIP(hipGetLastError());
+  if (splits_out) *splits_out = (splits > 1 && d2_split) ? splits : 1;
+  if (parts_out && splits > 1 && d2_split) {
+    *parts_out = C;
+    return SEGVLAD_OK;
+  }
   if (splits > 1 && d2_split) {
     const int64_t mn = (int64_t)M * ldc;
     hipLaunchKernelGGL(splitk_reduce_d2_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, ctx->stream, C, splits, M, N, ldc,
@@ -335,6 +344,12 @@ int sv_launch_l2_strided(segvlad_ctx* ctx, const float* Q, const float* R, float
                          int64_t ldc, const float* qn, const float* rn, int b_stride, bool split_ok) {
   return gemm_launch(ctx, 1, Q, R, dist, M, n_sample, Kd, ldc, nullptr, nullptr, qn, rn, b_stride, nullptr, 0, nullptr, nullptr,
                      nullptr, 0, split_ok);
+}
+
+int sv_launch_l2_strided_parts(segvlad_ctx* ctx, const float* Q, const float* R, float* dist, int M, int n_sample, int Kd,
+                               int64_t ldc, const float* qn, const float* rn, int b_stride, const float** parts, int* splits) {
+  return gemm_launch(ctx, 1, Q, R, dist, M, n_sample, Kd, ldc, nullptr, nullptr, qn, rn, b_stride, nullptr, 0, nullptr, nullptr,
+                     nullptr, 0, true, parts, splits);
 }
 
 int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M, int n_sample, int Kd, const float* qn,

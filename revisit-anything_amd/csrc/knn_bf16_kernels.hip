@@ -2060,21 +2060,25 @@ __device__ __forceinline__ float wg_kth_smallest_(const uint32_t (&key)[PER], ui
 // left; the per-bit count is a DPP wave sum + a four-entry LDS exchange (one barrier per bit: the exchange slots alternate).
 // The wave kernel's 64-keys-per-lane instantiation is ~8000 straight-line instructions that a pass runs through ONCE --
 // instruction fetch, not arithmetic: 29 us for a 3906-entry sample row; this kernel takes ~10.
-__global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+// PERK: keys per thread.  32 covers the candidate lists' capacity (8192); 16 (lists of <= 4096 entries -- every list the
+// single-image plan produces in practice) halves the slot loops of the load and of every radix step: the kernel picks the
+// body by the list's length (workgroup-uniform).
+template <int PERK>
+__device__ __forceinline__ void select_wg_body(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
                                                         const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
                                                         const float* __restrict__ thr_in, int64_t thr_in_ld,
                                                         const float* __restrict__ qn, float c_eps, float rn_max,
                                                         float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
                                                         uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
                                                         uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
-                                                        uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt) {
+                                                        uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt,
+                                                        const uint32_t c) {
   constexpr uint32_t PAD = 0xffffffffu;
-  constexpr int PER = 32;   // 8192 keys: the candidate lists' capacity (SV_CAP)
+  constexpr int PER = PERK;   // 32: 8192 keys, the candidate lists' capacity (SV_CAP)
   __shared__ uint32_t xs[2][4];
   __shared__ uint32_t s_n;
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
-  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];
   const uint32_t flagged = ovf_rows[row];
   const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
   uint32_t key[PER], cidv[PER];
@@ -2135,6 +2139,86 @@ __global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ c
       ref_cnt[row] = total;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
+                                                        const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
+                                                        const float* __restrict__ thr_in, int64_t thr_in_ld,
+                                                        const float* __restrict__ qn, float c_eps, float rn_max,
+                                                        float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
+                                                        uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
+                                                        uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
+                                                        uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt) {
+  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[blockIdx.x];
+  if (c <= 4096u)
+    select_wg_body<16>(cnt, cd2, cid, cap, k, mode, check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+                       ovf_count, rovf_rows, rovf_count, ref_lim, fixed_cnt, c);
+  else
+    select_wg_body<32>(cnt, cd2, cid, cap, k, mode, check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+                       ovf_count, rovf_rows, rovf_count, ref_lim, fixed_cnt, c);
+}
+
+// The sampled exact level of a single-image pass: the K-split partial dot products of <= 128 query rows against <= 4096
+// sample rows are reduced (slices added in index order, sv_d2 with the norms: splitk_reduce_d2_kernel's arithmetic, value for
+// value) and the row's rank-th smallest distance is selected in the same workgroup -- one launch instead of two in a pass
+// that is a chain of dependent launches.
+__global__ __launch_bounds__(256) void l0_reduce_rank_kernel(const float* __restrict__ part, int splits, int M, int N, int64_t ldc,
+                                                             const float* __restrict__ row_add, const float* __restrict__ col_add,
+                                                             int b_stride, int rank, float* __restrict__ thr_out,
+                                                             uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ovf_rows) {
+  constexpr uint32_t PAD = 0xffffffffu;
+  constexpr int PER = 16;
+  __shared__ uint32_t xs[2][4];
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const int64_t mn = (int64_t)M * ldc;
+  const float q2 = row_add[row];
+  // slice-major: the 16 loads of a slice are in flight together, two slices per round trip (one load after the other down a
+  // column is 8 dependent round trips per key: 35 us for this kernel)
+  float sum[PER], rn[PER];
+  const float* p0 = part + row * ldc + tid;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const bool in = tid + 256 * i < N;
+    sum[i] = in ? p0[256 * i] : 0.f;
+    rn[i] = in ? col_add[(int64_t)(tid + 256 * i) * b_stride] : 0.f;
+  }
+  int t = 1;
+  for (; t + 1 < splits; t += 2) {
+    float a[PER], b[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const bool in = tid + 256 * i < N;
+      a[i] = in ? p0[(int64_t)t * mn + 256 * i] : 0.f;
+      b[i] = in ? p0[(int64_t)(t + 1) * mn + 256 * i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) sum[i] = (sum[i] + a[i]) + b[i];   // (index order, as splitk_reduce_d2_kernel adds them)
+  }
+  if (t < splits) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) sum[i] += (tid + 256 * i < N) ? p0[(int64_t)t * mn + 256 * i] : 0.f;
+  }
+  uint32_t key[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) key[i] = (tid + 256 * i < N) ? f2key_(sv_d2(q2, rn[i], sum[i])) : PAD;
+  if (tid == 0) cnt[row] = 0u;   // the next level's filter appends from zero
+  if (ovf_rows[row] || N < rank) {   // (workgroup-uniform)
+    if (tid == 0) thr_out[row] = -INFINITY;
+    return;
+  }
+  const float ak = wg_kth_smallest_<PER>(key, (uint32_t)N, rank, xs, tid);
+  if (tid == 0) thr_out[row] = ak;
+}
+
+int sv_launch_l0_reduce_rank(segvlad_ctx* ctx, const float* parts, int splits, int M, int n_sample, int64_t ldc, const float* qn,
+                             const float* rn, int b_stride, int rank, float* thr_out, uint32_t* cand_cnt, const uint32_t* fail_rows) {
+  if (M <= 0) return SEGVLAD_OK;
+  if (n_sample > 4096) return ctx->fail(SEGVLAD_ERR_LIMIT, "l0_reduce_rank: rows of at most 4096 columns");
+  hipLaunchKernelGGL(l0_reduce_rank_kernel, dim3(M), dim3(256), 0, ctx->stream, parts, splits, M, n_sample, ldc, qn, rn, b_stride, rank,
+                     thr_out, cand_cnt, fail_rows);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
 }
 
 __global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
