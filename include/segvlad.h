@@ -213,7 +213,18 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *                                                      level behind an exact sample of 2048..4096 rows, a workgroup per
  *                                                      list in the selects, refinement lists shared by workgroups, the
  *                                                      query scale left on the device | the plan of the batches
- *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning   */
+ *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning
+ *        "f16_mf", "f16_epi", "f16_walk", "f16_pp", "f16_deep_cfg"   integers, A/B switches of the fp16 filter kernels
+ *                                                      (MFMA shape, epilogue, tile walk, loop form, deep-row geometry:
+ *                                                      csrc/ctx.h SvOptions); never change a result
+ *        "guard_undersize" "<buffer>:<bytes>"          tests of the guard mode only (see below)
+ *
+ *      Environment, read ONCE by segvlad_create: SEGVLAD_GUARD=1 creates a GUARDED context (development / test runs):
+ *      every device buffer of the context is allocated at its exact size between two fences of poison words, the back
+ *      fence of a per-call scratch buffer right behind the bytes of the CURRENT request, and every call -- and
+ *      segvlad_synchronize -- ends with a check of all fences: an out-of-bounds write fails the call with
+ *      SEGVLAD_ERR_STATE and names the buffer.  (The library's scratch only ever grows; without the guard a request that
+ *      an earlier, larger one already covers cannot fail.)  Results are unchanged; calls synchronise the device. */
 int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
 
 /* ---- statistics of the last segvlad_search on this context (HOST array, up to 10 values):
@@ -247,7 +258,13 @@ int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n);
  *      segvlad_allgather_rows   [n_local][d] fp32 of every rank -> [world * n_local][d], rank order (equal slices): the
  *                               query descriptors when every rank describes a slice of the query images
  *      segvlad_search_sharded   global exact top-k (ascending (d2, id); (inf, -1) beyond the total row count), identical
- *                               on every rank.  id_base = global index of this shard's first row.  Collective. */
+ *                               on every rank.  id_base = global index of this shard's first row.  Collective: every
+ *                               rank enters the all-gather or none does -- a rank whose LOCAL search fails still
+ *                               contributes ((inf, -1) records and its status in a trailer record), and then EVERY rank
+ *                               returns an error (the failing rank its own, the others SEGVLAD_ERR_COMM naming it); a
+ *                               rank that cannot join any more (no memory for the exchange buffers) aborts the
+ *                               communicator (ncclCommAbort) instead of leaving its peers waiting.
+ *      segvlad_allgather_rows   n_local must be the same on every rank. */
 #define SEGVLAD_COMM_ID_BYTES 128
 int segvlad_comm_unique_id(void* id_out);
 int segvlad_comm_init(segvlad_ctx* ctx, const void* id, int rank, int world);
