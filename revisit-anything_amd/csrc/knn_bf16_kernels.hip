@@ -1532,7 +1532,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   }
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
   size_t lds = 2 * (size_t)BM * HBK * 2 + (size_t)NB * BN * HBK * 2;  // two A stages + NB B stages
-  if (!PERSIST) {  // epilogue: row records + per-row counters + one survivor list per wave
+  if (!PERSIST && EPI == 0) {  // epilogue: row records + per-row counters + one survivor list per wave
     constexpr int TMl = BM / (32 * WM), TNl = BN / (32 * WN);
     constexpr int LCAPl = (TMl * TNl * 256 < 2048) ? TMl * TNl * 256 : 2048;
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
@@ -1647,6 +1647,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 0, 0, true, 1, 1>(SV_F16_ARGS);   // plain loop (A/B)
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);  // + 16 x 16 x 32 MFMA
       }
+      if (ctx->opt.f16_small_mf == 1)   // (A/B: the small levels on the new shape + wave-private epilogue, non-persistent)
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);
       return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true>(SV_F16_ARGS);
     case 251:   // 250 without the bias (A/B; norms too unbalanced for the biased margin)
     unbiased_250:

@@ -1,0 +1,74 @@
+"""Every selectable variant of the fp16 candidate filter returns the SAME bits (round 4: MFMA shape, epilogue, tile walk, loop
+form, deep-row geometry are options of the context -- `csrc/ctx.h: SvOptions` -- and only ever change the schedule): the
+result of each is compared with the all-fp32 filter's, bit for bit, on shapes that reach the persistent batch kernel (>= 1024
+tiles), its serpentine walk with a short k-loop, coherent databases that overflow a wave's hit list (the in-place flush), and
+the deep-row (blocked accumulation) kernels."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    return SegVLADEngine(0)
+
+
+def _unit(x):
+    return torch.nn.functional.normalize(x, dim=1)
+
+
+def _check_variants(R, Q, k, variants, defaults):
+    eng = _engine()
+    eng.db_add(R)
+    eng.set_option("knn_filter", "fp32")
+    ref = eng.search(Q, k)
+    assert eng.search_stats()["filter"] == "fp32"
+    eng.set_option("knn_filter", "auto")
+    for v in variants:
+        for key, val in {**defaults, **v}.items():
+            eng.set_option(key, val)
+        d2, idx = eng.search(Q, k)
+        st = eng.search_stats()
+        assert st["filter"] == "f16" and st["levels"] >= 1, (v, st)
+        assert torch.equal(idx, ref[1]) and torch.equal(d2, ref[0]), f"variant {v} differs from the fp32 filter"
+    eng.close()
+
+
+BATCH_DEFAULTS = {"f16_epi": -1, "f16_mf": -1, "f16_walk": -1, "f16_pp": -1, "f16_small_mf": 0, "f16_gm": -1}
+BATCH_VARIANTS = [{}, {"f16_epi": 0}, {"f16_mf": 0}, {"f16_walk": 0}, {"f16_walk": 1}, {"f16_walk": 2}, {"f16_walk": 3, "f16_gm": 4},
+                  {"f16_pp": 0}, {"f16_small_mf": 1}, {"f16_mf": 0, "f16_walk": 3}]
+
+
+def test_batch_filter_variants_are_bit_identical_to_the_fp32_filter():
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(11)
+    n, d, nq = 300_000, 256, 3000          # 12 x 1172 tiles of 256 x 256: the persistent kernel; 4 k-tiles: a short serpentine
+    R = _unit(torch.randn(n, d, device="cuda:0", generator=g))
+    Q = _unit(R[(torch.arange(nq, device="cuda:0") * 97) % n] + 0.05 * torch.randn(nq, d, device="cuda:0", generator=g))
+    _check_variants(R, Q, 100, BATCH_VARIANTS, BATCH_DEFAULTS)
+
+
+def test_batch_filter_variants_on_a_coherent_database():
+    """Every query's neighbourhood sits in ONE 256-row tile (300 near-copies of each of 40 anchors, contiguous): thousands of
+    hits in single 64 x 128 wave blocks -- the wave-private epilogue flushes its list in place, the older one walks its
+    accumulators -- and refine bands beyond the first-tier list."""
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(12)
+    d, anchors, copies = 128, 40, 300
+    A = _unit(torch.randn(anchors, d, device="cuda:0", generator=g))
+    clump = _unit(A.repeat_interleave(copies, dim=0) + 0.02 * torch.randn(anchors * copies, d, device="cuda:0", generator=g))
+    fill = _unit(torch.randn(290_000, d, device="cuda:0", generator=g))
+    R = torch.cat([fill[:100_000], clump, fill[100_000:]])
+    Q = _unit(A.repeat_interleave(50, dim=0) + 0.02 * torch.randn(anchors * 50, d, device="cuda:0", generator=g))   # 2000 queries
+    _check_variants(R, Q, 200, [{}, {"f16_epi": 0}, {"f16_mf": 0}, {"f16_walk": 0}], BATCH_DEFAULTS)
+
+
+def test_deep_row_filter_variants_are_bit_identical_to_the_fp32_filter():
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(13)
+    n, d, nq = 40_000, 4096, 1500           # d >= 4096: blocked accumulation (4 k-blocks of 1024)
+    R = _unit(torch.randn(n, d, device="cuda:0", generator=g))
+    Q = _unit(R[(torch.arange(nq, device="cuda:0") * 13) % n] + 0.05 * torch.randn(nq, d, device="cuda:0", generator=g))
+    _check_variants(R, Q, 50, [{"f16_deep_cfg": c} for c in (-1, 0, 1, 2, 3, 4)], {"f16_deep_cfg": -1})

@@ -53,6 +53,13 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, const unsigned c
       __builtin_amdgcn_global_load_lds((gptr_t)(src + off), (lptr_t)(lds + 65536 + w * 2048), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(src + off + 1024), (lptr_t)(lds + 65536 + w * 2048 + 1024), 16, 0, 0);
     }
+    if (MODE == 6) {   // MODE 3's two pieces per step as buffer_load ... lds: SGPR resource + one 32-bit VGPR offset (no 64-bit pointer math)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+      const unsigned off = foot == 0 ? (unsigned)(w * 32768 + (it * 2048) % 32768 + l * 16)
+                                     : (unsigned)((((size_t)blockIdx.x * 8 + w) * 131072 + (size_t)it * 2048 + l * 16) % (src_bytes - 4096));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(lds + 65536 + w * 2048), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(lds + 65536 + w * 2048 + 1024), 16, off, 0, 1024, 0);
+    }
     if (MODE == 4) {   // same bytes through registers: 2 global_load_dwordx4 per step, ds_write_b128 one step later
       const size_t off = foot == 0 ? (size_t)w * 32768 + ((size_t)it * 2048) % 32768 + l * 16   /* 256 KiB shared: L2 hits */
                                    : (((size_t)blockIdx.x * 8 + w) * 131072 + (size_t)it * 2048 + l * 16) % (src_bytes - 4096);
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, const unsigned c
       st1 = *reinterpret_cast<const f32x4*>(src + off + 1024);
     }
     if (MODE >= 2 && (it & 3) == 3) {
-      if (MODE == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (MODE == 3 || MODE == 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
@@ -172,7 +179,7 @@ template <int MODE, int RND>
 void run(const char* name, float* out, int iters, int blocks, const unsigned char* src, size_t src_bytes, int foot = 0) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE, RND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void*>(k16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const size_t ldsb = MODE >= 3 ? 65536 + 16384 : 65536;
+  const size_t ldsb = MODE >= 3 ? 65536 + 16384 : 65536;   // (modes 3, 4, 6: a landing zone for the pieces)
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL((k<MODE, RND>), dim3(blocks), dim3(512), ldsb, 0, out, iters, src, src_bytes, foot);
@@ -201,6 +208,7 @@ int main(int argc, char** argv) {
     run<1, 1>("mfma + 6 ds_read_b128 / 8 mfma (random)", out, iters, blocks, src, src_bytes);
     run<2, 1>("  + s_barrier / 32 mfma", out, iters, blocks, src, src_bytes);
     run<3, 1>("  + 8 DMA pieces / 32 mfma + vmcnt", out, iters, blocks, src, src_bytes);
+    run<6, 1>("  + 8 DMA pieces as buffer_load lds", out, iters, blocks, src, src_bytes);
     run<4, 1>("  + 8 (global_load x4 -> ds_write_b128)", out, iters, blocks, src, src_bytes);
     run<3, 1>("  + 8 DMA pieces, streaming 1 GiB", out, iters, blocks, src, src_bytes, 1);
   }
