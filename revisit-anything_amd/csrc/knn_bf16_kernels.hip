@@ -503,8 +503,26 @@ __device__ __forceinline__ float acc_elem(const f32x16& v, int r) {
 //      registers, but a QUARTER of the accumulator read-modify-write traffic per flop inside the matrix pipe.  The chip is
 //      power-limited on this kernel (tools/ubench/mfma_peak: random operands sustain 1.71-1.76 PF in the 32 x 32 x 16 shape
 //      and 1.92-2.01 PF in the 16 x 16 x 32 shape, MFMA only), so the shape that needs less energy per flop is the faster one.
+// The buffer-resource type and its two builtins exist in the DEVICE pass only; the host pass, which parses the kernel bodies
+// too (and silently drops a kernel's launch stub when its body does not type-check there), sees inert stand-ins.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t sv_rsrc_t;
+#define SV_BUF_RSRC(base) __builtin_amdgcn_make_buffer_rsrc((void*)(base), 0, (int)0xffffffffu, 0x00020000)
+#define SV_BUF_LOAD_LDS(rs, ldsptr, voff, soff, aux) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (ldsptr), 16, (voff), (soff), 0, (aux))
+#else
+typedef int sv_rsrc_t;
+#define SV_BUF_RSRC(base) 0
+#define SV_BUF_LOAD_LDS(rs, ldsptr, voff, soff, aux) ((void)(rs), (void)(ldsptr), (void)(voff), (void)(soff))
+#endif
+
+// BUF : the operand DMA as `buffer_load_dwordx4 ... lds` -- an SGPR resource per operand and tile, ONE never-rewritten 32-bit
+//      VGPR offset per piece, the k-offset in an SGPR -- instead of `global_load_lds_dwordx4` on a 64-bit per-lane pointer that
+//      every piece re-forms in the same VGPR pair (a write-after-read stall behind the previous piece's address read).  Needs
+//      every piece offset of a tile below 4 GiB (the launcher checks).  tools/ubench/mfma_peak: 1317 -> 1345 TF for the loop
+//      of this kernel's byte : flop ratio; the deep-row kernel 126.4 -> 125.2 ms; the ping-pong batch kernel 18.19 -> 18.70 ms
+//      (slower: its default stays global_load_lds).
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total, int walk,
@@ -601,9 +619,39 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   auto b_off = [](int st_) { return PERSIST ? (st_ == 0 ? 4 * PA : (st_ == 1 ? 2 * PA : PA)) : 2 * PA + st_ * PB; };
   const int lrow_p = l / CH, lch = l % CH;
   // head of a tile: A(0), B(0) and (NB == 3) B(1), by global->LDS DMA
+  // BUF: byte offset of this lane's 16 bytes of piece j inside its tile (rows beyond the operand clamp to its last row: they
+  // are never emitted), and the tile's buffer resource
+  auto voff_a = [&](int64_t m0_, int j) -> unsigned {
+    const int row = (w * JA + j) * RP + lrow_p;
+    const int rr = (m0_ + row < M) ? row : (int)((int64_t)M - 1 - m0_);
+    return (unsigned)rr * (unsigned)(d * 2) + 16u * (unsigned)swz(row, lch);
+  };
+  auto voff_b = [&](int64_t n0_, int j) -> unsigned {
+    const int row = (w * JB + j) * RP + lrow_p;
+    const int rr = (n0_ + row < N) ? row : (int)((int64_t)N - 1 - n0_);
+    return (unsigned)rr * (unsigned)(ldb * 2) + 16u * (unsigned)swz(row, lch);
+  };
+  auto rsrc_of = [](const uint16_t* base) -> sv_rsrc_t { return SV_BUF_RSRC(base); };
   auto issue_head = [&](int tm_, int tn_, bool rev_) {
     const int64_t m0_ = (int64_t)tm_ * BM, n0_ = (int64_t)tn_ * BN;
     const int k0_ = kofs(rev_, 0), k1_ = kofs(rev_, 1);
+    if constexpr (BUF) {
+      const sv_rsrc_t ra = rsrc_of(Qh + m0_ * d), rb_ = rsrc_of(Rh + n0_ * ldb);
+#pragma unroll
+      for (int j = 0; j < JA; ++j)
+        SV_BUF_LOAD_LDS(ra, (lptr_t)(lds + a_off(0) + (w * JA + j) * 1024), voff_a(m0_, j), 2 * k0_, AUXA);
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const unsigned vo = voff_b(n0_, j);
+        SV_BUF_LOAD_LDS(rb_, (lptr_t)(lds + b_off(0) + (w * JB + j) * 1024), vo, 2 * k0_, AUXB);
+      }
+      if (NB == 3 && ntiles > 1) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+          SV_BUF_LOAD_LDS(rb_, (lptr_t)(lds + b_off(1) + (w * JB + j) * 1024), voff_b(n0_, j), 2 * k1_, AUXB);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const int row = (w * JA + j) * RP + lrow_p;
@@ -727,19 +775,28 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   }
 
   // per-lane source rows of this wave's DMA pieces (clamped: edge rows are never emitted)
-  const uint16_t* srcA[JA];
-  const uint16_t* srcB[JB];
+  const uint16_t* srcA[BUF ? 1 : JA];
+  const uint16_t* srcB[BUF ? 1 : JB];
+  unsigned voA[BUF ? JA : 1], voB[BUF ? JB : 1];
+  const sv_rsrc_t rsA = rsrc_of(Qh + m0 * d), rsB = rsrc_of(Rh + n0 * ldb);
+  if constexpr (BUF) {
 #pragma unroll
-  for (int j = 0; j < JA; ++j) {
-    const int row = (w * JA + j) * RP + lrow_p;
-    const int64_t qa = (m0 + row < M) ? (m0 + row) : (int64_t)(M - 1);
-    srcA[j] = Qh + qa * d + 8 * swz(row, lch);
-  }
+    for (int j = 0; j < JA; ++j) voA[j] = voff_a(m0, j);
 #pragma unroll
-  for (int j = 0; j < JB; ++j) {
-    const int row = (w * JB + j) * RP + lrow_p;
-    const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
-    srcB[j] = Rh + rb * ldb + 8 * swz(row, lch);
+    for (int j = 0; j < JB; ++j) voB[j] = voff_b(n0, j);
+  } else {
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const int row = (w * JA + j) * RP + lrow_p;
+      const int64_t qa = (m0 + row < M) ? (m0 + row) : (int64_t)(M - 1);
+      srcA[j] = Qh + qa * d + 8 * swz(row, lch);
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int row = (w * JB + j) * RP + lrow_p;
+      const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
+      srcB[j] = Rh + rb * ldb + 8 * swz(row, lch);
+    }
   }
   constexpr int BAHEAD = NB - 1;  // how many k-tiles ahead the B DMA runs (A always runs one ahead)
   // DMA piece p of iteration kt: pieces 0..JA-1 belong to A(kt+1), JA..JA+JB-1 to B(kt+BAHEAD)
@@ -747,7 +804,16 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     if (ABL == 3) return;  // ablation: no DMA in the loop
     if (ABL == 13 && piece < JA) return;    // ablation: B only
     if (ABL == 14 && piece >= JA) return;   // ablation: A only
-    if (piece < JA) {
+    if constexpr (BUF) {
+      if (piece < JA) {
+        if (kt + 1 < ntiles)
+          SV_BUF_LOAD_LDS(rsA, (lptr_t)(lds + a_off(ia_next) + (w * JA + piece) * 1024), voA[piece], 2 * kofs(rev, kt + 1), AUXA);
+      } else {
+        const int j = piece - JA;
+        if (kt + BAHEAD < ntiles)
+          SV_BUF_LOAD_LDS(rsB, (lptr_t)(lds + b_off(ib_next) + (w * JB + j) * 1024), voB[j], 2 * kofs(rev, kt + BAHEAD), AUXB);
+      }
+    } else if (piece < JA) {
       if (kt + 1 < ntiles)
         __builtin_amdgcn_global_load_lds((gptr_t)(srcA[piece] + kofs(rev, kt + 1)),
                                          (lptr_t)(lds + a_off(ia_next) + (w * JA + piece) * 1024), 16, 0, AUXA);
@@ -1497,7 +1563,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 }
 
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1538,7 +1604,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF, BUF>;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -1564,6 +1630,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
   // deep rows (raw K*D descriptors, d >= 4096): blocked accumulation (configuration 300), which is what keeps the
   // filter's error margin -- and with it the refine band -- as tight as at d = 1024 (sv_f16_c_eps)
   const int c = sv_f16_kblock(ctx->opt, d) ? 300 : ctx->opt.f16_cfg >= 0 ? ctx->opt.f16_cfg : (M > 128 ? 250 : M > 64 ? 63 : 62);
+  // BUF kernels: every piece offset of a 256-row tile (row pitch d * b_stride fp16 for the database side) in 32 bits
+  const bool buf_ok = ctx->opt.f16_buf != 0 && (int64_t)256 * d * b_stride * 2 + 4096 < (int64_t)0xffffffffLL;
   switch (c) {
     case 300:   // blocked accumulation (deep rows): two accumulator sets, a k-block of SV_F16_KBLOCK = 16 k-tiles of 64
       static_assert(SV_F16_KBLOCK == 16 * 64, "k-block = KBT x HBK");
@@ -1575,8 +1643,10 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
       // (1: half the MFMAs per phase of the 64 x 128 wave tiles behind the same barriers), 128 x 128 tiles with the 16 x 16 x 32
       // shape 234 ms ping-pong / 198 ms plain (2 / 3: one wave per SIMD)
       if (ctx->f16_bias_ok && ctx->opt.f16_mf != 0 && ctx->opt.f16_epi != 0 && M > 128) {
-        if (ctx->opt.f16_deep_cfg < 0 || ctx->opt.f16_deep_cfg == 4)   // the default: 780 vs 667 TF algorithmic at 10 000 x 50 000 x 98 304
+        if (ctx->opt.f16_deep_cfg < 0 || ctx->opt.f16_deep_cfg == 4) {   // the default: 780 vs 667 TF algorithmic at 10 000 x 50 000 x 98 304
+          if (buf_ok) return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1, true>(SV_F16_ARGS);
           return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1>(SV_F16_ARGS);
+        }
         if (ctx->opt.f16_deep_cfg == 1) return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 2, 16, true, 1, 1>(SV_F16_ARGS);
         if (ctx->opt.f16_deep_cfg == 2) return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 2, 16, true, 1, 1>(SV_F16_ARGS);
         if (ctx->opt.f16_deep_cfg == 3) return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1>(SV_F16_ARGS);   // plain loop
@@ -1645,6 +1715,10 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1>(SV_F16_ARGS);   // + wave-private epilogue
         if (ctx->opt.f16_pp == 0)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 0, 0, true, 1, 1>(SV_F16_ARGS);   // plain loop (A/B)
+        // (buffer_load lds is SLOWER in this kernel -- 18.70 vs 18.19 ms -- although faster in the micro-benchmark's loop and in
+        //  the deep-row kernel, 125.2 vs 126.4 ms: only on request here)
+        if (buf_ok && ctx->opt.f16_buf == 1)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, true>(SV_F16_ARGS);   // + buffer_load lds
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);  // + 16 x 16 x 32 MFMA
       }
       if (ctx->opt.f16_small_mf == 1)   // (A/B: the small levels on the new shape + wave-private epilogue, non-persistent)
