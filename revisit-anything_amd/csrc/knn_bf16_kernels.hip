@@ -446,10 +446,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N_>
 __device__ __forceinline__ void wait_vm_lgkm0() {  // s_waitcnt needs a literal count
-  if (N_ == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  else if (N_ == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-  else if (N_ == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-  else if (N_ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  static_assert(N_ == 0 || N_ == 1 || N_ == 2 || N_ == 3 || N_ == 4 || N_ == 8, "add the literal");
+  if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N_ == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N_ == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N_ == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 }
 
@@ -522,7 +524,7 @@ typedef int sv_rsrc_t;
 //      of this kernel's byte : flop ratio; the deep-row kernel 126.4 -> 125.2 ms; the ping-pong batch kernel 18.19 -> 18.70 ms
 //      (slower: its default stays global_load_lds).
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total, int walk,
@@ -875,14 +877,19 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
             b[0][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
           }
         }
+        // DSPLIT > 0: the last DSPLIT pieces of a phase are issued from its MFMA segment (between the MFMAs) instead of its
+        // load segment -- the load segment (12 fragment reads + the DMA issue) is what the partner's 32 MFMAs have to cover.
+        // The pieces of the LAST phase that move are B(kt+2)'s (pieces >= JA): they are issued behind the k-tile's wait, so
+        // the wait leaves only the JB - DSPLIT of them that are in flight by then (older ones retire first: in order).
+        static_assert(DSPLIT == 0 || (MF == 1 && PPn == 2 && DPP > DSPLIT && JB >= DSPLIT && NB == 3), "split DMA issue: the 16 x 16 x 32 ping-pong loop");
 #pragma unroll
-        for (int pz = 0; pz < DPP; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
+        for (int pz = 0; pz < DPP - DSPLIT; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
         if (ph == PPn - 1) {
           // last load segment of the k-tile: this wave's pieces of A(kt+1) and B(kt+1) have landed (B(kt+2), the
           // youngest JB DMA instructions, may still fly).  The barriers between here and the first read of tile kt+1
           // (one for the leading half, two for the lagging half) make that true for every wave's pieces.
           if (NB == 3 && kt + 2 < ntiles)
-            wait_vm_lgkm0<JB>();
+            wait_vm_lgkm0<JB - DSPLIT>();
           else
             wait_vm_lgkm0<0>();
         } else {
@@ -902,10 +909,18 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
               for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = MFMA_F16(a[k2][mt], b[k2][nt], acc[mt][nt]);
         } else {
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
+          for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < TN16; ++nt)
               acc16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][mt], b[0][nt], acc16[mt][nt], 0, 0, 0);
+            if constexpr (DSPLIT > 0) {   // one moved piece behind each of the first DSPLIT rows of MFMAs
+              if (mt < DSPLIT) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(ph * DPP + (DPP - DSPLIT) + mt, kt, ia ^ 1, ibn);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1563,7 +1578,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 }
 
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1604,7 +1619,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF, BUF>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF, BUF, DSPLIT>;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -1717,6 +1732,10 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 0, 0, true, 1, 1>(SV_F16_ARGS);   // plain loop (A/B)
         // (buffer_load lds is SLOWER in this kernel -- 18.70 vs 18.19 ms -- although faster in the micro-benchmark's loop and in
         //  the deep-row kernel, 125.2 vs 126.4 ms: only on request here)
+        if (ctx->opt.f16_dsplit == 2)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 2>(SV_F16_ARGS);   // split DMA issue (A/B)
+        if (ctx->opt.f16_dsplit == 1)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 1>(SV_F16_ARGS);
         if (buf_ok && ctx->opt.f16_buf == 1)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, true>(SV_F16_ARGS);   // + buffer_load lds
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);  // + 16 x 16 x 32 MFMA
