@@ -600,8 +600,27 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     return tm_ < tiles_m && tn_ < tiles_n;
   };
   // serpentine k: element offset of k-tile x of a step that runs backwards (wave-uniform)
-  auto rev_of = [&](int sq) -> bool { return (walk & 2) && ((sq >> 5) & 1); };
-  auto kofs = [&](bool rev_, int x) -> int { return (rev_ ? ntiles - 1 - x : x) * HBK; };
+  // walk bit 2 ("rotated k start"): workgroup (i_m, i_n) of the XCD's gm x gn block starts its k-loop at k-tile
+  // (i_m ntiles / gm + i_n) mod ntiles and wraps around.  The gm workgroups that share a database tile (and the gn that share a
+  // query tile) otherwise ask for the same k-slice at the same moment: one L2 miss, everybody waiting out its HBM latency;
+  // rotated, a slice is fetched by the first workgroup that reaches it and is an L2 HIT for the others, one to two k-tiles
+  // later.  The k-order of a step: rot, rot + 1, ... (mod ntiles), or -- serpentine, odd steps -- rot - 1, rot - 2, ...: the
+  // reversed step starts on the slice the previous one ended on.  (rev_of packs both: bit 0 = reversed, bits 1.. = rot.)
+  auto rev_of = [&](int sq) -> int {
+    int rot = 0;
+    if (walk & 4) {
+      const int within = sq & 31, im = within % gm, in_ = within / gm;
+      rot = (im * (ntiles >= gm ? ntiles / gm : 1) + in_) % ntiles;
+    }
+    return 2 * rot + (((walk & 2) && ((sq >> 5) & 1)) ? 1 : 0);
+  };
+  auto kofs = [&](int rev_, int x) -> int {
+    const int rot = rev_ >> 1;
+    int i = (rev_ & 1) ? rot - 1 - x : rot + x;
+    if (i < 0) i += ntiles;
+    if (i >= ntiles) i -= ntiles;
+    return i * HBK;
+  };
   int tm, tn;
   int seq = (int)(blockIdx.x >> 3);
   if (PERSIST) {
@@ -634,7 +653,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     return (unsigned)rr * (unsigned)(ldb * 2) + 16u * (unsigned)swz(row, lch);
   };
   auto rsrc_of = [](const uint16_t* base) -> sv_rsrc_t { return SV_BUF_RSRC(base); };
-  auto issue_head = [&](int tm_, int tn_, bool rev_) {
+  auto issue_head = [&](int tm_, int tn_, int rev_) {
     const int64_t m0_ = (int64_t)tm_ * BM, n0_ = (int64_t)tn_ * BN;
     const int k0_ = kofs(rev_, 0), k1_ = kofs(rev_, 1);
     if constexpr (BUF) {
@@ -693,7 +712,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     }
   };
   if (BIAS) load_cn(tn);
-  bool rev = PERSIST ? rev_of(seq) : false;   // (only the persistent walk has steps to alternate)
+  int rev = PERSIST ? rev_of(seq) : 0;   // (only the persistent walk has steps to alternate / rotate)
   issue_head(tm, tn, rev);
   if (NB == 3 && ntiles > 1)
     wait_vm_lgkm0<JB>();
@@ -1596,7 +1615,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   // default 3: measured on 10 000 x 1 M x 1024 (rocprofv3 FETCH_SIZE, calibrated; tools/pmc_walk.sh): L2 fills of the full-level
   // launch 42.7 GB (walk 0) / 45.1 GB (2: serpentine alone) / 26.3 GB (3), at the same speed (18.39 / 18.34 ms per search's filter
   // launches, interleaved A/B)
-  const int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 3) : 3) : 0;
+  const int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 7) : 3) : 0;
   if (gm > 0) {
     gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
     while (gm > 1 && gm / 2 >= tiles_m) gm >>= 1;
