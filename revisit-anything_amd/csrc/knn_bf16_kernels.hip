@@ -856,6 +856,24 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     static_assert(PP == 0 || (KS % PPn == 0 && (JA + JB) % PPn == 0 && PH >= 1), "phase geometry");
     const bool lag = w >= NW / 2;           // wave-uniform (w comes from readfirstlane)
     if (lag) __builtin_amdgcn_s_barrier(); // the second half of the waves runs one barrier (= one segment) behind
+    // DSPLIT < 0 (APF): four of a phase's twelve fragments are read at the END of the previous phase's MFMA segment (16 more
+    // live registers) -- a load segment is then 8 fragment reads + the DMA issue, and the partner's 32 MFMAs have less to
+    // cover.  Phase 1 takes its A fragments that way (same stages as phase 0: landed).  Phase 0 of the NEXT k-tile takes its
+    // first four B fragments: B(kt+1) was requested a whole k-tile earlier, and a vmcnt(JA) added to phase 0's load segment
+    // (behind the issue of A(kt+1)) makes every wave's pieces of it certain one barrier before the earliest such read --
+    // the A stage of the next tile would not do, the lagging half only waits for it one segment after the leading half's
+    // MFMA segment that would read it.
+    constexpr bool APF = DSPLIT < 0;
+    constexpr int DSP = DSPLIT > 0 ? DSPLIT : 0;
+    static_assert(!APF || (MF == 1 && PPn == 2 && TN16 >= 4 && NB == 3), "fragment prefetch: the 16 x 16 x 32 ping-pong loop");
+    f16x8 apf[4];
+    if constexpr (APF) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rb = wn * (16 * TN16) + 16 * t + (l & 15);
+        apf[t] = *reinterpret_cast<const f16x8*>(lds + b_off(ib) + rb * RB + swz(rb, l >> 4) * 16);
+      }
+    }
     for (int kt = 0; kt < ntiles; ++kt) {
       const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
       const unsigned char* SA = lds + a_off(ia);
@@ -888,29 +906,34 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int ra = wm * 64 + 16 * t + (l & 15);
-            a[0][t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
+            if (APF && ph == 1) a[0][t] = apf[t];
+            else a[0][t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, cl) * 16);
           }
 #pragma unroll
           for (int t = 0; t < TN16; ++t) {
             const int rb = wn * (16 * TN16) + 16 * t + (l & 15);
-            b[0][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
+            if (APF && ph == 0 && t < 4) b[0][t] = apf[t];
+            else b[0][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
           }
         }
         // DSPLIT > 0: the last DSPLIT pieces of a phase are issued from its MFMA segment (between the MFMAs) instead of its
         // load segment -- the load segment (12 fragment reads + the DMA issue) is what the partner's 32 MFMAs have to cover.
         // The pieces of the LAST phase that move are B(kt+2)'s (pieces >= JA): they are issued behind the k-tile's wait, so
         // the wait leaves only the JB - DSPLIT of them that are in flight by then (older ones retire first: in order).
-        static_assert(DSPLIT == 0 || (MF == 1 && PPn == 2 && DPP > DSPLIT && JB >= DSPLIT && NB == 3), "split DMA issue: the 16 x 16 x 32 ping-pong loop");
+        static_assert(DSP == 0 || (MF == 1 && PPn == 2 && DPP > DSP && JB >= DSP && NB == 3), "split DMA issue: the 16 x 16 x 32 ping-pong loop");
 #pragma unroll
-        for (int pz = 0; pz < DPP - DSPLIT; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
+        for (int pz = 0; pz < DPP - DSP; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
         if (ph == PPn - 1) {
           // last load segment of the k-tile: this wave's pieces of A(kt+1) and B(kt+1) have landed (B(kt+2), the
           // youngest JB DMA instructions, may still fly).  The barriers between here and the first read of tile kt+1
           // (one for the leading half, two for the lagging half) make that true for every wave's pieces.
           if (NB == 3 && kt + 2 < ntiles)
-            wait_vm_lgkm0<JB - DSPLIT>();
+            wait_vm_lgkm0<JB - DSP>();
           else
             wait_vm_lgkm0<0>();
+        } else if (APF && ph == 0) {
+          if (kt + 1 < ntiles) wait_vm_lgkm0<JA>();   // B(kt+1) landed (A(kt+1), just issued, may fly)
+          else wait_vm_lgkm0<0>();
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -932,11 +955,28 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
             for (int nt = 0; nt < TN16; ++nt)
               acc16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][mt], b[0][nt], acc16[mt][nt], 0, 0, 0);
-            if constexpr (DSPLIT > 0) {   // one moved piece behind each of the first DSPLIT rows of MFMAs
-              if (mt < DSPLIT) {
+            if constexpr (DSP > 0) {   // one moved piece behind each of the first DSPLIT rows of MFMAs
+              if (mt < DSP) {
                 __builtin_amdgcn_sched_barrier(0);
-                dma_piece(ph * DPP + (DPP - DSPLIT) + mt, kt, ia ^ 1, ibn);
+                dma_piece(ph * DPP + (DPP - DSP) + mt, kt, ia ^ 1, ibn);
                 __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          if constexpr (APF) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ph == 0) {           // phase 1's A fragments
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int ra = wm * 64 + 16 * t + (l & 15);
+                apf[t] = *reinterpret_cast<const f16x8*>(SA + ra * RB + swz(ra, 4 + (l >> 4)) * 16);
+              }
+            } else if (kt + 1 < ntiles) {   // the next k-tile's first four B fragments of phase 0
+              const unsigned char* SN = lds + b_off((ib + 1 >= NB) ? 0 : ib + 1);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int rb = wn * (16 * TN16) + 16 * t + (l & 15);
+                apf[t] = *reinterpret_cast<const f16x8*>(SN + rb * RB + swz(rb, l >> 4) * 16);
               }
             }
           }
@@ -1751,6 +1791,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 0, 0, true, 1, 1>(SV_F16_ARGS);   // plain loop (A/B)
         // (buffer_load lds is SLOWER in this kernel -- 18.70 vs 18.19 ms -- although faster in the micro-benchmark's loop and in
         //  the deep-row kernel, 125.2 vs 126.4 ms: only on request here)
+        if (ctx->opt.f16_dsplit == -1)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, -1>(SV_F16_ARGS);   // fragment prefetch (A/B)
         if (ctx->opt.f16_dsplit == 2)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 2>(SV_F16_ARGS);   // split DMA issue (A/B)
         if (ctx->opt.f16_dsplit == 1)

@@ -4,6 +4,8 @@
 //   until at most `keep` of its pieces are outstanding, optionally joins a workgroup barrier, and loops.
 //   FOOT 0: all workgroups of an XCD read the same 2 MiB (L2 hits); FOOT 1: every workgroup streams its own region
 //   (HBM / MALL misses); FOOT 2: half and half (the filter's A / B mix).
+//   FOOT 3 / 4 / 5: the single-image filter's database stream -- a workgroup owns 128 consecutive 2-KiB rows (256 KiB) at a
+//   time and walks them in k-tiles: each 1-KiB piece = 8 rows x 128 B (FOOT 3), 4 rows x 256 B (4) or 2 rows x 512 B (5).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -38,7 +40,28 @@ __global__ __launch_bounds__(512) void k(const unsigned char* src, size_t src_by
       const bool shared = FOOT == 0 || (FOOT == 2 && (p & 1) == 0);
       if (shared) off = (size_t)xcd * (2u << 20) + ((pos + (size_t)w * 65536) & ((2u << 20) - 1));
       else off = (16u << 20) + (((size_t)blockIdx.x * 8 + w) * (8u << 20) + pos) % (src_bytes - (32u << 20));
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + off + l * 16), (lptr_t)(mine + slot * 1024), 16, 0, 0);
+      size_t lane_off = l * 16;
+      if (FOOT >= 3) {
+        // this workgroup's piece counter (all waves in step): 256 pieces per 256-KiB tile
+        constexpr int RB = FOOT == 3 ? 128 : FOOT == 4 ? 256 : 512;     // bytes of one row in a piece
+        constexpr int RPP = 1024 / RB;                                   // rows per piece
+        constexpr int LPR = RB / 16;                                     // lanes per row
+        const size_t pc = pos / 1024 * 8 + w;                            // piece index of the workgroup's stream
+        const size_t tile = pc / 256, in = pc % 256;                     // tile = 128 rows x 2 KiB
+        const size_t kt = in / (128 / RPP), rp = in % (128 / RPP);       // k-tile, row group
+        const size_t tbase = (16u << 20) + ((tile * 256 + blockIdx.x) * (256u << 10)) % (src_bytes - (32u << 20));
+        off = tbase + (rp * RPP + l / LPR) * 2048 + kt * RB;
+        lane_off = (l % LPR) * 16;
+      }
+      if (FOOT == 6) {
+        // k-split stream: the workgroup's tile = 16 consecutive 2-KiB rows (32 KiB, contiguous); wave w takes bytes
+        // [256 w, 256 w + 256) of every row: 4 pieces of 4 rows x 256 B; tiles dealt round-robin over the workgroups
+        const size_t pc = pos / 1024;                    // this wave's piece counter
+        const size_t tile = pc / 4, rp = pc % 4;
+        off = (16u << 20) + ((tile * gridDim.x + blockIdx.x) * (32u << 10)) % (src_bytes - (32u << 20)) + (rp * 4 + l / 16) * 2048 + w * 256;
+        lane_off = (l % 16) * 16;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + off + lane_off), (lptr_t)(mine + slot * 1024), 16, 0, 0);
       pos += 1024;
       slot = slot + 1 == SLOTS ? 0 : slot + 1;
     }
@@ -60,7 +83,7 @@ static void run(const unsigned char* src, size_t bytes, unsigned* sink, const ch
   hipEventCreate(&a);
   hipEventCreate(&b);
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, src, bytes, rounds / 8, sink);
-  hipDeviceSynchronize();
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { printf("%-44s launch failed (LDS %zu)\n", what, lds); return; }
   hipEventRecord(a);
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, src, bytes, rounds, sink);
   hipEventRecord(b);
@@ -91,5 +114,15 @@ int main() {
   run<8, 8, 1, 2>(src, bytes, sink, "half shared / half streaming, one round in flight");
   run<8, 16, 1, 2>(src, bytes, sink, "half shared / half streaming, two rounds");
   run<16, 16, 1, 2>(src, bytes, sink, "half/half, 16 pieces per round, one round");
+  run<8, 8, 1, 3>(src, bytes, sink, "row tiles, 128-B row pieces, one round in flight");
+  run<8, 8, 1, 4>(src, bytes, sink, "row tiles, 256-B row pieces, one round in flight");
+  run<8, 8, 1, 5>(src, bytes, sink, "row tiles, 512-B row pieces, one round in flight");
+  run<4, 16, 0, 3>(src, bytes, sink, "row tiles, 128-B row pieces, 16 in flight, no barrier");
+  run<4, 16, 0, 5>(src, bytes, sink, "row tiles, 512-B row pieces, 16 in flight, no barrier");
+  run<4, 16, 0, 1>(src, bytes, sink, "streaming (1-KiB contiguous), 16 in flight, no barrier");
+  run<4, 4, 0, 6>(src, bytes, sink, "k-split tiles (4 rows x 256 B), 4-8 in flight, no barrier");
+  run<4, 8, 0, 6>(src, bytes, sink, "k-split tiles (4 rows x 256 B), 8-12 in flight, no barrier");
+  run<4, 16, 0, 6>(src, bytes, sink, "k-split tiles (4 rows x 256 B), 16-20 in flight, no barrier");
+  run<4, 16, 1, 6>(src, bytes, sink, "k-split tiles (4 rows x 256 B), 16-20 in flight, barrier");
   return 0;
 }
