@@ -863,7 +863,11 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     // (behind the issue of A(kt+1)) makes every wave's pieces of it certain one barrier before the earliest such read --
     // the A stage of the next tile would not do, the lagging half only waits for it one segment after the leading half's
     // MFMA segment that would read it.
-    constexpr bool APF = DSPLIT < 0;
+    constexpr bool APF = DSPLIT == -1;
+    // DSPLIT == -2 (DFIRST): a load segment issues its DMA pieces FIRST and its twelve fragment reads behind them (raw
+    // ds_read_b128: the compiler would put s_waitcnt vmcnt(0) in front of any LDS read it can see behind a DMA) -- asks
+    // whether a DMA's issue is cheaper with no LDS read of the wave in flight (A/B).
+    constexpr bool DFIRST = DSPLIT == -2;
     constexpr int DSP = DSPLIT > 0 ? DSPLIT : 0;
     static_assert(!APF || (MF == 1 && PPn == 2 && TN16 >= 4 && NB == 3), "fragment prefetch: the 16 x 16 x 32 ping-pong loop");
     f16x8 apf[4];
@@ -903,6 +907,24 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
           //  covers rows {0-3, 12-15} of one chunk and rows {4-11} of the next, 16 distinct bank groups)
           static_assert(MF == 0 || (PH == 2 && CH == 8), "a phase = 32 k of 128-byte rows");
           const int cl = 4 * ph + (l >> 4);
+          if constexpr (DFIRST) {
+            static_assert(!DFIRST || TN16 == 8, "DMA-first load segment: 64 x 128 wave tiles");
+#pragma unroll
+            for (int pz = 0; pz < DPP; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
+            // (rows 16 t apart: the swizzle term (row >> 1) & 7 does not depend on t -> one lane address per operand, t in the offset)
+            const int ra0 = wm * 64 + (l & 15), rb0 = wn * (16 * TN16) + (l & 15);
+            const unsigned aa = (unsigned)(size_t)(lptr_t)lds + a_off(ia) + ra0 * RB + swz(ra0, cl) * 16;
+            const unsigned ab = (unsigned)(size_t)(lptr_t)lds + b_off(ib) + rb0 * RB + swz(rb0, cl) * 16;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\t"
+                         "ds_read_b128 %3, %4 offset:6144"
+                         : "=&v"(a[0][0]), "=&v"(a[0][1]), "=&v"(a[0][2]), "=&v"(a[0][3]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\t"
+                         "ds_read_b128 %3, %4 offset:6144"
+                         : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[0][2]), "=&v"(b[0][3]) : "v"(ab));
+            asm volatile("ds_read_b128 %0, %4 offset:8192\n\tds_read_b128 %1, %4 offset:10240\n\tds_read_b128 %2, %4 offset:12288\n\t"
+                         "ds_read_b128 %3, %4 offset:14336"
+                         : "=&v"(b[0][4 % TN16]), "=&v"(b[0][5 % TN16]), "=&v"(b[0][6 % TN16]), "=&v"(b[0][7 % TN16]) : "v"(ab));
+          } else {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int ra = wm * 64 + 16 * t + (l & 15);
@@ -915,14 +937,17 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
             if (APF && ph == 0 && t < 4) b[0][t] = apf[t];
             else b[0][t] = *reinterpret_cast<const f16x8*>(SB + rb * RB + swz(rb, cl) * 16);
           }
+          }
         }
         // DSPLIT > 0: the last DSPLIT pieces of a phase are issued from its MFMA segment (between the MFMAs) instead of its
         // load segment -- the load segment (12 fragment reads + the DMA issue) is what the partner's 32 MFMAs have to cover.
         // The pieces of the LAST phase that move are B(kt+2)'s (pieces >= JA): they are issued behind the k-tile's wait, so
         // the wait leaves only the JB - DSPLIT of them that are in flight by then (older ones retire first: in order).
         static_assert(DSP == 0 || (MF == 1 && PPn == 2 && DPP > DSP && JB >= DSP && NB == 3), "split DMA issue: the 16 x 16 x 32 ping-pong loop");
+        if constexpr (!DFIRST) {
 #pragma unroll
-        for (int pz = 0; pz < DPP - DSP; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
+          for (int pz = 0; pz < DPP - DSP; ++pz) dma_piece(ph * DPP + pz, kt, ia ^ 1, ibn);
+        }
         if (ph == PPn - 1) {
           // last load segment of the k-tile: this wave's pieces of A(kt+1) and B(kt+1) have landed (B(kt+2), the
           // youngest JB DMA instructions, may still fly).  The barriers between here and the first read of tile kt+1
@@ -936,6 +961,11 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
           else wait_vm_lgkm0<0>();
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if constexpr (DFIRST && MF == 1) {   // (the raw reads' registers are final only behind the wait above)
+          asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]));
+#pragma unroll
+          for (int t = 0; t < TN16; ++t) asm volatile("" : "+v"(b[0][t]));
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1793,6 +1823,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
         //  the deep-row kernel, 125.2 vs 126.4 ms: only on request here)
         if (ctx->opt.f16_dsplit == -1)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, -1>(SV_F16_ARGS);   // fragment prefetch (A/B)
+        if (ctx->opt.f16_dsplit == -2)
+          return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, -2>(SV_F16_ARGS);   // DMA-first load segment (A/B)
         if (ctx->opt.f16_dsplit == 2)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 2>(SV_F16_ARGS);   // split DMA issue (A/B)
         if (ctx->opt.f16_dsplit == 1)
