@@ -182,6 +182,8 @@ def parse():
     p.add_argument("--group", type=int, default=4, help="reference images per 'same place' sibling group (4 = the headline workload; 31 = a "
                    "17places-like video sequence, gt.py:60-64: every frame has its +-15 neighbours as near-duplicates)")
     p.add_argument("--pipeline", action="store_true", help="describe batch i+1 (its own context and stream) under the search of batch i")
+    p.add_argument("--vote-depth", action="store_true", help="search k_vote = 50 deep instead of the reference's 200 (same votes; the "
+                   "'vote_depth' sub-records of the line: NOT the headline, whose step searches 200 like place_rec_main.py:56)")
     p.add_argument("--no-sub-records", action="store_true", help="skip the 'config2' (raw K*D search, BASELINE configs[1]) and "
                    "'redundant_db' (sibling groups of 31) sub-records of the N=1 line")
     p.add_argument("--search-stats", action="store_true", help="record candidate / refine list occupancies (one extra read-back per search)")
@@ -374,7 +376,7 @@ def run(a, top=True):
         qd = pipe.describe(q_tok, q_msk, q_off_local)
         if world > 1:   # every rank needs all query descriptors: one all_gather of the ragged slices
             qd = index.gather_rows(qd, [int(qb[r + 1] - qb[r]) * S for r in range(world)])
-        return index.retrieve(qd, q_off_all, 200, 50, 5)
+        return index.retrieve(qd, q_off_all, 200, 50, 5, vote_depth_only=a.vote_depth)
 
     # pipelined steps: K describes + K searches, describe(i+1) enqueued on its own stream BEFORE search(i) is issued (the
     # search synchronises with the host twice; everything it needs to overlap with must already be in the queue)
@@ -728,11 +730,12 @@ def run(a, top=True):
                       "(bit-identical to the all-fp32 path); the projection GEMM is a 3-product fp16 split with fp32 accumulation",
         "data": "synthetic",
         "config": {"workload": f"{nQ} query images x {S} seg vs {nR * S}-segment DB ({nR} ref images), {W}x{H} -> {N} tokens, "
-                               f"D={D}, K={K}, {'PCA ' + str(P) if use_pca else 'raw K*D'}, order {a.order}, search 200 / vote 50",
+                               f"D={D}, K={K}, {'PCA ' + str(P) if use_pca else 'raw K*D'}, order {a.order}, " + ("search 50 (the vote's depth) / vote 50" if a.vote_depth else "search 200 / vote 50"),
                    "query_images": nQ, "db_segments": nR * S, "segments_per_image": S, "clusters": K, "desc_dim": D,
                    "tokens": N, "pca_dim": P if use_pca else None, "order": a.order, "parallelism": f"db-row-shard x{world}" + (" (C-ABI RCCL communicator)" if a.native_comm and world > 1 else ""),
                    "query_own": a.query_own},
         "recall_at_1": recalls[0], "recall_at_5": recalls[4], "db_build_s": t_build,
+        "pred_sha1": __import__("hashlib").sha1(np.ascontiguousarray(pred).astype(np.int64).tobytes()).hexdigest()[:16],
         "pca_path": pca_path, "sibling_group": a.group, "recall_at_1_within_sibling_group": recalls_group[0],
         "search_stats": sstats, "per_rank_stages_ms": per_rank,
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in stages.items()},
@@ -776,7 +779,7 @@ def sub_record(a, **over):
     except Exception as e:   # a sub-record never takes the headline line down with it
         return {"error": f"{type(e).__name__}: {e}"}
     keep = ("value", "unit", "ms_per_step", "ms_per_step_hip_event_median", "filter_dtype", "recall_at_1", "recall_at_5",
-            "recall_at_1_within_sibling_group", "sibling_group", "search_stats", "stages_ms_per_step", "db_build_s", "steps")
+            "recall_at_1_within_sibling_group", "sibling_group", "search_stats", "stages_ms_per_step", "db_build_s", "steps", "pred_sha1")
     out = {k: r[k] for k in keep if k in r}
     out["workload"] = r["config"]["workload"]
     if r.get("oracle_check"):
@@ -797,6 +800,16 @@ def main():
         res["config2"] = sub_record(a, no_pca=True, db_images=1000, search_stats=True)
         # a 17places-like temporally redundant database (gt.py:60-64): sibling groups of 31 near-duplicate frames
         res["redundant_db"] = sub_record(a, group=31, search_stats=True)
+        # the same two workloads for a caller that does not keep the 200-wide lists (place_rec_main.py:61-75 pickles them only
+        # under save_results; the prediction reads 50 columns, :77-85): the single index searches -- and refines -- 50 deep, as
+        # every shard of a multi-GPU run already does.  Same predictions; NOT the headline, whose step searches 200.
+        for key, over in (("vote_depth", {}), ("config2_vote_depth", {"no_pca": True, "db_images": 1000})):
+            r = sub_record(a, vote_depth=True, search_stats=True, **over)
+            full = res if key == "vote_depth" else res["config2"]
+            if "error" not in r:
+                r = {k: r[k] for k in ("value", "unit", "ms_per_step", "search_stats", "stages_ms_per_step", "workload", "pred_sha1") if k in r}
+                r["predictions_identical_to_search_200"] = bool(r.get("pred_sha1")) and r.get("pred_sha1") == full.get("pred_sha1")
+            res[key] = r
     if world == 1 and a.shard_sim > 1 and not a.no_sub_records and not a.no_pca and not a.sweep_own:
         try:
             res["shard_sim"] = shard_sim(a, a.shard_sim)

@@ -146,9 +146,11 @@ class SegVLADPipeline:
 
     # ---- a10..a12: descriptors -> ranked reference images ----------------------------------------------
     def retrieve(self, qdesc: torch.Tensor, qseg_offsets: np.ndarray, k_search: int = 200, k_vote: int = 50, n_top: int = 5,
-                 mode: int = _lib.VOTE_WT_BORDA_IM, want_scores: bool = False):
-        """search k_search (place_rec_main.py:56) -> keep k_vote and 2-d^2 (:78-81) -> vote (:84)."""
-        d2, idx = self.eng.search(qdesc, k_search)
+                 mode: int = _lib.VOTE_WT_BORDA_IM, want_scores: bool = False, vote_depth_only: bool = False):
+        """search k_search (place_rec_main.py:56) -> keep k_vote and 2-d^2 (:78-81) -> vote (:84).  vote_depth_only: search
+        only as deep as the vote reads (the 200-wide lists are only pickled under save_results, :61-75): the same k_vote columns
+        -- an exact search's first columns do not depend on its depth -- for a quarter of the refinement."""
+        d2, idx = self.eng.search(qdesc, k_vote if vote_depth_only else k_search)
         sims, m = self.eng.sims_from_d2(d2, idx, k_vote)
         pred, sc = self.eng.vote(m, sims, qseg_offsets, n_top=n_top, mode=mode, want_scores=want_scores)
         return pred, sc, m, sims

@@ -152,10 +152,12 @@ class ShardedSegmentIndex:
         return d2c, idc
 
     def retrieve(self, Q, qseg_offsets: Sequence[int], k_search: int = 200, k_vote: int = 50, n_top: int = 5, mode: int = 0,
-                 want_scores: bool = False):
+                 want_scores: bool = False, vote_depth_only: bool = False):
         """search -> keep k_vote, 2-d^2 -> vote with the global segment->image map.  The global min/max of the
-        vote (func_vpr.py:212-213) is taken over the merged (global) similarities, so it needs no extra collective."""
-        if self.world > 1:
+        vote (func_vpr.py:212-213) is taken over the merged (global) similarities, so it needs no extra collective.
+        vote_depth_only: a caller that does not keep the k_search-wide lists (place_rec_main.py:61-75 pickles them only under
+        save_results) may have a single index search k_vote deep as well -- same first k_vote columns, same votes."""
+        if self.world > 1 or vote_depth_only:
             # The reference searches 200 and keeps 50 (place_rec_main.py:56,78).  The global top-50 is contained in the union
             # of the per-shard top-50 lists, and an exact search returns the same first 50 rows whatever depth it is asked
             # for (ascending by (distance, id)): every shard searches -- and refines -- k_vote deep, not k_search, and only

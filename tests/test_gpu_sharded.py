@@ -235,3 +235,24 @@ def test_cabi_sharded_entry_world_1(tmp_path):
     pa = a.retrieve(torch.from_numpy(Q).to(eng.device), off, k_search=60, k_vote=50, n_top=5)
     pb = b.retrieve(torch.from_numpy(Q).to(eng.device), off, k_search=60, k_vote=50, n_top=5)
     assert torch.equal(pa[0], pb[0]) and torch.equal(pa[2], pb[2]) and torch.equal(pa[3], pb[3])
+
+
+def test_vote_depth_only_retrieve_equals_the_search_200_retrieve():
+    """A single index asked to search only as deep as the vote reads (k_vote = 50 of place_rec_main.py:56's 200) returns the same
+    kept neighbours, similarities, predictions and scores: an exact search's first 50 columns do not depend on its depth."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from revisit_anything_amd.engine import SegVLADEngine
+    from revisit_anything_amd.sharded import ShardedSegmentIndex
+
+    R, img, Q, tau, off, n_img, S = _problem()
+    eng = SegVLADEngine(0)
+    idx = ShardedSegmentIndex(eng, device=eng.device)
+    idx.build(torch.from_numpy(R).to(eng.device), img)
+    Qg = torch.from_numpy(Q).to(eng.device)
+    full = idx.retrieve(Qg, off, k_search=200, k_vote=50, n_top=5, want_scores=True)
+    lean = idx.retrieve(Qg, off, k_search=200, k_vote=50, n_top=5, want_scores=True, vote_depth_only=True)
+    for a, b in zip(full, lean):
+        assert torch.equal(torch.as_tensor(a), torch.as_tensor(b))
+    eng.close()
