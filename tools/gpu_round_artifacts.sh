@@ -65,7 +65,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   f=$(find /tmp/prof_st -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_stream_pass_kernel_stats.csv
   cd $REPO
   # micro-benchmarks behind the ceilings quoted in DESIGN.md (MFMA rate under the power cap; gather bandwidth vs bytes in flight)
-  { timeout 120 ./tools/ubench/mfma_peak 20000; timeout 120 ./tools/ubench/gather_bw; } > $OUT/${TAG}_ubench.txt 2>&1
+  { timeout 120 ./tools/ubench/mfma_peak 20000; timeout 120 ./tools/ubench/gather_bw; timeout 120 ./tools/ubench/lds_dma_bw; } > $OUT/${TAG}_ubench.txt 2>&1
   # the plain same-shape GEMM yardstick (torch.matmul fp16, result written) on its own
   timeout 120 python tools/yardstick_gemm.py > $OUT/${TAG}_yardstick_gemm.json 2>/dev/null
 fi
