@@ -1334,6 +1334,9 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // per-query scratch is sized for the rows of one chunk -- min(nq, SV_CHUNK), not SV_CHUNK: a one-image search on a large
   // index used to allocate > 1 GiB of candidate lists (the buffers only ever grow, so a later large batch re-allocates once)
   const size_t mrows = (size_t)std::min(nq, SV_CHUNK);
+  // flag block: [nq] row flags, 2 counts (flagged, second-tier), [mrows] second-tier flags of the current chunk -- one fill
+  const size_t ovf_bytes = (((size_t)nq + 2 + mrows) * 4 + 255) & ~(size_t)255;   // (a whole number of 256-byte blocks: one fill kernel)
+  bool ovf_zeroed = false;
   if (f16_path || bf16_path) {
     if (ctx->db_rn_max_rows < n) {
       float m = 0.f;
@@ -1361,21 +1364,33 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       ctx->db_f16_rows = n;
     }
     SV_HIP(ctx->s_qf16.reserve((size_t)nq * d * 2));
+    // batches on the default configuration take the biased-accumulator kernel when the norms allow it (below): min ||q||^2
+    const bool want_q2min = nq > 128 && (ctx->opt.f16_cfg < 0 || ctx->opt.f16_cfg == 250 || ctx->opt.f16_cfg == 300);
+    float q2min_pre = 0.f;
+    bool have_q2min = false;
     if (nq <= 128 && (((int64_t)nq * d) & 3) == 0 && (int64_t)nq * d <= (1 << 18)) {
       // one query image per pass: the scale is computed AND consumed on the device (a host round trip in front of every pass
       // was ~45 us of a ~600 us call).  One workgroup reads the block twice: up to 1 MiB of queries (128 x 2048 floats);
       // deeper rows (raw K*D descriptors) keep the many-workgroup kernels and their read-back.
       SV_HIP(ctx->s_qscale.reserve(16));
       const bool fuse_qn = !qn_done && (reinterpret_cast<uintptr_t>(dq) & 15) == 0;   // (d % 64 == 0 on this path)
+      SV_HIP(ctx->s_ovf.reserve(ovf_bytes));
       SV_TRY(sv_launch_query_f16_small(ctx, (const float*)dq, (int64_t)nq * d, ctx->db_f16_scale, ctx->s_qf16.as<uint16_t>(),
-                                       ctx->s_qscale.as<float>(), fuse_qn ? ctx->s_qnorm.as<float>() : nullptr, nq, d));
+                                       ctx->s_qscale.as<float>(), fuse_qn ? ctx->s_qnorm.as<float>() : nullptr, nq, d,
+                                       ctx->s_ovf.as<uint32_t>(), (int)(ovf_bytes / 4)));
+      ovf_zeroed = true;   // (the flag block of this search: no fill launch of its own in front of the pass)
       if (fuse_qn) qn_done = true;
       ctx->f16_scale_dev = ctx->s_qscale.as<float>();
       pl.inv_scale = 0.f;   // (unused: the kernels read s_qscale[1])
     } else {
       SV_TRY(ensure_qn());
       float qmax = 0.f;
-      SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
+      if (want_q2min) {   // both scalars behind one read-back
+        SV_TRY(sv_maxabs_and_norm_min(ctx, (const float*)dq, (int64_t)nq * d, qn, nq, &qmax, &q2min_pre));
+        have_q2min = true;
+      } else {
+        SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
+      }
       qscale = pow2_scale(qmax);
       SV_TRY(sv_launch_to_f16(ctx, (const float*)dq, (int64_t)nq * d, qscale, ctx->s_qf16.as<uint16_t>()));
       pl.inv_scale = 1.f / (qscale * ctx->db_f16_scale);
@@ -1385,9 +1400,9 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     // its margin: bias_mult = 1 + max||r|| / (2 min||q||), 1.5 for unit vectors
     float bias_mult = 1.f;
     ctx->f16_bias_ok = false;
-    if (nq > 128 && (ctx->opt.f16_cfg < 0 || ctx->opt.f16_cfg == 250 || ctx->opt.f16_cfg == 300)) {   // (deep rows too: round 4)
-      float q2min = 0.f;
-      SV_TRY(sv_row_norm_min(ctx, qn, nq, &q2min));
+    if (want_q2min) {   // (deep rows too: round 4)
+      float q2min = q2min_pre;
+      if (!have_q2min) SV_TRY(sv_row_norm_min(ctx, qn, nq, &q2min));
       if (q2min > 0.f && pl.rn_max > 0.f) {
         const float bm = 1.f + std::sqrt(pl.rn_max) / (2.f * std::sqrt(q2min));
         if (std::isfinite(bm) && bm <= 5.f) {
@@ -1430,9 +1445,8 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   plh.inv_scale = pl.inv_scale;
   plh.rn_max = pl.rn_max;
   // layout: [nq] row flags, 2 counts (flagged, second-tier), [mrows] second-tier flags of the current chunk -- one memset
-  const size_t ovf_bytes = (((size_t)nq + 2 + mrows) * 4 + 255) & ~(size_t)255;   // (a whole number of 256-byte blocks: one fill kernel)
   SV_HIP(ctx->s_ovf.reserve(ovf_bytes));
-  SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ovf_bytes, ctx->stream));
+  if (!ovf_zeroed) SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ovf_bytes, ctx->stream));
   uint32_t* flag_rows = ctx->s_ovf.as<uint32_t>();
   uint32_t* flag_count = flag_rows + nq;
   uint32_t* rovf_flags = flag_count + 2;

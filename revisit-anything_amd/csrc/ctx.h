@@ -384,6 +384,8 @@ int sv_refine_small_repair(segvlad_ctx* ctx);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);
+int sv_maxabs_and_norm_min(segvlad_ctx* ctx, const float* x, int64_t n, const float* norms, int64_t n_norms, float* maxabs_host,
+                           float* norm_min_host);
 // gemm_f16x3_kernels.hip
 int sv_launch_split_f16x2(segvlad_ctx* ctx, const float* X, int64_t n_rows, int d, const float* sub, float scale, uint16_t* h1,
                           uint16_t* h2);
@@ -402,7 +404,7 @@ int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float sc
 // [1] = 1 / (query scale x db_scale)); ctx->f16_scale_dev != null makes the filter kernel read [1] instead of its argument
 // qn_out != null (needs d % 4 == 0, 16-byte aligned rows): also the rows' squared norms, bit for bit sv_launch_row_sumsq's
 int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev,
-                              float* qn_out = nullptr, int nq = 0, int d = 0);
+                              float* qn_out, int nq, int d, uint32_t* zero, int zero_words);
 int sv_launch_to_f16_devscale(segvlad_ctx* ctx, const float* X, int64_t n_elems, const float* scales_dev, uint16_t* out);
 int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,

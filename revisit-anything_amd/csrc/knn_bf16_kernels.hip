@@ -339,10 +339,13 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float* __restrict__ X
 // front of this one.
 __global__ __launch_bounds__(1024) void query_f16_small_kernel(const float* __restrict__ X, int64_t n4, float db_scale,
                                                                _Float16* __restrict__ out, float* __restrict__ scales,
-                                                               float* __restrict__ qn_out, int nq, int d) {
+                                                               float* __restrict__ qn_out, int nq, int d,
+                                                               uint32_t* __restrict__ zero, int zero_words) {
   __shared__ uint32_t wmax[16];
   __shared__ float s_scale;
   const int tid = threadIdx.x;
+  // the search's flag block, zeroed here instead of by a fill launch of its own in front of the pass's dependent chain
+  for (int j = tid; j < zero_words; j += 1024) zero[j] = 0u;
   if (qn_out) {
     const int lane = tid & 63;
     for (int row = tid >> 6; row < nq; row += 16) {
@@ -397,9 +400,9 @@ __global__ __launch_bounds__(1024) void query_f16_small_kernel(const float* __re
 }
 
 int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems, float db_scale, uint16_t* out, float* scales_dev,
-                              float* qn_out, int nq, int d) {
+                              float* qn_out, int nq, int d, uint32_t* zero, int zero_words) {
   hipLaunchKernelGGL(query_f16_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, X, n_elems / 4, db_scale,
-                     reinterpret_cast<_Float16*>(out), scales_dev, qn_out, nq, d);
+                     reinterpret_cast<_Float16*>(out), scales_dev, qn_out, nq, d, zero, zero_words);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -3013,6 +3016,31 @@ int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_
   float f;
   memcpy(&f, &u, 4);
   *out_host = (n > 0 && key != 0xffffffffu) ? f : 0.f;
+  return SEGVLAD_OK;
+}
+
+// max |x| of a block and the smallest of a list of row norms behind ONE read-back (a batch search needs both before its first
+// filter launch: two synchronisations in a row otherwise)
+int sv_maxabs_and_norm_min(segvlad_ctx* ctx, const float* x, int64_t n, const float* norms, int64_t n_norms, float* maxabs_host,
+                           float* norm_min_host) {
+  SV_HIP(ctx->s_minmax.reserve(32));
+  uint32_t* mm = ctx->s_minmax.as<uint32_t>() + 4;   // [4] = max |x| bits (init 0), [5] = min key (init all ones)
+  static const uint32_t init[2] = {0u, 0xffffffffu};
+  SV_HIP(hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, ctx->stream));
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (n > 0) hipLaunchKernelGGL(maxabs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, n, mm);
+  int nb = (int)((n_norms + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  if (n_norms > 0) hipLaunchKernelGGL(min_kernel, dim3(nb), dim3(256), 0, ctx->stream, norms, n_norms, mm + 1);
+  uint32_t h[2] = {0u, 0u};
+  SV_HIP(hipMemcpyAsync(h, mm, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(maxabs_host, &h[0], 4);
+  const uint32_t u = (h[1] & 0x80000000u) ? (h[1] & 0x7fffffffu) : ~h[1];
+  float f;
+  memcpy(&f, &u, 4);
+  *norm_min_host = (n_norms > 0 && h[1] != 0xffffffffu) ? f : 0.f;
   return SEGVLAD_OK;
 }
 
