@@ -135,7 +135,6 @@ struct SvOptions {
                           // (sv_launch_f16_filter)
   int f16_buf = -1;       // operand DMA as buffer_load ... lds: -1 = the deep-row kernel only (measured faster there, slower in the
                           // batch kernel), 1 = both, 0 = neither
-  int f16_pol = 0;        // batch kernel: cache policy of the operand DMA, bit 0 = database tiles non-temporal, bit 1 = query tiles (A/B)
   int f16_dsplit = 0;     // batch kernel: pieces per phase whose DMA is issued from the MFMA segment instead of the load segment; -1: four of a phase's fragment reads issued from the previous MFMA segment; -2: a load segment's DMAs ahead of its fragment reads (A/B)
   int f16_small_mf = 0;   // 1: the batch filter's small (non-persistent) levels on the 16 x 16 x 32 shape + wave-private epilogue (A/B)
   int f16_pp = -1;        // main batch kernel: 0 = plain loop instead of the ping-pong loop (A/B)

@@ -1824,11 +1824,6 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 0, 0, true, 1, 1>(SV_F16_ARGS);   // plain loop (A/B)
         // (buffer_load lds is SLOWER in this kernel -- 18.70 vs 18.19 ms -- although faster in the micro-benchmark's loop and in
         //  the deep-row kernel, 125.2 vs 126.4 ms: only on request here)
-        // cache policy of the operand DMA (A/B): 1 = database tiles non-temporal (streamed once per query block: should not
-        // displace the XCD's resident query tiles), 2 = query tiles non-temporal, 3 = both
-        if (ctx->opt.f16_pol == 1) return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 1, 2, 0, true, 1, 1>(SV_F16_ARGS);
-        if (ctx->opt.f16_pol == 2) return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 2, 2, 0, true, 1, 1>(SV_F16_ARGS);
-        if (ctx->opt.f16_pol == 3) return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 3, 2, 0, true, 1, 1>(SV_F16_ARGS);
         if (ctx->opt.f16_dsplit == -1)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, -1>(SV_F16_ARGS);   // fragment prefetch (A/B)
         if (ctx->opt.f16_dsplit == -2)

@@ -36,9 +36,9 @@ def _check_variants(R, Q, k, variants, defaults):
     eng.close()
 
 
-BATCH_DEFAULTS = {"f16_epi": -1, "f16_mf": -1, "f16_walk": -1, "f16_pp": -1, "f16_small_mf": 0, "f16_gm": -1, "f16_buf": -1, "f16_dsplit": 0, "f16_pol": 0}
+BATCH_DEFAULTS = {"f16_epi": -1, "f16_mf": -1, "f16_walk": -1, "f16_pp": -1, "f16_small_mf": 0, "f16_gm": -1, "f16_buf": -1, "f16_dsplit": 0}
 BATCH_VARIANTS = [{}, {"f16_epi": 0}, {"f16_mf": 0}, {"f16_walk": 0}, {"f16_walk": 1}, {"f16_walk": 2}, {"f16_walk": 3, "f16_gm": 4},
-                  {"f16_pp": 0}, {"f16_small_mf": 1}, {"f16_mf": 0, "f16_walk": 3}, {"f16_buf": 1}, {"f16_buf": 1, "f16_walk": 2}, {"f16_dsplit": 1}, {"f16_dsplit": 2}, {"f16_dsplit": -1}, {"f16_dsplit": -2}, {"f16_pol": 1}, {"f16_pol": 2}, {"f16_pol": 3}, {"f16_walk": 7}, {"f16_walk": 4}, {"f16_walk": 5}]
+                  {"f16_pp": 0}, {"f16_small_mf": 1}, {"f16_mf": 0, "f16_walk": 3}, {"f16_buf": 1}, {"f16_buf": 1, "f16_walk": 2}, {"f16_dsplit": 1}, {"f16_dsplit": 2}, {"f16_dsplit": -1}, {"f16_dsplit": -2}, {"f16_walk": 7}, {"f16_walk": 4}, {"f16_walk": 5}]
 
 
 def test_batch_filter_variants_are_bit_identical_to_the_fp32_filter():

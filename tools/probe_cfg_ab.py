@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from revisit_anything_amd.engine import SegVLADEngine  # noqa: E402
 
-DEFAULTS = {"f16_cfg": -1, "f16_gm": -1, "f16_walk": -1, "f16_epi": -1, "f16_mf": -1, "f16_deep_cfg": -1, "f16_pp": -1, "f16_small_mf": 0, "f16_buf": -1, "f16_dsplit": 0, "f16_pol": 0}
+DEFAULTS = {"f16_cfg": -1, "f16_gm": -1, "f16_walk": -1, "f16_epi": -1, "f16_mf": -1, "f16_deep_cfg": -1, "f16_pp": -1, "f16_small_mf": 0, "f16_buf": -1, "f16_dsplit": 0}
 
 
 def parse(spec):
