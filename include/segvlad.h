@@ -214,9 +214,13 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *                                                      list in the selects, refinement lists shared by workgroups, the
  *                                                      query scale left on the device | the plan of the batches
  *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning
- *        "f16_mf", "f16_epi", "f16_walk", "f16_pp", "f16_deep_cfg"   integers, A/B switches of the fp16 filter kernels
- *                                                      (MFMA shape, epilogue, tile walk, loop form, deep-row geometry:
- *                                                      csrc/ctx.h SvOptions); never change a result
+ *        "f16_mf", "f16_epi", "f16_walk", "f16_pp", "f16_deep_cfg", "f16_buf", "f16_dsplit", "f16_small_mf"
+ *                                                      integers, A/B switches of the fp16 filter kernels (MFMA shape,
+ *                                                      epilogue, tile walk, loop form, deep-row geometry, DMA form,
+ *                                                      placement of the DMA / fragment reads in a phase: csrc/ctx.h
+ *                                                      SvOptions); never change a result
+ *                                                      (tests/test_gpu_filter_variants.py holds every one to the bits of
+ *                                                      the all-fp32 filter)
  *        "guard_undersize" "<buffer>:<bytes>"          tests of the guard mode only (see below)
  *
  *      Environment, read ONCE by segvlad_create: SEGVLAD_GUARD=1 creates a GUARDED context (development / test runs):

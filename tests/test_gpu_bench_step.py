@@ -48,6 +48,13 @@ def test_bench_step_predictions_equal_oracle_on_20_images():
     assert rd["sibling_group"] == 31 and rd["search_stats"]["n_fallback"] == 0 and rd["search_stats"]["n_redo"] <= 100
     assert rd["recall_at_1_within_sibling_group"] >= 0.95
     assert j["roofline"].get("ubench", {}).get("mfma_only_random_tflops", 0) > 500
+    # round 4: the same two workloads with the single index searching only as deep as the vote reads (50 of 200 columns):
+    # the predictions are those of the 200-deep runs, the refinement a fraction
+    vd, c2v = j["vote_depth"], j["config2_vote_depth"]
+    assert "error" not in vd and "error" not in c2v, (vd, c2v)
+    assert vd["predictions_identical_to_search_200"] is True and c2v["predictions_identical_to_search_200"] is True
+    assert "search 50" in vd["workload"] and "search 200" in j["config"]["workload"]
+    assert c2v["stages_ms_per_step"]["knn_select"] < 0.5 * c2["stages_ms_per_step"]["knn_select"]
 
 
 def test_bench_two_ranks_one_gpu_equal_single_rank(tmp_path):
