@@ -262,6 +262,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "f16_small_mf")) return as_int(&o.f16_small_mf);
   if (!strcmp(key, "f16_buf")) return as_int(&o.f16_buf);
   if (!strcmp(key, "f16_dsplit")) return as_int(&o.f16_dsplit);
+  if (!strcmp(key, "tnk_gram")) return as_int(&o.tnk_gram);
   if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);
   if (!strcmp(key, "x3_gm")) return as_int(&o.x3_gm);
   if (!strcmp(key, "search_stats")) return as_int(&o.search_stats);

@@ -135,6 +135,8 @@ struct SvOptions {
                           // (sv_launch_f16_filter)
   int f16_buf = -1;       // operand DMA as buffer_load ... lds: -1 = the deep-row kernel only (measured faster there, slower in the
                           // batch kernel), 1 = both, 0 = neither
+  int tnk_gram = 1;       // fused VLAD -> PCA, project form: block norms of tasks with <= 64 tokens from their Gram matrix on the
+                          // 16-bit matrix pipe (gram_norms_kernel); 0 = the fp32 block sums for every task
   int f16_dsplit = 0;     // batch kernel: pieces per phase whose DMA is issued from the MFMA segment instead of the load segment; -1: four of a phase's fragment reads issued from the previous MFMA segment; -2: a load segment's DMAs ahead of its fragment reads (A/B)
   int f16_small_mf = 0;   // 1: the batch filter's small (non-persistent) levels on the 16 x 16 x 32 shape + wave-private epilogue (A/B)
   int f16_pp = -1;        // main batch kernel: 0 = plain loop instead of the ping-pong loop (A/B)

@@ -1161,7 +1161,8 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
                                                                     const int32_t* __restrict__ seg_off, int N, int D, int K, int SC,
                                                                     int Dpad, float* __restrict__ block_norms, float xscale,
                                                                     _Float16* __restrict__ h1, _Float16* __restrict__ h2,
-                                                                    const int32_t* __restrict__ rowbase, int64_t dummy_row) {
+                                                                    const int32_t* __restrict__ rowbase, int64_t dummy_row,
+                                                                    int skip_le) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
   const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -1182,6 +1183,7 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
   const int nd = Dpad >> 7, total = nd * npairs;
   const size_t tb = (size_t)b * N + o0;
   if ((n >= TNK_LCAP) != BIG) return;   // the other instantiation's task
+  if (n <= skip_le) return;             // gram_norms_kernel's task (skip_le = -1: none)
   if (n == 0) {   // an empty cluster: zero norms, no rows
     for (int s = l; s < S; s += 64) block_norms[(size_t)(s0 + s) * K + k] = 0.f;
     return;
@@ -1340,6 +1342,196 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
   }
 }
 
+// ---- block norms from the Gram matrix of a task's residuals (round 4) ---------------------------------------------------------
+// ||sum_t m_t r_t||^2 = m^T (R R^T) m: a task (image, cluster) with n <= 32 tokens needs the n x n Gram matrix G of its token
+// residuals -- ONE 32 x 32 accumulator tile instead of the 64 x 128 block sums of token_norms_kernel (128 accumulator registers,
+// eight fp32 MFMAs per pair of tokens: that kernel is bound by the fp32 matrix pipe, 8 B/clk/CU of tokens) -- and, per segment,
+// a bit-masked quadratic form over G.  G runs on the 16-bit pipe: the residuals are split r * xscale = h + l + e exactly as the
+// planes want them (|e| <= 2^-22 |r|), G += l h^T + h l^T + h h^T with the A and B fragments being the SAME registers
+// (v_mfma_f32_32x32x16_f16: lane (i, kk) holds token i, columns 8 kk .. 8 kk + 7 of a 16-column k-step), and those fragments
+// are, byte for byte, the planes' 16-byte chunks.  One wave per task; tokens stream through a two-slot wave-private DMA queue,
+// 32 tokens x 32 columns (4 KiB, four pieces of 8 tokens x 128 B, source-side swizzled: chunk ^ ((token >> 1) & 7)) per step.
+// Tasks with more than 64 tokens of one image in one cluster stay with token_norms_kernel (skip_le).
+// T = 2: tasks of 33 .. 64 tokens -- two token tiles, the three Gram tiles G00, G01, G11 (G10 = G01^T is not formed), 8 KiB per
+// step and queue slot, two waves per workgroup.
+constexpr int GNK_SLOT = 4096;   // one token tile of a step: 32 tokens x 128 B
+
+template <int T>
+__global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
+                                                                         const int32_t* __restrict__ tok_order,
+                                                                         const int32_t* __restrict__ lab_off,
+                                                                         const uint64_t* __restrict__ colmask,
+                                                                         const float* __restrict__ C,
+                                                                         const int32_t* __restrict__ seg_off, int N, int D, int K, int SC,
+                                                                         float* __restrict__ block_norms, float xscale,
+                                                                         _Float16* __restrict__ h1, _Float16* __restrict__ h2,
+                                                                         const int32_t* __restrict__ rowbase, int safe_waits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  constexpr int WAVES = T == 1 ? 4 : 2;
+  constexpr int NG = T * (T + 1) / 2;   // Gram tiles held: (0,0) | (0,0), (0,1), (1,1)
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = (int)blockIdx.x * WAVES + w;
+  if (k >= K) return;   // (no barriers in this kernel)
+  const size_t wsz = 2 * (size_t)T * GNK_SLOT + (size_t)D * 4;
+  unsigned char* qbase = smem + (size_t)w * wsz;                      // [2][T x 4 KiB] DMA queue
+  float* cl = reinterpret_cast<float*>(qbase + 2 * T * GNK_SLOT);     // [D] centre k
+  const int o0 = lab_off[(size_t)b * (K + 1) + k];
+  const int n = lab_off[(size_t)b * (K + 1) + k + 1] - o0;
+  if (n > 32 * T || (T == 2 && n <= 32)) return;   // the other instantiation's / token_norms_kernel's task
+  const int s0 = seg_off[b], S = seg_off[b + 1] - s0;
+  if (n == 0) {   // an empty cluster: zero norms, no rows
+    for (int s = l; s < S; s += 64) block_norms[(size_t)(s0 + s) * K + k] = 0.f;
+    return;
+  }
+  const size_t tb = (size_t)b * N + o0;
+  for (int d = 4 * l; d < D; d += 256) *reinterpret_cast<float4*>(cl + d) = *reinterpret_cast<const float4*>(C + (size_t)k * D + d);
+  bool real[T];
+  float rn[T];
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt) {
+    real[tt] = 32 * tt + i < n;
+    rn[tt] = real[tt] ? rnorm[tb + 32 * tt + i] : 0.f;
+  }
+  const float* Xb = Xt + (size_t)b * N * D;
+  // DMA sources of this lane: piece pz = tokens 8 pz .. 8 pz + 7, lane -> token 8 pz + (l >> 3), LDS position l & 7
+  const float* src[4 * T];
+#pragma unroll
+  for (int pz = 0; pz < 4 * T; ++pz) {
+    const int jj = 8 * pz + (l >> 3);
+    const int t = jj < n ? tok_order[tb + jj] : tok_order[tb];   // (rows beyond n: a valid address, never used)
+    src[pz] = Xb + (size_t)t * D + 4 * ((l & 7) ^ ((jj >> 1) & 7));
+  }
+  const int steps = D >> 5;
+  auto issue = [&](int f) {
+#pragma unroll
+    for (int pz = 0; pz < 4 * T; ++pz)
+      __builtin_amdgcn_global_load_lds((agg_gptr_t)(src[pz] + 32 * f), (agg_lptr_t)(qbase + (f & 1) * (T * GNK_SLOT) + pz * 1024), 16, 0, 0);
+  };
+  issue(0);
+  if (steps > 1) issue(1);
+  f32x16 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  size_t prow[T];
+  unsigned pswz[T];
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt) {
+    const int64_t rr = (int64_t)rowbase[(size_t)b * K + k] + 32 * tt + i;   // this lane's row of the grouped planes
+    prow[tt] = (size_t)(rr >> 7) * (size_t)(D >> 5) * 4096 + (size_t)(rr & 127) * 32;
+    pswz[tt] = (unsigned)sv_x3_swz(rr);
+  }
+  const unsigned fsw = (unsigned)((i >> 1) & 7);
+  const unsigned a_tok = lds_addr(qbase) + (unsigned)i * 128u;
+  for (int f = 0; f < steps; ++f) {
+    // the DMAs of step f have landed: behind them were issued the 4 T plane stores of step f - 2, the 4 T DMAs of step f + 1
+    // and the 4 T stores of step f - 1 (loads and stores retire in issue order)
+    // (safe_waits: the development switch debug_search = 7 -- everything, at every step; the test compares the two bit for bit)
+    if (f >= 2 && f + 1 < steps && !safe_waits) {
+      if (T == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    f32x4 x[T][4], c[4];
+    {
+      const unsigned ac = lds_addr(cl) + (unsigned)(32 * f + 8 * kk) * 4u;
+      // chunks 2 kk, 2 kk + 1 (k-step 0) and 4 + 2 kk, 5 + 2 kk (k-step 1) of token i, at their swizzled positions
+      const unsigned p0 = ((unsigned)(2 * kk) ^ fsw) << 4, p1 = ((unsigned)(2 * kk + 1) ^ fsw) << 4;
+      const unsigned p2 = ((unsigned)(4 + 2 * kk) ^ fsw) << 4, p3 = ((unsigned)(5 + 2 * kk) ^ fsw) << 4;
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+        const unsigned a0 = a_tok + (unsigned)(f & 1) * (T * GNK_SLOT) + (unsigned)tt * GNK_SLOT;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+                     : "=&v"(x[tt][0]), "=&v"(x[tt][1]), "=&v"(x[tt][2]), "=&v"(x[tt][3])
+                     : "v"(a0 + p0), "v"(a0 + p1), "v"(a0 + p2), "v"(a0 + p3)
+                     : "memory");
+      }
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:80\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                   : "v"(ac)
+                   : "memory");
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) asm volatile("" : "+v"(x[tt][0]), "+v"(x[tt][1]), "+v"(x[tt][2]), "+v"(x[tt][3]));   // (final behind the wait)
+    }
+    if (f + 2 < steps) issue(f + 2);   // the slot has been read
+    asm volatile("" ::: "memory");     // (the plane stores below stay behind these DMAs: the counted wait relies on the order)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 hh[T], ll[T];
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = x[tt][2 * ks + (e >> 2)][e & 3], cv = c[2 * ks + (e >> 2)][e & 3];
+          const float fv = real[tt] ? fmaf(xv, rn[tt], -cv) * xscale : 0.f;
+          hh[tt][e] = (_Float16)fv;
+          ll[tt][e] = (_Float16)(fv - (float)hh[tt][e]);
+        }
+        // the planes' 16-byte chunk (row, columns 32 f + 16 ks + 8 kk ..): issued by every step (the counted waits above;
+        // lane 0 of tile 0 is always a real token, tile 1 of a T = 2 task always holds one)
+        const size_t ob = prow[tt] + (size_t)f * 4096 + (size_t)((((unsigned)(2 * ks + kk)) ^ pswz[tt]) << 3);
+        if (real[tt]) {
+          *reinterpret_cast<f16x8*>(h1 + ob) = hh[tt];
+          *reinterpret_cast<f16x8*>(h2 + ob) = ll[tt];
+        }
+      }
+      // G(a, b) += l_a h_b^T + h_a l_b^T + h_a h_b^T, small terms first
+#pragma unroll
+      for (int ta = 0, g = 0; ta < T; ++ta)
+#pragma unroll
+        for (int tb2 = ta; tb2 < T; ++tb2, ++g) {
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ll[ta], hh[tb2], acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh[ta], ll[tb2], acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh[ta], hh[tb2], acc[g], 0, 0, 0);
+        }
+    }
+  }
+  // ---- per segment: m^T G m over this lane's 16 entries G(a, b)[frag_row(r, kk)][i] of every tile, then across the wave ------
+  const float inv_x2 = 1.f / (xscale * xscale);
+  const int SCb = (S + 63) >> 6;
+  for (int sc = 0; sc < SCb; ++sc) {
+    const int Sc = min(64, S - 64 * sc);
+    uint64_t mt[T];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) mt[tt] = real[tt] ? colmask[(tb + 32 * tt + i) * SC + sc] : 0ull;   // (lanes 32..63 repeat lanes 0..31)
+    for (int s = 0; s < Sc; ++s) {
+      uint32_t W[T];   // bit t: token 32 tt + t covered by segment s
+      bool any = false;
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+        W[tt] = (uint32_t)__builtin_amdgcn_ballot_w64(((mt[tt] >> s) & 1ull) != 0ull);
+        any |= W[tt] != 0u;
+      }
+      float p = 0.f;
+      if (any) {   // (wave-uniform)
+#pragma unroll
+        for (int ta = 0, g = 0; ta < T; ++ta)
+#pragma unroll
+          for (int tb2 = ta; tb2 < T; ++tb2, ++g) {
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q += ((W[ta] >> frag_row(r, kk)) & 1u) ? acc[g][r] : 0.f;
+            q = ((W[tb2] >> i) & 1u) ? q : 0.f;
+            p += (ta == tb2) ? q : 2.f * q;   // the off-diagonal tile stands for its transpose as well
+          }
+        p += dpp_f32<0xB1>(p);
+        p += dpp_f32<0x4E>(p);
+        p += dpp_f32<0x141>(p);
+        p += dpp_f32<0x140>(p);
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+      }
+      if (l == 0) block_norms[(size_t)(s0 + 64 * sc + s) * K + k] = sqrtf(fmaxf(p, 0.f) * inv_x2);
+    }
+  }
+}
+
 int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* colmask, const float* centres, int K, int D,
                           const int32_t* seg_off_dev, int B, int N, int SC, float* block_norms, float xscale, uint16_t* h1,
                           uint16_t* h2, const int32_t* rowbase, int64_t dummy_row) {
@@ -1347,6 +1539,23 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
   const int Dpad = (D + 127) & ~127;
   const size_t lds = (size_t)TNK_WAVES * ((size_t)TNK_QD * 1024 + (size_t)TNK_LCAP * 16 + (size_t)Dpad * 4);
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "token_norms: D=%d needs %zu B of LDS", D, lds);
+  // tasks of <= 64 tokens: the Gram kernels (option tnk_gram, default on; D a multiple of 32); the rest: the block-sum kernels
+  const bool gram = ctx->opt.tnk_gram != 0 && (D % 32) == 0;
+  const int skip_le = gram ? 64 : -1;
+  if (gram) {
+    for (int T = 1; T <= 2; ++T) {
+      if (T == 2 && N <= 32) break;
+      const int waves = T == 1 ? 4 : 2;
+      const size_t glds = (size_t)waves * (2 * (size_t)T * GNK_SLOT + (size_t)D * 4);
+      auto gk = T == 1 ? gram_norms_kernel<1> : gram_norms_kernel<2>;
+      if (glds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(gk), glds));
+      hipLaunchKernelGGL(gk, dim3((K + waves - 1) / waves, B), dim3(64 * waves), glds, ctx->stream, xt, ctx->s_rnsorted.as<float>(),
+                         ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres, seg_off_dev, N, D, K, SC,
+                         block_norms, xscale, reinterpret_cast<_Float16*>(h1), reinterpret_cast<_Float16*>(h2), rowbase,
+                         dummy_row < 0 ? 1 : 0);
+      SV_HIP(hipGetLastError());
+    }
+  }
   for (int big = 0; big < 2; ++big) {
     if (big && N < TNK_LCAP) break;
     auto kern = big ? token_norms_kernel<true> : token_norms_kernel<false>;
@@ -1355,7 +1564,7 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
     hipLaunchKernelGGL(kern, dim3((K + TNK_WAVES - 1) / TNK_WAVES, B), dim3(64 * TNK_WAVES), lds, ctx->stream, xt,
                        ctx->s_rnsorted.as<float>(), ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres,
                        seg_off_dev, N, D, K, SC, Dpad, block_norms, xscale, reinterpret_cast<_Float16*>(h1),
-                       reinterpret_cast<_Float16*>(h2), rowbase, dummy_row);
+                       reinterpret_cast<_Float16*>(h2), rowbase, dummy_row, skip_le);
     SV_HIP(hipGetLastError());
   }
   return SEGVLAD_OK;

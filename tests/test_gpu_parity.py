@@ -796,16 +796,69 @@ def test_images_pca_project_form_big_clusters_and_partial_chunk(eng):
             eng.set_option("pca_path", "auto")
         assert np.abs(ys[path] - ref).max() <= 3e-5 * np.abs(ref).max()
     assert np.abs(ys["project"] - ys["planes"]).max() <= 1e-5 * np.abs(ref).max()
-    # the token kernel's counted waits (DMA queue + plane stores in one vmcnt stream) against the same kernel waiting for
-    # everything at every step (development switch debug_search = 7): bit-identical
+    # the token kernels' counted waits (DMA queue + plane stores in one vmcnt stream) against the same kernels waiting for
+    # everything at every step (development switch debug_search = 7): bit-identical -- with the Gram kernel taking the tasks
+    # of <= 32 tokens (the default) and with the block-sum kernel taking every task (tnk_gram = 0); the two agree to fp32 noise
     eng.set_option("pca_path", "project")
-    eng.set_option("debug_search", "7")
     try:
-        y_safe = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=False)["out"].cpu().numpy()
+        for gram in ("1", "0"):
+            eng.set_option("tnk_gram", gram)
+            y_cnt = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=False)["out"].cpu().numpy()
+            eng.set_option("debug_search", "7")
+            y_safe = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=False)["out"].cpu().numpy()
+            eng.set_option("debug_search", "0")
+            assert np.array_equal(y_safe, y_cnt), gram
+            if gram == "1":
+                assert np.array_equal(y_cnt, ys["project"])
+            else:
+                assert np.abs(y_cnt - ref).max() <= 3e-5 * np.abs(ref).max()
+                assert np.abs(y_cnt - ys["project"]).max() <= 2e-6 * np.abs(ref).max()
     finally:
         eng.set_option("debug_search", "0")
+        eng.set_option("tnk_gram", "1")
         eng.set_option("pca_path", "auto")
-    assert np.array_equal(y_safe, ys["project"])
+
+
+def test_block_norms_from_the_gram_matrix_equal_the_block_sums(eng):
+    """Round 4: tasks (image, cluster) of <= 32 tokens take their block norms from the Gram matrix of their residuals on the
+    16-bit matrix pipe (gram_norms_kernel: ||sum_t m_t r_t||^2 = m^T (R R^T) m, three split products); larger tasks and
+    tnk_gram = 0 keep the fp32 block sums.  Bench proportions scaled down (24 tokens per cluster on average, so both kernels
+    get tasks: some clusters of an image hold > 32 tokens), 50 and 70 segments (one and two segment chunks), an empty
+    cluster, heavy cancellation (segments covering tokens spread around the centre): both forms against the fp64 oracle, and
+    against each other far inside that tolerance."""
+    D, K, N, P = 128, 16, 16 * 24, 48
+    C = synth().make_vocab(K, D, seed=491)
+    rng = np.random.Generator(np.random.PCG64(492))
+    toks, incs, adjs = [], [], []
+    for b, S in enumerate([50, 70, 50, 3]):
+        cents = C[:K - 1] if b == 2 else C          # image 2: cluster K - 1 stays empty
+        toks.append(synth().make_tokens(cents, N, seed=4950 + b, noise=0.5 if b in (1, 3) else 0.05))
+        incs.append(rng.random((S, N)) < (0.3 if b != 1 else 0.05))
+        adjs.append(np.eye(S, dtype=bool) | (rng.random((S, S)) < 0.08))
+    mean, comps, var = synth().make_pca_model(K * D, P, seed=49)
+    eng.set_vocab(C)
+    eng.pca_set(mean, comps, var, whiten=True)
+    offs = np.concatenate([[0], np.cumsum([i.shape[0] for i in incs])]).astype(np.int32)
+    bits = np.concatenate([O().pack_bits_u64(i) for i in incs]).view(np.int64)
+    adj = cat_adj(adjs)
+    tk = np.stack(toks)
+    lab = eng.seg_vlad(tk, bits, offs, adj, want_labels=True)["labels"].cpu().numpy()
+    cnt = np.stack([np.bincount(lab[b], minlength=K) for b in range(4)])
+    assert (cnt > 32).any() and (cnt <= 32).sum() > cnt.size // 2 and (cnt[2] == 0).any()
+    ref = np.concatenate([O().seg_vlad(toks[b], incs[b], C, adjs[b]) for b in range(4)])
+    ref = O().pca_transform(ref, mean, comps, var, True)
+    ys = {}
+    eng.set_option("pca_path", "project")
+    try:
+        for gram in ("1", "0"):
+            eng.set_option("tnk_gram", gram)
+            ys[gram] = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=False)["out"].cpu().numpy()
+            assert np.abs(ys[gram] - ref).max() <= 3e-5 * np.abs(ref).max(), gram
+    finally:
+        eng.set_option("tnk_gram", "1")
+        eng.set_option("pca_path", "auto")
+    assert np.abs(ys["1"] - ys["0"]).max() <= 2e-6 * np.abs(ref).max()
+    assert not np.array_equal(ys["1"], ys["0"])   # (the Gram kernel did run)
 
 
 # ------------------------------------------------------------------------------------------------
