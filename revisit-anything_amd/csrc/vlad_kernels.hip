@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
 // step and queue slot, two waves per workgroup.
 constexpr int GNK_SLOT = 4096;   // one token tile of a step: 32 tokens x 128 B
 
-template <int T>
+template <int T, int QS>   // token tiles of a task, slots of the DMA queue (steps in flight + the one being read)
 __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const float* __restrict__ Xt, const float* __restrict__ rnorm,
                                                                          const int32_t* __restrict__ tok_order,
                                                                          const int32_t* __restrict__ lab_off,
@@ -1375,9 +1375,9 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = (int)blockIdx.x * WAVES + w;
   if (k >= K) return;   // (no barriers in this kernel)
-  const size_t wsz = 2 * (size_t)T * GNK_SLOT + (size_t)D * 4;
-  unsigned char* qbase = smem + (size_t)w * wsz;                      // [2][T x 4 KiB] DMA queue
-  float* cl = reinterpret_cast<float*>(qbase + 2 * T * GNK_SLOT);     // [D] centre k
+  const size_t wsz = (size_t)QS * T * GNK_SLOT + (size_t)D * 4;
+  unsigned char* qbase = smem + (size_t)w * wsz;                      // [QS][T x 4 KiB] DMA queue
+  float* cl = reinterpret_cast<float*>(qbase + QS * T * GNK_SLOT);    // [D] centre k
   const int o0 = lab_off[(size_t)b * (K + 1) + k];
   const int n = lab_off[(size_t)b * (K + 1) + k + 1] - o0;
   if (n > 32 * T || (T == 2 && n <= 32)) return;   // the other instantiation's / token_norms_kernel's task
@@ -1405,13 +1405,20 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
     src[pz] = Xb + (size_t)t * D + 4 * ((l & 7) ^ ((jj >> 1) & 7));
   }
   const int steps = D >> 5;
+  // only the pieces that hold a token are requested (NP of them, wave-uniform), and of the last one only its tokens' lanes: a task
+  // holds ~24 of its tile's 32 rows on average
+  const int NP = (n + 7) >> 3;
   auto issue = [&](int f) {
 #pragma unroll
     for (int pz = 0; pz < 4 * T; ++pz)
-      __builtin_amdgcn_global_load_lds((agg_gptr_t)(src[pz] + 32 * f), (agg_lptr_t)(qbase + (f & 1) * (T * GNK_SLOT) + pz * 1024), 16, 0, 0);
+      if (pz < NP) {   // (wave-uniform: the instruction is issued, and counted, exactly NP times per step)
+        if (8 * pz + (l >> 3) < n)
+          __builtin_amdgcn_global_load_lds((agg_gptr_t)(src[pz] + 32 * f), (agg_lptr_t)(qbase + (f % QS) * (T * GNK_SLOT) + pz * 1024), 16, 0, 0);
+      }
   };
-  issue(0);
-  if (steps > 1) issue(1);
+#pragma unroll
+  for (int q = 0; q < QS; ++q)
+    if (q < steps) issue(q);
   f32x16 acc[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g)
@@ -1428,15 +1435,11 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
   const unsigned fsw = (unsigned)((i >> 1) & 7);
   const unsigned a_tok = lds_addr(qbase) + (unsigned)i * 128u;
   for (int f = 0; f < steps; ++f) {
-    // the DMAs of step f have landed: behind them were issued the 4 T plane stores of step f - 2, the 4 T DMAs of step f + 1
-    // and the 4 T stores of step f - 1 (loads and stores retire in issue order)
+    // the DMAs of step f have landed: behind them were issued, for each of the QS - 1 steps in between, 4 T plane stores and NP
+    // DMAs, and the 4 T stores of step f - 1 (loads and stores retire in issue order)
     // (safe_waits: the development switch debug_search = 7 -- everything, at every step; the test compares the two bit for bit)
-    if (f >= 2 && f + 1 < steps && !safe_waits) {
-      if (T == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (f >= QS && f + QS - 1 < steps && !safe_waits) tnk_wait_vm(QS * 4 * T + (QS - 1) * NP);   // (<= 23 by the helper: stricter beyond)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x4 x[T][4], c[4];
     {
       const unsigned ac = lds_addr(cl) + (unsigned)(32 * f + 8 * kk) * 4u;
@@ -1445,7 +1448,7 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
       const unsigned p2 = ((unsigned)(4 + 2 * kk) ^ fsw) << 4, p3 = ((unsigned)(5 + 2 * kk) ^ fsw) << 4;
 #pragma unroll
       for (int tt = 0; tt < T; ++tt) {
-        const unsigned a0 = a_tok + (unsigned)(f & 1) * (T * GNK_SLOT) + (unsigned)tt * GNK_SLOT;
+        const unsigned a0 = a_tok + (unsigned)(f % QS) * (T * GNK_SLOT) + (unsigned)tt * GNK_SLOT;
         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
                      : "=&v"(x[tt][0]), "=&v"(x[tt][1]), "=&v"(x[tt][2]), "=&v"(x[tt][3])
                      : "v"(a0 + p0), "v"(a0 + p1), "v"(a0 + p2), "v"(a0 + p3)
@@ -1459,7 +1462,7 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
 #pragma unroll
       for (int tt = 0; tt < T; ++tt) asm volatile("" : "+v"(x[tt][0]), "+v"(x[tt][1]), "+v"(x[tt][2]), "+v"(x[tt][3]));   // (final behind the wait)
     }
-    if (f + 2 < steps) issue(f + 2);   // the slot has been read
+    if (f + QS < steps) issue(f + QS);   // the slot has been read
     asm volatile("" ::: "memory");     // (the plane stores below stay behind these DMAs: the counted wait relies on the order)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1546,8 +1549,9 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
     for (int T = 1; T <= 2; ++T) {
       if (T == 2 && N <= 32) break;
       const int waves = T == 1 ? 4 : 2;
-      const size_t glds = (size_t)waves * (2 * (size_t)T * GNK_SLOT + (size_t)D * 4);
-      auto gk = T == 1 ? gram_norms_kernel<1> : gram_norms_kernel<2>;
+      const int qs = T == 1 ? 3 : 2;   // (three slots of 4 KiB, or two of 8)
+      const size_t glds = (size_t)waves * ((size_t)qs * T * GNK_SLOT + (size_t)D * 4);
+      auto gk = T == 1 ? gram_norms_kernel<1, 3> : gram_norms_kernel<2, 2>;
       if (glds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(gk), glds));
       hipLaunchKernelGGL(gk, dim3((K + waves - 1) / waves, B), dim3(64 * waves), glds, ctx->stream, xt, ctx->s_rnsorted.as<float>(),
                          ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres, seg_off_dev, N, D, K, SC,
