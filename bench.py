@@ -634,8 +634,15 @@ def run(a, top=True):
                          "'planes' form (22.7 vs 32.9 MB), so fractions are not comparable across the two -- stage_ms is"}
     if vlad_roof["achieved"]:
         vlad_roof["frac"] = vlad_roof["achieved"] / PEAK_HBM_GBS
-    agg_kernel = "token_norms_kernel" if pca_form == "project" else "aggregate_kernel"
-    agg_traffic, _, agg_src = pmc_counters(agg_kernel, wl_key)
+    if pca_form == "project":
+        # round 4: the block norms + residual planes come from the Gram kernels (tasks of <= 32 / <= 64 tokens), the
+        # block-sum kernel keeps the larger tasks: the quoted traffic is the sum over the three launches
+        agg_kernel = "gram_norms_kernel<1> + gram_norms_kernel<2> + token_norms_kernel"
+        parts = [pmc_counters(kn, wl_key)[0] for kn in ("gram_norms_kernelILi1E", "gram_norms_kernelILi2E", "token_norms_kernelILb0E")]
+        agg_traffic = sum(p for p in parts if p) if any(parts) else None
+    else:
+        agg_kernel = "aggregate_kernel"
+        agg_traffic, _, agg_src = pmc_counters(agg_kernel, wl_key)
     vlad_roof["aggregate_kernel"] = agg_kernel
     vlad_roof["aggregate_traffic"] = agg_traffic
     pca_roof = None
