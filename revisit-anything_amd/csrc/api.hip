@@ -270,6 +270,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "assign_narrow")) return as_int(&o.assign_narrow);
   if (!strcmp(key, "agg_kpb")) return as_int(&o.agg_kpb);
   if (!strcmp(key, "pj_nw")) return as_int(&o.pj_nw);
+  if (!strcmp(key, "pj_f16")) return as_int(&o.pj_f16);
   if (!strcmp(key, "small_plan")) return as_int(&o.small_plan);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
   if (!strcmp(key, "debug_fail_search")) return as_int(&o.debug_fail_search);
@@ -381,6 +382,15 @@ int segvlad_set_vocab(segvlad_ctx* ctx, const float* C, int K, int D) {
   SV_TRY(sv_launch_vocab_prepare(ctx));
   // largest centre component: bounds the token residuals x^ - C_k whose fp16 planes the "project" form builds (images_impl)
   SV_TRY(sv_maxabs(ctx, ctx->vocab.as<float>(), (int64_t)K * D, &ctx->vocab_maxabs));
+  // largest centre norm: ||x^ - C_k|| <= 1 + max ||C_k||, the bound behind the fp16 split of the PROJECTED residuals (the P-space
+  // sums of the "project" form on the 16-bit pipe)
+  {
+    float n2 = 0.f;
+    SV_HIP(ctx->s_qnorm.reserve((size_t)K * sizeof(float)));
+    SV_TRY(sv_launch_row_sumsq(ctx, ctx->vocab.as<float>(), K, D, ctx->s_qnorm.as<float>()));
+    SV_TRY(sv_row_norm_max(ctx, ctx->s_qnorm.as<float>(), K, &n2));
+    ctx->vocab_norm_max = std::sqrt(n2 > 0.f ? n2 : 0.f);
+  }
   return sv_finish(ctx);
 }
 
@@ -614,10 +624,22 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
       SV_TRY(sv_launch_gemm_f16x3_grouped(ctx, ctx->s_xh1.as<uint16_t>(), ctx->s_xh2.as<uint16_t>(), ctx->pca_w1.as<uint16_t>(),
                                           ctx->pca_w2.as<uint16_t>(), (int)rows_pad, ctx->P, D, K, ctx->s_tilegrp.as<int32_t>(),
                                           1.f / (xscale * ctx->pca_w_scale), ctx->s_pz.as<float>()));
+      // |z_tp| = |W_k[p, :] . r_t| <= sqrt(D) max|W| (1 + max ||C_k||): a power-of-two scale that keeps z * zscale inside fp16
+      // (the elementwise bound of W is the one pca_set left in pca_w_scale; typical |z| sits ~2^-7 below the bound, still
+      // 2^10 above the point where the low half of the split would go subnormal)
+      float zscale = 0.f;
+      if (ctx->pca_w_scale > 0.f) {
+        const float zb = std::sqrt((float)D) * (16384.f / ctx->pca_w_scale) * (1.f + ctx->vocab_norm_max);
+        if (std::isfinite(zb) && zb > 0.f) {
+          int e;
+          frexpf(zb, &e);
+          zscale = ldexpf(1.f, 14 - e);
+        }
+      }
       SV_TRY(sv_launch_project_aggregate(ctx, ctx->s_pz.as<float>(), ctx->pca_cproj.as<float>(), bn, ctx->s_gscale.as<float>(),
                                          ctx->s_colmask.as<uint64_t>(), ctx->s_laboff.as<int32_t>(), ctx->s_rowbase.as<int32_t>(),
                                          ctx->s_segoff.as<int32_t>(), B, N, K, ctx->P, SC, S_max, ctx->pca_scale.as<float>(),
-                                         (float*)d_y));
+                                         (float*)d_y, zscale));
       sc.count(2);
       if (l2norm) {
         SV_TRY(sv_launch_normalize_rows(ctx, (const float*)d_y, S_tot, ctx->P, (float*)d_y));

@@ -153,6 +153,7 @@ struct SvOptions {
                           //    outstanding memory operation at every step (verification of its counted waits: same bits)
   int small_plan = 1;     // <= 128 queries (one query image per pass): one filter level behind an exact sample of 2048..4096
                           // rows (see segvlad_search); 0 = the deep plan of the batches
+  int pj_f16 = 1;         // P-space aggregation: the tile sums on the 16-bit matrix pipe (0: fp32 MFMA, as before round 4)
   int pj_nw = 8;          // waves (32-column slices) per workgroup of the P-space aggregation: 8, or 4 (three workgroups per
                           // CU instead of one: measured SLOWER, 3.72 vs 3.40 ms for the PCA stage of 200 images)
   int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
@@ -209,6 +210,7 @@ struct segvlad_ctx {
   // vocabulary
   int K = 0, D = 0, Kpad = 0;
   float vocab_maxabs = 0.f;   // max |C_kd| (set_vocab): scale of the residual planes of the "project" form
+  float vocab_norm_max = 0.f; // max_k ||C_k||_2 (set_vocab): bound of the projected residuals (16-bit P-space sums)
   // PCA model
   int P = 0, KD = 0, whiten = 0;
   float pca_w_scale = 0.f, pca_mean_maxabs = 0.f;
@@ -400,7 +402,7 @@ int sv_launch_group_plan(segvlad_ctx* ctx, const int32_t* lab_off, int B, int K,
 int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* mean, int P, int64_t KD, float* wmu /*[P] = W mean*/);
 int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* wmu, const float* block_norms, const float* gscale,
                                 const uint64_t* colmask, const int32_t* lab_off, const int32_t* rowbase, const int32_t* seg_off_dev,
-                                int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y);
+                                int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y, float zscale);
 int sv_launch_to_f16(segvlad_ctx* ctx, const float* X, int64_t n_elems, float scale, uint16_t* out);
 // single-image searches: the query plane and its scales without a host round trip (scales_dev[0] = query scale,
 // [1] = 1 / (query scale x db_scale)); ctx->f16_scale_dev != null makes the filter kernel read [1] instead of its argument

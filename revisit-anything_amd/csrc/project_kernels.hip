@@ -112,7 +112,14 @@ int sv_launch_project_consts(segvlad_ctx* ctx, const float* comps, const float* 
 // where its column-mask bit is set, else 0, B = z.  The mean term W mu and the whitening scale are applied in the epilogue.
 constexpr int PJ_T = 32;   // rows per tile (an image has at most K + N / 32 tiles: `maxt`)
 
-template <int NW>   // waves per workgroup = 32-column slices: 8 (256 columns, 82 KiB of LDS: one workgroup per CU; default) or
+// F16 (round 4): the sums of a tile on the 16-bit matrix pipe.  Inside a tile (one cluster) the weights factor out,
+// y_s += a_sk * (sum_t m_st z_t): the inner sum has 0 / 1 coefficients -- exact in fp16 -- and z * zscale = h + l (|rest| <= 2^-22
+// |z|; zscale a power of two from a rigorous bound on |z|), so it is two v_mfma_f32_32x32x16_f16 per 16 rows and segment half
+// (A = the mask bits as 1.0 / 0.0, B = l, then h) instead of eight v_mfma_f32_32x32x2f32 at a sixteenth of the rate; the weight
+// is applied to the tile's 32 x 32 sums (one fma per accumulator element, the 16 weights of a lane's rows as four 16-byte reads
+// of a [cluster][segment] table).  The mask fragments are the same for the workgroup's eight waves: 256 threads build them once
+// per tile (from the tokens' mask words, while the tile is fetched) and every wave reads its 16 bytes per (k-step, half).
+template <int NW, bool F16 = false>   // waves per workgroup = 32-column slices: 8 (256 columns, 82 KiB of LDS: one workgroup per CU; default) or
                     // 4 (128 columns, 49 KiB: three per CU; option pj_nw = 4 -- measured slower: every workgroup repeats the
                     // per-tile mask loads, barriers and the weight table)
 __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float* __restrict__ Z, const float* __restrict__ wmu,
@@ -122,10 +129,12 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
                                                                 const int32_t* __restrict__ rowbase,
                                                                 const int32_t* __restrict__ seg_off, int N, int K, int P, int SC,
                                                                 int maxt, const float* __restrict__ col_scale,
-                                                                float* __restrict__ Y) {
+                                                                float* __restrict__ Y, float zscale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  static_assert(!F16 || NW == 8, "16-bit tile sums: the 8-wave workgroup");
   const int KS = K + 1 + (K & 1);                                  // row stride of ag, always odd: conflict-free column reads
-  float* ag = reinterpret_cast<float*>(smem);                      // [64][KS]  a_sk = g_s / ||V_sk||   (0 for empty blocks)
+  float* ag = reinterpret_cast<float*>(smem);                      // [64][KS]  a_sk = g_s / ||V_sk||   (0 for empty blocks); F16: [K][64]
   constexpr int NC = 32 * NW, NT_ = 64 * NW, C4W = NC / 4;         // columns, threads, float4 per staged row
   float* zt = ag + 64 * KS;                                        // [2][PJ_T][NC] staged rows
   uint64_t* mk = reinterpret_cast<uint64_t*>(zt + 2 * PJ_T * NC);  // [2][PJ_T] column masks of the staged tokens
@@ -133,6 +142,8 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
   int32_t* tl_j = tl_k + maxt;                                     // [maxt] first token (label-grouped order) of tile t
   int32_t* tl_z = tl_j + maxt;                                     // [maxt] first row of Z of tile t
   int32_t* tl_n = tl_z + maxt;                                     // [maxt] rows in tile t
+  // F16: [2 buffers][k-step][segment half][64 lanes] 16-byte mask fragments, behind the lists (+ K + 1 tile offsets)
+  uint4* af = reinterpret_cast<uint4*>((reinterpret_cast<uintptr_t>(tl_n + maxt + K + 1) + 15) & ~(uintptr_t)15);
   __shared__ int s_tiles;
   const int b = blockIdx.y, p0 = blockIdx.x * NC;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -184,7 +195,8 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
         const float nrm = bn[(size_t)(s0 + 64 * sc + s) * K + k];
         a = nrm > 1e-12f ? gscale[s0 + 64 * sc + s] / nrm : 0.f;   // an all-zero block contributes nothing (reference: 0 / 1e-12)
       }
-      ag[s * KS + k] = a;
+      if (F16) ag[k * 64 + s] = a;
+      else ag[s * KS + k] = a;
     }
     f32x16 acc[2];
 #pragma unroll
@@ -198,6 +210,7 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
     // and the loop is unrolled by two (an array indexed by t & 1 would go to scratch memory).
     float4 va[4], vb[4];
     uint64_t ma = 0ull, mb = 0ull;
+    uint4 fa = make_uint4(0u, 0u, 0u, 0u), fb = make_uint4(0u, 0u, 0u, 0u);   // F16: this thread's mask fragment of the tile in flight
 #define SV_PJ_FETCH(V, M, t_)                                                                                   \
     do {                                                                                                        \
       const int nt_ = tl_n[t_];                                                                                 \
@@ -209,6 +222,23 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
       }                                                                                                         \
       if (tid < PJ_T) M = tid < nt_ ? colmask[((size_t)b * N + tl_j[t_] + tid) * SC + sc] : 0ull;               \
     } while (0)
+    // F16: thread (k-step, half, lane) = (tid >> 7, (tid >> 6) & 1, tid & 63) packs the mask bits of its lane's 8 rows
+    // (16 ks + 8 kk + e) for segment 32 half + i as fp16 1.0 / 0.0
+#define SV_PJ_FETCH_F(Fv, t_)                                                                                   \
+    do {                                                                                                        \
+      if (F16 && tid < 256) {                                                                                   \
+        const int nt_ = tl_n[t_], ks_ = tid >> 7, hf_ = (tid >> 6) & 1, ln_ = tid & 63;                         \
+        const int sh_ = 32 * hf_ + (ln_ & 31), j0_ = 16 * ks_ + 8 * (ln_ >> 5);                                 \
+        const uint64_t* mrow_ = colmask + ((size_t)b * N + tl_j[t_] + j0_) * SC + sc;                           \
+        uint32_t d_[4];                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+          const uint64_t m0_ = (j0_ + 2 * q < nt_) ? mrow_[(size_t)(2 * q) * SC] : 0ull;                        \
+          const uint64_t m1_ = (j0_ + 2 * q + 1 < nt_) ? mrow_[(size_t)(2 * q + 1) * SC] : 0ull;                \
+          d_[q] = (((m0_ >> sh_) & 1ull) ? 0x3C00u : 0u) | (((m1_ >> sh_) & 1ull) ? 0x3C000000u : 0u);          \
+        }                                                                                                       \
+        Fv = make_uint4(d_[0], d_[1], d_[2], d_[3]);                                                            \
+      }                                                                                                         \
+    } while (0)
 #define SV_PJ_STASH(V, M, buf_)                                                                                 \
     do {                                                                                                        \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
@@ -216,6 +246,10 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
         *reinterpret_cast<float4*>(zt + (size_t)(buf_) * PJ_T * NC + row * NC + 4 * c4) = V[q];                 \
       }                                                                                                         \
       if (tid < PJ_T) mk[(buf_) * PJ_T + tid] = M;                                                              \
+    } while (0)
+#define SV_PJ_STASH_F(Fv, buf_)                                                                                 \
+    do {                                                                                                        \
+      if (F16 && tid < 256) af[(buf_) * 256 + tid] = Fv;                                                        \
     } while (0)
 #define SV_PJ_MUL(t_)                                                                                           \
     do {                                                                                                        \
@@ -235,26 +269,106 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
         }                                                                                                       \
       }                                                                                                         \
     } while (0)
+#define SV_PJ_MUL16(t_)                                                                                         \
+    do {                                                                                                        \
+      const int cur_ = (t_) & 1, k_ = tl_k[t_], nt_ = tl_n[t_];                                                 \
+      const float* ztc = zt + (size_t)cur_ * PJ_T * NC + 32 * w + i + (size_t)(8 * kk) * NC;                    \
+      const uint4* afc = af + cur_ * 256 + l;                                                                   \
+      f32x16 ta0, ta1;                                                                                          \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                        \
+        if (ks == 1 && nt_ <= 16) break;                                                                        \
+        f16x8 hh, ll;                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                         \
+          const float v = ztc[(size_t)(16 * ks + e) * NC] * zscale;                                             \
+          hh[e] = (_Float16)v;                                                                                  \
+          ll[e] = (_Float16)(v - (float)hh[e]);                                                                 \
+        }                                                                                                       \
+        const uint4 a0u = afc[(2 * ks) * 64];                                                                   \
+        const f16x8 a0 = __builtin_bit_cast(f16x8, a0u);                                                        \
+        if (ks == 0) {                                                                                          \
+          f32x16 zero_;                                                                                         \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) zero_[r] = 0.f;                                        \
+          ta0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, ll, zero_, 0, 0, 0);                                 \
+        } else {                                                                                                \
+          ta0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, ll, ta0, 0, 0, 0);                                   \
+        }                                                                                                       \
+        ta0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, hh, ta0, 0, 0, 0);                                     \
+        if (two) {                                                                                              \
+          const uint4 a1u = afc[(2 * ks + 1) * 64];                                                             \
+          const f16x8 a1 = __builtin_bit_cast(f16x8, a1u);                                                      \
+          if (ks == 0) {                                                                                        \
+            f32x16 zero_;                                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) zero_[r] = 0.f;                                      \
+            ta1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, ll, zero_, 0, 0, 0);                               \
+          } else {                                                                                              \
+            ta1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, ll, ta1, 0, 0, 0);                                 \
+          }                                                                                                     \
+          ta1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, hh, ta1, 0, 0, 0);                                   \
+        }                                                                                                       \
+      }                                                                                                         \
+      /* the weights of this lane's 16 rows (r = 4 q + r3 <-> segment 8 q + 4 kk + r3): four 16-byte reads per half */ \
+      const float* agk = ag + k_ * 64 + 4 * kk;                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+        const float4 w0 = *reinterpret_cast<const float4*>(agk + 8 * q);                                        \
+        acc[0][4 * q + 0] = fmaf(w0.x, ta0[4 * q + 0], acc[0][4 * q + 0]);                                      \
+        acc[0][4 * q + 1] = fmaf(w0.y, ta0[4 * q + 1], acc[0][4 * q + 1]);                                      \
+        acc[0][4 * q + 2] = fmaf(w0.z, ta0[4 * q + 2], acc[0][4 * q + 2]);                                      \
+        acc[0][4 * q + 3] = fmaf(w0.w, ta0[4 * q + 3], acc[0][4 * q + 3]);                                      \
+        if (two) {                                                                                              \
+          const float4 w1 = *reinterpret_cast<const float4*>(agk + 32 + 8 * q);                                 \
+          acc[1][4 * q + 0] = fmaf(w1.x, ta1[4 * q + 0], acc[1][4 * q + 0]);                                    \
+          acc[1][4 * q + 1] = fmaf(w1.y, ta1[4 * q + 1], acc[1][4 * q + 1]);                                    \
+          acc[1][4 * q + 2] = fmaf(w1.z, ta1[4 * q + 2], acc[1][4 * q + 2]);                                    \
+          acc[1][4 * q + 3] = fmaf(w1.w, ta1[4 * q + 3], acc[1][4 * q + 3]);                                    \
+        }                                                                                                       \
+      }                                                                                                         \
+    } while (0)
+#define SV_PJ_MULX(t_)                                                                                          \
+    do {                                                                                                        \
+      if constexpr (F16) SV_PJ_MUL16(t_);                                                                       \
+      else SV_PJ_MUL(t_);                                                                                       \
+    } while (0)
     // set A carries the odd tiles' predecessors: tile 0 -> LDS directly, then A = tile 1, B = tile 2, A = tile 3, ...
     if (tiles > 0) {
       SV_PJ_FETCH(va, ma, 0);
+      SV_PJ_FETCH_F(fa, 0);
       SV_PJ_STASH(va, ma, 0);
+      SV_PJ_STASH_F(fa, 0);
     }
-    if (tiles > 1) SV_PJ_FETCH(va, ma, 1);
+    if (tiles > 1) {
+      SV_PJ_FETCH(va, ma, 1);
+      SV_PJ_FETCH_F(fa, 1);
+    }
     __syncthreads();   // ag and tile 0 visible
     for (int t = 0; t < tiles; t += 2) {
       // even tile t: tile t+1 waits in A, tile t+2 is requested into B
-      if (t + 2 < tiles) SV_PJ_FETCH(vb, mb, t + 2);
-      SV_PJ_MUL(t);
-      if (t + 1 < tiles) SV_PJ_STASH(va, ma, 1);   // (the readers of that buffer -- tile t-1 -- passed the previous barrier)
+      if (t + 2 < tiles) {
+        SV_PJ_FETCH(vb, mb, t + 2);
+        SV_PJ_FETCH_F(fb, t + 2);
+      }
+      SV_PJ_MULX(t);
+      if (t + 1 < tiles) {   // (the readers of that buffer -- tile t-1 -- passed the previous barrier)
+        SV_PJ_STASH(va, ma, 1);
+        SV_PJ_STASH_F(fa, 1);
+      }
       __syncthreads();
       if (t + 1 >= tiles) break;
       // odd tile t+1: tile t+2 waits in B, tile t+3 is requested into A
-      if (t + 3 < tiles) SV_PJ_FETCH(va, ma, t + 3);
-      SV_PJ_MUL(t + 1);
-      if (t + 2 < tiles) SV_PJ_STASH(vb, mb, 0);
+      if (t + 3 < tiles) {
+        SV_PJ_FETCH(va, ma, t + 3);
+        SV_PJ_FETCH_F(fa, t + 3);
+      }
+      SV_PJ_MULX(t + 1);
+      if (t + 2 < tiles) {
+        SV_PJ_STASH(vb, mb, 0);
+        SV_PJ_STASH_F(fb, 0);
+      }
       __syncthreads();
     }
+#undef SV_PJ_MULX
+#undef SV_PJ_MUL16
+#undef SV_PJ_STASH_F
+#undef SV_PJ_FETCH_F
 #undef SV_PJ_MUL
 #undef SV_PJ_STASH
 #undef SV_PJ_FETCH
@@ -266,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int s = 32 * mt + pj_frag_row(r, kk);
-          if (s < Sc) Y[(size_t)(s0 + 64 * sc + s) * P + pcol] = (acc[mt][r] - mu) * cs;
+          if (s < Sc) Y[(size_t)(s0 + 64 * sc + s) * P + pcol] = ((F16 ? acc[mt][r] * (1.f / zscale) : acc[mt][r]) - mu) * cs;
         }
       }
     }
@@ -275,25 +389,31 @@ __global__ __launch_bounds__(64 * NW) void project_aggregate_kernel(const float*
 
 int sv_launch_project_aggregate(segvlad_ctx* ctx, const float* Z, const float* wmu, const float* block_norms, const float* gscale,
                                 const uint64_t* colmask, const int32_t* lab_off, const int32_t* rowbase, const int32_t* seg_off_dev,
-                                int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y) {
+                                int B, int N, int K, int P, int SC, int S_max, const float* col_scale, float* Y, float zscale) {
   if (B <= 0 || S_max <= 0) return SEGVLAD_OK;
   if (P % 4) return ctx->fail(SEGVLAD_ERR_ARG, "project_aggregate: P=%d must be a multiple of 4", P);
   const int maxt = K + (N + PJ_T - 1) / PJ_T;   // every cluster may end in a partial tile
   const int nw = ctx->opt.pj_nw == 4 ? 4 : 8;
   if (K > 64 * nw) return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d clusters need %d threads", K, K);
+  // zscale > 0: the tile sums on the 16-bit pipe (8-wave workgroups; + the mask-fragment image: 2 x 4 KiB, 16-byte aligned)
+  const bool f16 = zscale > 0.f && nw == 8 && ctx->opt.pj_f16 != 0;
   const size_t lds = (size_t)64 * (K + 1 + (K & 1)) * 4 + (size_t)2 * PJ_T * 32 * nw * 4 + (size_t)2 * PJ_T * 8 + (size_t)4 * maxt * 4 +
-                     (size_t)(K + 1) * 4;
+                     (size_t)(K + 1) * 4 + (f16 ? 16 + 2 * 256 * 16 : 0);
   if (lds > 160 * 1024)
     return ctx->fail(SEGVLAD_ERR_LIMIT, "project_aggregate: K=%d, N=%d need %zu B of LDS", K, N, lds);
-  const void* fn = nw == 8 ? reinterpret_cast<const void*>(project_aggregate_kernel<8>) : reinterpret_cast<const void*>(project_aggregate_kernel<4>);
+  const void* fn = f16 ? reinterpret_cast<const void*>(project_aggregate_kernel<8, true>)
+                       : nw == 8 ? reinterpret_cast<const void*>(project_aggregate_kernel<8>) : reinterpret_cast<const void*>(project_aggregate_kernel<4>);
   if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(fn, (size_t)lds));
   const dim3 grid((P + 32 * nw - 1) / (32 * nw), B), block(64 * nw);
-  if (nw == 8)
+  if (f16)
+    hipLaunchKernelGGL((project_aggregate_kernel<8, true>), grid, block, lds, ctx->stream, Z, wmu, block_norms, gscale, colmask, lab_off,
+                       rowbase, seg_off_dev, N, K, P, SC, maxt, col_scale, Y, zscale);
+  else if (nw == 8)
     hipLaunchKernelGGL(project_aggregate_kernel<8>, grid, block, lds, ctx->stream, Z, wmu, block_norms, gscale, colmask, lab_off, rowbase,
-                       seg_off_dev, N, K, P, SC, maxt, col_scale, Y);
+                       seg_off_dev, N, K, P, SC, maxt, col_scale, Y, 0.f);
   else
     hipLaunchKernelGGL(project_aggregate_kernel<4>, grid, block, lds, ctx->stream, Z, wmu, block_norms, gscale, colmask, lab_off, rowbase,
-                       seg_off_dev, N, K, P, SC, maxt, col_scale, Y);
+                       seg_off_dev, N, K, P, SC, maxt, col_scale, Y, 0.f);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

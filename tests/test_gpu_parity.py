@@ -859,6 +859,18 @@ def test_block_norms_from_the_gram_matrix_equal_the_block_sums(eng):
         eng.set_option("pca_path", "auto")
     assert np.abs(ys["1"] - ys["0"]).max() <= 2e-6 * np.abs(ref).max()
     assert not np.array_equal(ys["1"], ys["0"])   # (the Gram kernel did run)
+    # ... and the P-space aggregation's tile sums on the 16-bit pipe (0 / 1 coverage x a two-term split of the projected
+    # residuals, the weights applied to the tile sums) against the fp32-MFMA form (pj_f16 = 0)
+    eng.set_option("pca_path", "project")
+    try:
+        eng.set_option("pj_f16", "0")
+        y32 = eng.seg_vlad_pca(tk, bits, offs, adj, l2norm=False)["out"].cpu().numpy()
+    finally:
+        eng.set_option("pj_f16", "1")
+        eng.set_option("pca_path", "auto")
+    assert np.abs(y32 - ref).max() <= 3e-5 * np.abs(ref).max()
+    assert np.abs(y32 - ys["1"]).max() <= 2e-6 * np.abs(ref).max()
+    assert not np.array_equal(y32, ys["1"])
 
 
 # ------------------------------------------------------------------------------------------------
