@@ -221,6 +221,10 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *                                                      SvOptions); never change a result
  *                                                      (tests/test_gpu_filter_variants.py holds every one to the bits of
  *                                                      the all-fp32 filter)
+ *        "tnk_gram", "pj_f16"   1 | 0                  fused VLAD -> PCA, "project" form: block norms from the Gram matrix of a
+ *                                                      task's token residuals / the P-space tile sums, both on the 16-bit
+ *                                                      matrix pipe (round 4) | the fp32-MFMA kernels of rounds 2-3; the two
+ *                                                      agree to ~1e-6 relative (tests/test_gpu_parity.py)
  *        "guard_undersize" "<buffer>:<bytes>"          tests of the guard mode only (see below)
  *
  *      Environment, read ONCE by segvlad_create: SEGVLAD_GUARD=1 creates a GUARDED context (development / test runs):
