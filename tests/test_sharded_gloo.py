@@ -198,3 +198,22 @@ def test_native_comm_surface_equals_single_index(tmp_path, world):
         assert np.array_equal(z["ids"], ids) and np.array_equal(z["d2"], d2)
         for i, p in enumerate(preds):
             assert z["pred"][i][:len(p)].tolist() == [int(x) for x in p]
+
+
+def test_single_index_vote_depth_only_equals_search_depth_retrieve():
+    """World size 1, no process group: a retrieve that searches only as deep as the vote reads (k_vote of k_search columns)
+    returns the same kept neighbours, similarities, predictions and scores -- the host logic of sharded.py on the checker
+    backend (the GPU twin: tests/test_gpu_sharded.py)."""
+    sys.path.insert(0, ROOT)
+    from revisit_anything_amd.sharded import ShardedSegmentIndex
+
+    R, img, Q, tau, off = make_problem()
+    idx = ShardedSegmentIndex(OracleBackend(), rank=0, world=1)
+    idx.build(R, img)
+    full = idx.retrieve(torch.from_numpy(Q), off, k_search=20, k_vote=10, n_top=3, want_scores=True)
+    lean = idx.retrieve(torch.from_numpy(Q), off, k_search=20, k_vote=10, n_top=3, want_scores=True, vote_depth_only=True)
+    for a, b in zip(full, lean):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    d2, ids = idx.search(torch.from_numpy(Q), 20)     # (the pass-through of a single index: the backend's result as it is)
+    rd2, rid = OracleBackend.search(idx.be, Q, 20)
+    assert torch.equal(d2, rd2) and torch.equal(ids, rid)
