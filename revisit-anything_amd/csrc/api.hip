@@ -126,6 +126,23 @@ hipError_t DevBuf::reserve_guarded(size_t bytes) {
   return e;
 }
 
+int sv_fork_side(segvlad_ctx* ctx) {
+  if (!ctx->side) {
+    SV_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    SV_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    SV_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  SV_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  SV_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  return SEGVLAD_OK;
+}
+
+int sv_join_side(segvlad_ctx* ctx) {
+  SV_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+  SV_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return SEGVLAD_OK;
+}
+
 int sv_guard_check(segvlad_ctx* ctx) {
   if (!ctx->guard) return SEGVLAD_OK;
   SV_HIP(hipDeviceSynchronize());
@@ -263,6 +280,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "f16_buf")) return as_int(&o.f16_buf);
   if (!strcmp(key, "f16_dsplit")) return as_int(&o.f16_dsplit);
   if (!strcmp(key, "tnk_gram")) return as_int(&o.tnk_gram);
+  if (!strcmp(key, "tnk_fork")) return as_int(&o.tnk_fork);
   if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);
   if (!strcmp(key, "x3_gm")) return as_int(&o.x3_gm);
   if (!strcmp(key, "search_stats")) return as_int(&o.search_stats);
@@ -307,6 +325,12 @@ int segvlad_destroy(segvlad_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   sv_comm_release(ctx);
+  if (ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipStreamDestroy(ctx->side);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
+  }
   ctx->for_each_buf([](DevBuf& b) { b.release(); });
   for (auto& kv : ctx->timers)
     for (hipEvent_t e : kv.second.ev)

@@ -137,6 +137,7 @@ struct SvOptions {
                           // batch kernel), 1 = both, 0 = neither
   int tnk_gram = 1;       // fused VLAD -> PCA, project form: block norms of tasks with <= 64 tokens from their Gram matrix on the
                           // 16-bit matrix pipe (gram_norms_kernel); 0 = the fp32 block sums for every task
+  int tnk_fork = 1;       // the two-tile Gram kernel on the context's side stream, beside the one-tile kernel (0: one after the other)
   int f16_dsplit = 0;     // batch kernel: pieces per phase whose DMA is issued from the MFMA segment instead of the load segment; -1: four of a phase's fragment reads issued from the previous MFMA segment; -2: a load segment's DMAs ahead of its fragment reads (A/B)
   int f16_small_mf = 0;   // 1: the batch filter's small (non-persistent) levels on the 16 x 16 x 32 shape + wave-private epilogue (A/B)
   int f16_pp = -1;        // main batch kernel: 0 = plain loop instead of the ping-pong loop (A/B)
@@ -200,6 +201,10 @@ struct SvSearchStats {
 struct segvlad_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // a second stream of the context's own, for kernels that share a launch slot with another one of the same call: forked off
+  // `stream` behind an event and joined back before anything else is enqueued (sv_fork_side / sv_join_side); created on first use
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   char err[512] = {0};
   bool profiling = false;
   bool scope_mute = false;   // set while a redo / fallback pass runs: its inner stages are part of "knn_redo" / "knn_fallback" only
@@ -290,6 +295,8 @@ int sv_out(segvlad_ctx* ctx, void* p, size_t bytes, void** dev);
 int sv_finish(segvlad_ctx* ctx);
 // guard mode: SEGVLAD_ERR_STATE if any fence of the context's buffers has been written (synchronises the device)
 int sv_guard_check(segvlad_ctx* ctx);
+int sv_fork_side(segvlad_ctx* ctx);   // side stream waits for everything enqueued on `stream` so far
+int sv_join_side(segvlad_ctx* ctx);   // `stream` waits for everything enqueued on the side stream so far
 void sv_begin(segvlad_ctx* ctx);
 
 struct StageScope {

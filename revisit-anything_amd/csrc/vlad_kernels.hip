@@ -1546,19 +1546,24 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
   const bool gram = ctx->opt.tnk_gram != 0 && (D % 32) == 0;
   const int skip_le = gram ? 64 : -1;
   if (gram) {
-    for (int T = 1; T <= 2; ++T) {
-      if (T == 2 && N <= 32) break;
+    // the two-tile tasks are few (6 % of the tokens at 24 per cluster): their launch is one task's latency with most of the chip
+    // idle -- on the context's side stream it runs beside the one-tile launch instead of in front of it (tnk_fork)
+    const bool fork = N > 32 && ctx->opt.tnk_fork != 0;
+    if (fork) SV_TRY(sv_fork_side(ctx));
+    for (int T = 2; T >= 1; --T) {
+      if (T == 2 && N <= 32) continue;
       const int waves = T == 1 ? 4 : 2;
       const int qs = T == 1 ? 3 : 2;   // (three slots of 4 KiB, or two of 8)
       const size_t glds = (size_t)waves * ((size_t)qs * T * GNK_SLOT + (size_t)D * 4);
       auto gk = T == 1 ? gram_norms_kernel<1, 3> : gram_norms_kernel<2, 2>;
       if (glds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(gk), glds));
-      hipLaunchKernelGGL(gk, dim3((K + waves - 1) / waves, B), dim3(64 * waves), glds, ctx->stream, xt, ctx->s_rnsorted.as<float>(),
-                         ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres, seg_off_dev, N, D, K, SC,
-                         block_norms, xscale, reinterpret_cast<_Float16*>(h1), reinterpret_cast<_Float16*>(h2), rowbase,
-                         dummy_row < 0 ? 1 : 0);
+      hipLaunchKernelGGL(gk, dim3((K + waves - 1) / waves, B), dim3(64 * waves), glds, (T == 2 && fork) ? ctx->side : ctx->stream, xt,
+                         ctx->s_rnsorted.as<float>(), ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres,
+                         seg_off_dev, N, D, K, SC, block_norms, xscale, reinterpret_cast<_Float16*>(h1),
+                         reinterpret_cast<_Float16*>(h2), rowbase, dummy_row < 0 ? 1 : 0);
       SV_HIP(hipGetLastError());
     }
+    if (fork) SV_TRY(sv_join_side(ctx));
   }
   for (int big = 0; big < 2; ++big) {
     if (big && N < TNK_LCAP) break;
