@@ -290,6 +290,8 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "pj_nw")) return as_int(&o.pj_nw);
   if (!strcmp(key, "pj_f16")) return as_int(&o.pj_f16);
   if (!strcmp(key, "small_plan")) return as_int(&o.small_plan);
+  if (!strcmp(key, "refine_group")) return as_int(&o.refine_group);
+  if (!strcmp(key, "query_group")) return as_int(&o.query_group);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
   if (!strcmp(key, "debug_fail_search")) return as_int(&o.debug_fail_search);
   if (!strcmp(key, "guard_undersize")) {
@@ -315,8 +317,9 @@ int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n) {
   if (!ctx) return SEGVLAD_ERR_ARG;
   if (!stats_out || n < 0) return ctx->fail(SEGVLAD_ERR_ARG, "search_stats: bad arguments");
   const SvSearchStats& t = ctx->sstats;
-  const int64_t v[10] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo, t.n_refine2};
-  for (int j = 0; j < n && j < 10; ++j) stats_out[j] = v[j];
+  const int64_t v[12] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo, t.n_refine2,
+                         t.grp_groups, t.grp_union_sum};
+  for (int j = 0; j < n && j < 12; ++j) stats_out[j] = v[j];
   return SEGVLAD_OK;
 }
 
@@ -1159,7 +1162,20 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
                                        ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count,
                                        rovf_rows, rovf_count, ref_lim));
         sc.count();
-        if (last) {
+        if (last && m > 128) {
+          // batches: bands of 32 consecutive query rows (the segments of an image) over the union of their rows where they
+          // overlap, the rest row by row (refine_group_kernels.hip); same bits either way
+          int nl = 0;
+          SV_TRY(sv_launch_refine_grouped(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP,
+                                          k, out_d2, out_idx, &nl));
+          sc.count(nl);
+          if (ctx->opt.search_stats && nl > 1) {
+            int64_t ng = 0, gg = 0, us = 0;
+            SV_TRY(sv_refine_group_stats(ctx, m, &ng, &gg, &us));
+            ctx->sstats.grp_groups += gg;
+            ctx->sstats.grp_union_sum += us;
+          }
+        } else if (last) {
           SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP,
                                         k, out_d2, out_idx, nullptr, fail_rows, fail_count, &poison_dev));
           sc.count();

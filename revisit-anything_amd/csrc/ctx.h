@@ -157,6 +157,10 @@ struct SvOptions {
   int pj_f16 = 1;         // P-space aggregation: the tile sums on the 16-bit matrix pipe (0: fp32 MFMA, as before round 4)
   int pj_nw = 8;          // waves (32-column slices) per workgroup of the P-space aggregation: 8, or 4 (three workgroups per
                           // CU instead of one: measured SLOWER, 3.72 vs 3.40 ms for the PCA stage of 200 images)
+  int refine_group = 1;   // batch searches: the refine bands of 32 consecutive query rows evaluated as ONE exact fp32 GEMM over the union of
+                          // their rows when the bands overlap (refine_group_kernels.hip); 0 = every row on its own (rounds 1-4)
+  int query_group = 0;    // hint: the query rows of a batch come in runs of this many rows per query image (1 .. 64; else unknown):
+                          // the grouped refinement then takes an image's rows as one group instead of 32-row blocks
   int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
 };
 
@@ -196,6 +200,8 @@ struct SvSearchStats {
   int64_t n_queries = 0;
   int64_t n_redo = 0;           // query rows whose heuristic thresholds did not verify and that were redone rigorously
   int64_t n_refine2 = 0;        // query rows whose refine band exceeded the first-tier list (SV_RCAP) and took the second tier
+  int64_t grp_groups = 0;       // groups of 32 query rows whose bands were refined over the union of their rows (search_stats only)
+  int64_t grp_union_sum = 0;    // sum of those unions' lengths (search_stats only)
 };
 
 struct segvlad_ctx {
@@ -249,7 +255,7 @@ struct segvlad_ctx {
   X(s_ref_cnt) X(s_ref_id) X(s_qscale) X(s_qf16) X(s_xh1) X(s_xh2) X(s_desc) X(s_tokorder) X(s_laboff) X(s_rnsorted) X(s_ovf)     \
   X(s_fb_q) X(s_fb_d2) X(s_fb_idx) X(s_fb_rows) X(s_rd_rows) X(s_rd_q) X(s_rd_d2) X(s_rd_idx) X(s_rd_flags) X(s_rd_p1) X(s_rd_p2)  \
   X(s_sel_todo) X(s_vote_keys) X(s_pz) X(s_rowbase) X(s_tilegrp) X(s_bn) X(s_l0part) X(s_ref_lim) X(s_sh_d2) X(s_sh_idx)          \
-  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc)
+  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work)
 #define SV_DECL_BUF(n) DevBuf n;
   SV_PERSISTENT_BUFS(SV_DECL_BUF)
   SV_SCRATCH_BUFS(SV_DECL_BUF)
@@ -392,6 +398,13 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
                            const uint32_t* only_rows = nullptr, uint32_t* fail_rows = nullptr, uint32_t* fail_count = nullptr,
                            const uint32_t** poison_dev = nullptr);
 int sv_refine_small_repair(segvlad_ctx* ctx);
+// refine_group_kernels.hip: the same refinement for a batch, with the bands of 32 consecutive query rows evaluated over the
+// union of their rows where they overlap (option refine_group); *launches = kernels launched
+constexpr int SV_RG_UCAP = 2048;   // longest union a group may hold (longer: its rows keep the per-row kernels)
+int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
+                             const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
+                             int* launches);
+int sv_refine_group_stats(segvlad_ctx* ctx, int nq, int64_t* groups, int64_t* grouped, int64_t* union_sum);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);

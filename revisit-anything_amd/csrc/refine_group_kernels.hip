@@ -1,0 +1,357 @@
+// Grouped exact refinement of the kNN refine bands (round 5).
+//
+// The exact level of the search (faiss IndexFlatL2.search, place_rec_main.py:53-60) re-evaluates, per query ROW, its band
+// {d2~ <= A_k + 2 eps} (>= k rows, <= SV_RCAP) with the sequential fp32 chain.  The rows of a query batch are the segments
+// of query images, 50 consecutive rows per image, and the segments of an image share most of their neighbours (a place's
+// reference segments): on the bench's raw 98 304-d workload (BASELINE configs[1]) the 50 bands of an image, 10 500 list
+// slots, hold ~220 DISTINCT database rows; on the PCA'd 1 M-row index 1000-1500 of 13 500.  Read per row, those rows
+// crossed HBM / L2 once per slot: 827 GB per 200 query images on raw descriptors.
+//
+// Here G consecutive query rows form a group (G = option "query_group" when it is 1 .. 64 -- the caller's hint that the query
+// rows come in runs of G per image, so that groups coincide with images -- else 32):
+//   refine_union_kernel        sorted union of the group's band lists (LDS bitonic sort + unique); a group whose union
+//                              is not at most half of its list slots (nothing shared: random queries), or longer than
+//                              RG_UCAP, keeps the per-row kernels (its rows are flagged in `perrow`)
+//   refine_group_gemm_kernel   exact distances of ALL 32 x U pairs of a grouped group on v_mfma_f32_32x32x2_f32: per output
+//                              element the sequential chain acc = fma(q[k], r[k], acc), k = 0 .. d - 1, from acc = 0 --
+//                              bit for bit the chain of refine_exact_kernel and of the distance-matrix path
+//                              (gemm_kernels.hip, same instruction, same k order) -- then sv_d2 with the same norms.
+//                              A row outside a query's own band only adds an exact distance that cannot enter its top k
+//                              (the band contains the top k, ties included), so the result is the per-row kernels'.
+//   refine_group_select_kernel per query row: (distance, id) sort of its U keys, top k.
+// Workgroup of the GEMM: 4 waves, wave w owns 32 union rows (MT = 1 or 2 accumulator tiles of 32 x 32: groups of <= 32 / <= 64
+// query rows), the query rows are shared through LDS; operands staged k-major ([k][row], odd row stride) exactly like
+// gemm_kernels.hip; global loads run THREE k-tiles ahead in three named register stages (a step's loads carry no condition in
+// the steady-state loop: with one, the compiler waits for every outstanding load before it reuses a stage -- measured: 2 TB/s),
+// one barrier per k-tile.  d % 32 == 0.
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int RG_GMAX = 64;      // query rows per group, at most
+
+__device__ __forceinline__ uint32_t rg_f2key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float rg_key2f(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ int rg_frag_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
+
+template <class T, int NTH = 256>
+__device__ __forceinline__ void rg_bitonic(T* a, int n, int tid) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (n >> 1); t += NTH) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const T x = a[lo], y = a[hi];
+        if ((y < x) == up) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- union of a group's band lists ---------------------------------------------------------------------------------------
+constexpr int RG_UT = 1024;   // threads of the union kernel (the sort is its time)
+__global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __restrict__ ref_cnt, const uint32_t* __restrict__ ref_id,
+                                                           int rcap, int m, int G, int ucap, uint32_t* __restrict__ grp_cnt,
+                                                           uint32_t* __restrict__ grp_ids, uint32_t* __restrict__ perrow,
+                                                           uint32_t* __restrict__ work /* [0] = count, then items */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* buf = reinterpret_cast<uint32_t*>(smem);   // [pow2 >= G * rcap]
+  __shared__ uint32_t off[RG_GMAX + 1];
+  __shared__ uint32_t wtot[RG_UT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int q0 = b * G;
+  const int nrows = min(G, m - q0);
+  if (tid == 0) {
+    uint32_t s = 0;
+    for (int t = 0; t < G; ++t) {
+      off[t] = s;
+      uint32_t c = t < nrows ? ref_cnt[q0 + t] : 0u;
+      if (c > (uint32_t)rcap) c = 0u;   // (never: an overflowing band leaves 0 and takes the second tier)
+      s += c;
+    }
+    off[G] = s;
+  }
+  __syncthreads();
+  const int total = (int)off[G];
+  bool grouped = false;
+  int U = 0;
+  if (total > 0) {
+    int np2 = 64;
+    while (np2 < total) np2 <<= 1;
+    for (int t = w; t < nrows; t += RG_UT / 64) {
+      const int c = (int)(off[t + 1] - off[t]);
+      for (int j = l; j < c; j += 64) buf[off[t] + j] = ref_id[(size_t)(q0 + t) * rcap + j];
+    }
+    for (int j = total + tid; j < np2; j += RG_UT) buf[j] = 0xffffffffu;
+    rg_bitonic<uint32_t, RG_UT>(buf, np2, tid);
+    // unique, in order: positions from a ballot prefix per wave + the waves' totals
+    uint32_t base = 0;
+    for (int j0 = 0; j0 < total; j0 += RG_UT) {
+      const int j = j0 + tid;
+      const bool first = j < total && (j == 0 || buf[j] != buf[j - 1]);
+      const uint64_t mk = __builtin_amdgcn_ballot_w64(first);
+      if (l == 0) wtot[w] = (uint32_t)__popcll(mk);
+      __syncthreads();
+      uint32_t o = base, all = 0;
+      for (int x = 0; x < RG_UT / 64; ++x) {
+        if (x < w) o += wtot[x];
+        all += wtot[x];
+      }
+      const uint32_t pos = o + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+      if (first && pos < (uint32_t)ucap) grp_ids[(size_t)b * ucap + pos] = buf[j];
+      base += all;
+      __syncthreads();
+    }
+    U = (int)base;
+    grouped = U <= ucap && 2 * U <= total;
+  }
+  if (tid == 0) {
+    grp_cnt[b] = grouped ? (uint32_t)U : 0u;
+    if (grouped) {
+      // the GEMM's work items (group, 128-row tile of its union), DENSE: a 2-D grid (tile, group) with early exits puts every
+      // live workgroup on the XCDs its linear id selects -- tiles 0 and 1 of 16: two of the eight XCDs, measured 5x slower
+      const uint32_t nt = (uint32_t)(U + 127) >> 7;
+      const uint32_t at = atomicAdd(&work[0], nt);
+      for (uint32_t t = 0; t < nt; ++t) work[1 + at + t] = ((uint32_t)b << 5) | t;
+    }
+  }
+  if (tid < nrows) perrow[q0 + tid] = grouped ? 0u : 1u;
+}
+
+// ---- G query rows x the union's rows: exact fp32 distances as sortable keys -----------------------------------------------
+// Every row is fetched in pieces of RG_KS floats (512 B): one load instruction of a wave covers two rows x 512 contiguous
+// bytes.  A super-tile of RG_KS k travels in ONE register stage ((MT + 4) x 4 sixteen-byte loads per thread: 96 KiB per
+// workgroup in flight while the previous super-tile is multiplied out of LDS) and is parked in a single LDS buffer between two
+// barriers.  The loads are inline asm with an explicit wait: a compiler-visible load with a condition on it makes every LDS
+// access behind it wait for all of them.
+// LDS image: ROW-major, row stride RG_LDR = RG_KS + 4 floats, and inside every group of 8 k the even k first, then the odd:
+// [k0 k2 k4 k6 | k1 k3 k5 k7].  v_mfma_f32_32x32x2_f32 takes k = 2 s from lanes 0-31 and k = 2 s + 1 from lanes 32-63, so a
+// lane's operands of FOUR consecutive k-steps are one aligned 16-byte read (rows 16 apart share a bank group, which the
+// 16-lane service groups of a ds_read_b128 never hold together), and a loaded float4 goes out as two 8-byte writes.
+// (Measured on the way, 10 000 x 200-row bands of 98 304-d rows: k-major [k][row] tiles fed by ds_read_b32 -- one or two reads,
+//  a wait and one or two MFMAs per k-step, one wave per SIMD -- 63 ms with the matrix pipes 8 % busy: a chain of LDS latencies,
+//  half of the LDS cycles bank conflicts of the transposing 4-byte stores; 128-byte row pieces three tiles ahead: 32-40 ms.)
+typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
+typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
+#define RG_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+constexpr int RG_KS = 128;
+constexpr int RG_LDR = RG_KS + 4;
+
+template <int MT>
+__global__ __launch_bounds__(256) void refine_group_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d, int m,
+                                                                int G, const float* __restrict__ qn, const float* __restrict__ rn,
+                                                                const uint32_t* __restrict__ grp_cnt,
+                                                                const uint32_t* __restrict__ grp_ids, int ucap,
+                                                                uint64_t* __restrict__ keys, const uint32_t* __restrict__ work) {
+  constexpr int NR = 32 * MT + 128;   // rows of a super-tile: the group's query rows, then 128 union rows
+  constexpr int NLD = NR / 8;         // 16-byte loads per thread and super-tile (a wave's instruction: 2 rows x 512 B)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                        // [NR][RG_LDR]
+  uint32_t* ids = reinterpret_cast<uint32_t*>(tile + NR * RG_LDR);     // [128]
+  if (blockIdx.x >= work[0]) return;
+  const uint32_t item = work[1 + blockIdx.x];
+  const int b = (int)(item >> 5), c0 = (int)(item & 31u) * 128;
+  const int U = (int)grp_cnt[b];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int q0 = b * G;
+  const int q_end = min(q0 + G, m);
+  if (tid < 128) ids[tid] = grp_ids[(size_t)b * ucap + (c0 + tid < U ? c0 + tid : 0)];   // (columns beyond U: a valid row, never stored)
+  __syncthreads();
+  // load j of this thread: staged row rr = 8 j + 2 w + (l >> 5), floats 4 (l & 31) .. + 3 of the super-tile
+  const float* src[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int rr = 8 * j + 2 * w + kk;
+    src[j] = (rr < 32 * MT ? Q + (size_t)min(q0 + rr, q_end - 1) * d   // (rows beyond the group: never stored)
+                           : R + (size_t)ids[rr - 32 * MT] * d) + 4 * i;
+  }
+  rg_f32x4 v[NLD];
+  auto gload = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) RG_GLOAD(v[j], src[j] + (size_t)st * RG_KS);
+  };
+  // floats 4 i .. 4 i + 3 = k-group i >> 1, half i & 1: the even k to slots 2 (i & 1) .. + 1, the odd k four slots further
+  float* st_base = tile + (2 * w + kk) * RG_LDR + 8 * (i >> 1) + 2 * (i & 1);
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) asm volatile("" : "+v"(v[j]));   // (the values exist from HERE on: behind the caller's wait; the
+                                                                   //  re-packing moves below are not memory operations)
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      float* p = st_base + 8 * j * RG_LDR;
+      rg_f32x2 ev, od;
+      ev[0] = v[j][0];
+      ev[1] = v[j][2];
+      od[0] = v[j][1];
+      od[1] = v[j][3];
+      *reinterpret_cast<rg_f32x2*>(p) = ev;
+      *reinterpret_cast<rg_f32x2*>(p + 4) = od;
+    }
+  };
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float* a_frag = tile + i * RG_LDR + 4 * kk;                       // + 32 t rows, + 8 g floats
+  const float* b_frag = tile + (32 * MT + 32 * w + i) * RG_LDR + 4 * kk;
+  const int nst = d / RG_KS;
+  gload(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  sstore();
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    if (st + 1 < nst) gload(st + 1);   // in flight while this super-tile is multiplied
+    // 16 groups of 8 k; the fragments of group g + 1 are requested before the MFMAs of group g are issued
+    rg_f32x4 fa[2][MT], fb[2];
+    fb[0] = *reinterpret_cast<const rg_f32x4*>(b_frag);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[0][t] = *reinterpret_cast<const rg_f32x4*>(a_frag + 32 * t * RG_LDR);
+#pragma unroll
+    for (int g = 0; g < RG_KS / 8; ++g) {
+      if (g + 1 < RG_KS / 8) {
+        fb[(g + 1) & 1] = *reinterpret_cast<const rg_f32x4*>(b_frag + 8 * (g + 1));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa[(g + 1) & 1][t] = *reinterpret_cast<const rg_f32x4*>(a_frag + 32 * t * RG_LDR + 8 * (g + 1));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][t][u], fb[g & 1][u], acc[t], 0, 0, 0);
+    }
+    __syncthreads();   // every wave is done with the LDS image
+    if (st + 1 < nst) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      sstore();
+      __syncthreads();
+    }
+  }
+  const int col = c0 + 32 * w + i;
+  if (col < U) {
+    const uint32_t id = ids[32 * w + i];
+    const float r2 = rn[id];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + 32 * t + rg_frag_row(r, kk);
+        if (q < q_end) keys[(size_t)q * ucap + col] = ((uint64_t)rg_f2key(sv_d2(qn[q], r2, acc[t][r])) << 32) | id;
+      }
+  }
+}
+
+// ---- per query row: sort its U keys, top k ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refine_group_select_kernel(const uint32_t* __restrict__ grp_cnt, const uint64_t* __restrict__ keys,
+                                                                  int G, int ucap, int k, float* __restrict__ d2_out,
+                                                                  int64_t* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);   // [np2 <= ucap]
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int U = (int)grp_cnt[row / G];
+  if (U == 0) return;   // the per-row kernels' group
+  int np2 = 2;
+  while (np2 < U) np2 <<= 1;
+  for (int j = tid; j < np2; j += 256) a[j] = j < U ? keys[(size_t)row * ucap + j] : ~0ull;
+  rg_bitonic<uint64_t>(a, np2, tid);
+  for (int j = tid; j < k; j += 256) {
+    float dd = INFINITY;
+    int64_t id = -1;
+    if (j < U) {
+      dd = rg_key2f((uint32_t)(a[j] >> 32));
+      id = (int64_t)(uint32_t)a[j];
+    }
+    d2_out[row * k + j] = dd;
+    idx_out[row * k + j] = id;
+  }
+}
+
+}   // namespace
+
+static int rg_group_rows(const segvlad_ctx* ctx) {
+  const int h = ctx->opt.query_group;
+  return (h >= 1 && h <= RG_GMAX) ? h : 32;
+}
+
+// The refinement of a batch: groups whose bands overlap go through the union GEMM, the others (and every row of a search the
+// grouping does not apply to) through the per-row kernels.  Same outputs as sv_launch_refine_exact, bit for bit.
+int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
+                             const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
+                             int* launches) {
+  if (launches) *launches = 0;
+  if (nq <= 0) return SEGVLAD_OK;
+  const int ucap = SV_RG_UCAP;
+  const int G = rg_group_rows(ctx);
+  int lpad = 64;
+  while (lpad < G * rcap) lpad <<= 1;
+  const bool can = ctx->opt.refine_group != 0 && d % RG_KS == 0 && nq > 128 && (size_t)lpad * 4 <= 128 * 1024 && k <= ucap &&
+                   (reinterpret_cast<uintptr_t>(Q) & 15) == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0;
+  if (!can) {
+    if (launches) *launches = 1;
+    return sv_launch_refine_exact(ctx, Q, R, nq, d, qn, rn, ref_cnt, ref_id, rcap, k, d2_out, idx_out);
+  }
+  const int nb = (nq + G - 1) / G;
+  SV_HIP(ctx->s_grp_cnt.reserve((size_t)nb * 4));
+  SV_HIP(ctx->s_grp_ids.reserve((size_t)nb * ucap * 4));
+  SV_HIP(ctx->s_grp_rows.reserve((size_t)nq * 4));
+  SV_HIP(ctx->s_grp_keys.reserve((size_t)nq * ucap * 8));
+  uint32_t* gcnt = ctx->s_grp_cnt.as<uint32_t>();
+  uint32_t* gids = ctx->s_grp_ids.as<uint32_t>();
+  uint32_t* prow = ctx->s_grp_rows.as<uint32_t>();
+  uint64_t* gkeys = ctx->s_grp_keys.as<uint64_t>();
+  static_assert(SV_RG_UCAP / 128 <= 32, "a work item holds its tile in 5 bits");
+  const int max_items = nb * (ucap / 128);
+  SV_HIP(ctx->s_grp_work.reserve((size_t)(max_items + 1) * 4));
+  uint32_t* work = ctx->s_grp_work.as<uint32_t>();
+  SV_HIP(hipMemsetAsync(work, 0, 4, ctx->stream));
+  const size_t ulds = (size_t)lpad * 4;
+  if (ulds + 1024 > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_union_kernel), ulds));
+  hipLaunchKernelGGL(refine_union_kernel, dim3(nb), dim3(RG_UT), ulds, ctx->stream, ref_cnt, ref_id, rcap, nq, G, ucap, gcnt, gids, prow,
+                     work);
+  SV_HIP(hipGetLastError());
+  {
+    const int mt = G > 32 ? 2 : 1;
+    const size_t glds = (size_t)(32 * mt + 128) * RG_LDR * 4 + 128 * 4;
+    auto gk = mt == 2 ? refine_group_gemm_kernel<2> : refine_group_gemm_kernel<1>;
+    SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(gk), glds));
+    hipLaunchKernelGGL(gk, dim3(max_items), dim3(256), glds, ctx->stream, Q, R, d, nq, G, qn, rn, gcnt, gids, ucap, gkeys, work);
+    SV_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(refine_group_select_kernel, dim3(nq), dim3(256), (size_t)ucap * 8, ctx->stream, gcnt, gkeys, G, ucap, k, d2_out,
+                     idx_out);
+  SV_HIP(hipGetLastError());
+  if (launches) *launches = 4;
+  return sv_launch_refine_exact(ctx, Q, R, nq, d, qn, rn, ref_cnt, ref_id, rcap, k, d2_out, idx_out, prow);
+}
+
+// statistics for bench.py / the tests: groups of the last grouped refinement that took the union GEMM, and the sum of their
+// union lengths (synchronises)
+int sv_refine_group_stats(segvlad_ctx* ctx, int nq, int64_t* groups, int64_t* grouped, int64_t* union_sum) {
+  const int nb = (nq + rg_group_rows(ctx) - 1) / rg_group_rows(ctx);
+  std::vector<uint32_t> h(nb);
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  SV_HIP(hipMemcpy(h.data(), ctx->s_grp_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
+  int64_t g = 0, s = 0;
+  for (uint32_t c : h) {
+    if (c) ++g;
+    s += c;
+  }
+  *groups = nb;
+  *grouped = g;
+  *union_sum = s;
+  return SEGVLAD_OK;
+}

@@ -95,12 +95,23 @@ class SegVLADEngine:
         """segvlad_set_option: arithmetic / tuning switches of this context (see include/segvlad.h)."""
         self._check(self.lib.segvlad_set_option(self._h, str(key).encode(), str(value).encode()), f"set_option({key})")
 
+    def hint_query_groups(self, qseg_offsets) -> int:
+        """Tell the search how the query rows of the coming batches are grouped (option ``query_group``): when every query
+        image brings the same number of rows (<= 64) the exact refinement takes an image's rows as one group -- the bands of
+        an image's segments share most of their rows (csrc/refine_group_kernels.hip).  Never changes a result."""
+        runs = np.diff(np.asarray(qseg_offsets, dtype=np.int64))
+        hint = int(runs[0]) if runs.size and int(runs.min()) == int(runs.max()) and 1 <= int(runs[0]) <= 64 else 0
+        if hint != getattr(self, "_group_hint", None):
+            self.set_option("query_group", hint)
+            self._group_hint = hint
+        return hint
+
     def search_stats(self) -> dict:
         """Statistics of the last search(): levels, filter arithmetic, rows redone on the exact path, list occupancies."""
-        v = (C.c_int64 * 10)()
-        self._check(self.lib.segvlad_search_stats(self._h, v, 10), "search_stats")
+        v = (C.c_int64 * 12)()
+        self._check(self.lib.segvlad_search_stats(self._h, v, 12), "search_stats")
         names = ("levels", "filter", "n_fallback", "cand_max", "cand_sum", "refine_max", "refine_sum", "n_queries", "n_redo",
-                 "n_refine2")
+                 "n_refine2", "grp_groups", "grp_union_sum")
         d = dict(zip(names, [int(x) for x in v]))
         d["filter"] = {0: "none", 1: "f16", 2: "bf16x3", 3: "fp32"}[d["filter"]]
         return d

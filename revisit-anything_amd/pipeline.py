@@ -150,6 +150,7 @@ class SegVLADPipeline:
         """search k_search (place_rec_main.py:56) -> keep k_vote and 2-d^2 (:78-81) -> vote (:84).  vote_depth_only: search
         only as deep as the vote reads (the 200-wide lists are only pickled under save_results, :61-75): the same k_vote columns
         -- an exact search's first columns do not depend on its depth -- for a quarter of the refinement."""
+        self.eng.hint_query_groups(qseg_offsets)
         d2, idx = self.eng.search(qdesc, k_vote if vote_depth_only else k_search)
         sims, m = self.eng.sims_from_d2(d2, idx, k_vote)
         pred, sc = self.eng.vote(m, sims, qseg_offsets, n_top=n_top, mode=mode, want_scores=want_scores)

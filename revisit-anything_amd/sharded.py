@@ -162,6 +162,8 @@ class ShardedSegmentIndex:
         vote (func_vpr.py:212-213) is taken over the merged (global) similarities, so it needs no extra collective.
         vote_depth_only: a caller that does not keep the k_search-wide lists (place_rec_main.py:61-75 pickles them only under
         save_results) may have a single index search k_vote deep as well -- same first k_vote columns, same votes."""
+        if hasattr(self.be, "hint_query_groups"):   # an image's rows as one group of the exact refinement (same results)
+            self.be.hint_query_groups(qseg_offsets)
         if self.world > 1 or vote_depth_only:
             # The reference searches 200 and keeps 50 (place_rec_main.py:56,78).  The global top-50 is contained in the union
             # of the per-shard top-50 lists, and an exact search returns the same first 50 rows whatever depth it is asked
