@@ -188,8 +188,8 @@ int segvlad_profile_reset(segvlad_ctx* ctx);
 int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* launches_out);
 
 /* ---- switches (no reference counterpart: the reference has one arithmetic, fp32/fp64 torch + faiss).
- *      Read ONCE: the environment variables SEGVLAD_KNN_FILTER / SEGVLAD_KNN_FP32 / SEGVLAD_PCA_FP32 /
- *      SEGVLAD_F16_CFG / ... give a context its defaults at segvlad_create; this call overrides them.
+ *      Read ONCE: the environment variables SEGVLAD_KNN_FILTER / SEGVLAD_KNN_FP32 / SEGVLAD_PCA_FP32 / SEGVLAD_PCA_PATH /
+ *      SEGVLAD_KNN_HEURISTIC / SEGVLAD_SEARCH_STATS give a context its defaults at segvlad_create; this call overrides them.
  *      No kNN switch changes a result (every filter is followed by the exact fp32 refinement: tests assert
  *      bit-equality); the PCA variants are all fp32-class and agree to ~1e-5 relative (tests hold each to the same
  *      oracle tolerance), not bit for bit.
@@ -213,19 +213,17 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *                                                      level behind an exact sample of 2048..4096 rows, a workgroup per
  *                                                      list in the selects, refinement lists shared by workgroups, the
  *                                                      query scale left on the device | the plan of the batches
- *        "f16_cfg", "f16_gm", "x3_tile", "x3_gm", "agg_kpb", "assign_narrow", "debug_search"   integers, tuning
- *        "f16_mf", "f16_epi", "f16_walk", "f16_pp", "f16_deep_cfg", "f16_buf", "f16_dsplit", "f16_small_mf"
- *                                                      integers, A/B switches of the fp16 filter kernels (MFMA shape,
- *                                                      epilogue, tile walk, loop form, deep-row geometry, DMA form,
- *                                                      placement of the DMA / fragment reads in a phase: csrc/ctx.h
- *                                                      SvOptions); never change a result
- *                                                      (tests/test_gpu_filter_variants.py holds every one to the bits of
- *                                                      the all-fp32 filter)
- *        "tnk_gram", "pj_f16"   1 | 0                  fused VLAD -> PCA, "project" form: block norms from the Gram matrix of a
- *                                                      task's token residuals / the P-space tile sums, both on the 16-bit
- *                                                      matrix pipe (round 4) | the fp32-MFMA kernels of rounds 2-3; the two
- *                                                      agree to ~1e-6 relative (tests/test_gpu_parity.py)
- *        "guard_undersize" "<buffer>:<bytes>"          tests of the guard mode only (see below)
+ *        "query_group"   0 | 1 .. 64                   a HINT, never a result: the query rows of the coming batches are the
+ *                                                      segments of query images, this many consecutive rows per image (0 =
+ *                                                      unknown).  The exact level of a batch search re-evaluates the refine
+ *                                                      bands of a group of rows -- an image's rows with the hint, 32-row
+ *                                                      blocks without -- as ONE fp32 GEMM over the union of their database
+ *                                                      rows when the bands overlap (the segments of an image share most of
+ *                                                      their neighbours), row by row when they do not
+ *        "refine_group"  1 | 0                         that grouped refinement | every row on its own (rounds 1-4); same bits
+ *      Every other key is a DEVELOPMENT switch (kernel tuning, A/B variants, debugging, the tests' own hooks), documented in
+ *      revisit-anything_amd/csrc/segvlad_dev.h and NOT part of this ABI: none changes a result, the shipped library holds
+ *      only the kernels they default to and rejects the values that select another (SEGVLAD_ERR_ARG).
  *
  *      Environment, read ONCE by segvlad_create: SEGVLAD_GUARD=1 creates a GUARDED context (development / test runs):
  *      every device buffer of the context is allocated at its exact size between two fences of poison words, the back

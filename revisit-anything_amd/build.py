@@ -32,7 +32,8 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False, ablations: bool = False) -> str:
     """ablations=True (development only): the build with the timing ablations (WRONG results) and the phase timers, as a
     SECOND library next to the product's (lib/libsegvlad_hip_abl.so; load it with SEGVLAD_LIB_PATH)."""
-    ablations = ablations or bool(os.environ.get("SEGVLAD_BUILD_ABLATIONS"))
+    # (the environment switch only applies to an explicit `python build.py`: _lib.load() must always get the product library
+    #  at LIB_PATH rebuilt, whatever the environment says -- ADVICE r04)
     lib_path = LIB_PATH.replace(".so", "_abl.so") if ablations else LIB_PATH
     if not ablations and not force and not needs_build():
         return LIB_PATH
@@ -63,4 +64,5 @@ def build(force: bool = False, verbose: bool = False, ablations: bool = False) -
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, ablations="--ablations" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True,
+                ablations="--ablations" in sys.argv or bool(os.environ.get("SEGVLAD_BUILD_ABLATIONS"))))

@@ -8,6 +8,8 @@
 #include <mutex>
 #include <utility>
 
+#include <initializer_list>
+
 #include "ctx.h"
 
 int segvlad_ctx::fail(int code, const char* fmt, ...) {
@@ -269,16 +271,34 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
     else return ctx->fail(SEGVLAD_ERR_ARG, "set_option(pca_path): want auto|planes|project, got '%s'", value);
     return SEGVLAD_OK;
   }
-  if (!strcmp(key, "f16_cfg")) return as_int(&o.f16_cfg);
+  // Switches that select one of the fp16 filter's measured-and-not-kept kernel variants (csrc/segvlad_dev.h): the shipped
+  // library holds the default kernels only and accepts just the values that mean "the default"; development builds
+  // (-DSEGVLAD_ABLATIONS: lib/libsegvlad_hip_abl.so) hold every variant.
+  auto as_dev = [&](int* dst, std::initializer_list<int> product_values) -> int {
+    int v = *dst;
+    SV_TRY(as_int(&v));
+#ifndef SEGVLAD_ABLATIONS
+    bool ok = false;
+    for (int a : product_values) ok = ok || a == v;
+    if (!ok)
+      return ctx->fail(SEGVLAD_ERR_ARG, "set_option(%s=%d): a development switch -- this library holds the default kernel only "
+                       "(SEGVLAD_BUILD_ABLATIONS=1 builds lib/libsegvlad_hip_abl.so)", key, v);
+#else
+    (void)product_values;
+#endif
+    *dst = v;
+    return SEGVLAD_OK;
+  };
+  if (!strcmp(key, "f16_cfg")) return as_dev(&o.f16_cfg, {-1, 250, 300, 62, 63});
   if (!strcmp(key, "f16_gm")) return as_int(&o.f16_gm);
   if (!strcmp(key, "f16_walk")) return as_int(&o.f16_walk);
-  if (!strcmp(key, "f16_epi")) return as_int(&o.f16_epi);
-  if (!strcmp(key, "f16_mf")) return as_int(&o.f16_mf);
-  if (!strcmp(key, "f16_deep_cfg")) return as_int(&o.f16_deep_cfg);
-  if (!strcmp(key, "f16_pp")) return as_int(&o.f16_pp);
-  if (!strcmp(key, "f16_small_mf")) return as_int(&o.f16_small_mf);
-  if (!strcmp(key, "f16_buf")) return as_int(&o.f16_buf);
-  if (!strcmp(key, "f16_dsplit")) return as_int(&o.f16_dsplit);
+  if (!strcmp(key, "f16_epi")) return as_dev(&o.f16_epi, {-1, 1});
+  if (!strcmp(key, "f16_mf")) return as_dev(&o.f16_mf, {-1, 1});
+  if (!strcmp(key, "f16_deep_cfg")) return as_dev(&o.f16_deep_cfg, {-1, 4});
+  if (!strcmp(key, "f16_pp")) return as_dev(&o.f16_pp, {-1, 2});
+  if (!strcmp(key, "f16_small_mf")) return as_dev(&o.f16_small_mf, {0});
+  if (!strcmp(key, "f16_buf")) return as_dev(&o.f16_buf, {-1, 0});
+  if (!strcmp(key, "f16_dsplit")) return as_dev(&o.f16_dsplit, {0});
   if (!strcmp(key, "tnk_gram")) return as_int(&o.tnk_gram);
   if (!strcmp(key, "tnk_fork")) return as_int(&o.tnk_fork);
   if (!strcmp(key, "x3_tile")) return as_int(&o.x3_tile);

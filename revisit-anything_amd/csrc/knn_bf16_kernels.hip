@@ -1754,17 +1754,20 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           if (buf_ok) return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1, true>(SV_F16_ARGS);
           return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1>(SV_F16_ARGS);
         }
+#ifdef SEGVLAD_ABLATIONS   // measured and not kept (development build; the shipped library holds the default only)
         if (ctx->opt.f16_deep_cfg == 1) return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 2, 16, true, 1, 1>(SV_F16_ARGS);
         if (ctx->opt.f16_deep_cfg == 2) return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 2, 16, true, 1, 1>(SV_F16_ARGS);
         if (ctx->opt.f16_deep_cfg == 3) return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1>(SV_F16_ARGS);   // plain loop
+#endif
       }
       return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 0, 0, 16>(SV_F16_ARGS);
+#ifdef SEGVLAD_ABLATIONS   // development builds only: the configurations measured on the way (rounds 1-4, DESIGN.md 4 / 7.1: correct
+                           // results, not kept), timing ablations (WRONG results) and phase timing
     case 0: return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);  // 160 KiB LDS, 1 workgroup / CU
     case 200:   // persistent workgroups that request the next tile's head before their epilogue
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true>(SV_F16_ARGS);
       return launch_f16_filter<256, 256, 4, 2, 64, 3>(SV_F16_ARGS);
-#ifdef SEGVLAD_ABLATIONS   // timing ablations (WRONG results) and phase timing: development builds only
     case 10: return launch_f16_filter<256, 256, 4, 2, 64, 3, 1>(SV_F16_ARGS);  // ablations of config 0 (WRONG results)
     case 20: return launch_f16_filter<256, 256, 4, 2, 64, 3, 2>(SV_F16_ARGS);
     case 30: return launch_f16_filter<256, 256, 4, 2, 64, 3, 3>(SV_F16_ARGS);
@@ -1809,13 +1812,14 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
               (double)c8[6] / ((double)((M + 255) / 256) * ((n_sample + 255) / 256)));
       return rc;
     }
-#endif
     case 50: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2>(SV_F16_ARGS);  // ping-pong, 2 phases per k-tile
     case 51: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 4>(SV_F16_ARGS);  // ping-pong, 4 phases per k-tile
     case 52: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 1>(SV_F16_ARGS);  // ping-pong, 1 phase per k-tile
+#endif
     case 250:   // the default for batches: biased accumulators (see BIAS) when segvlad_search found the norms balanced enough
       if (!ctx->f16_bias_ok) goto unbiased_250;
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024) {
+#ifdef SEGVLAD_ABLATIONS   // the A/B variants of the batch kernel (development build)
         if (ctx->opt.f16_epi == 0)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true>(SV_F16_ARGS);      // persistent + ping-pong
         if (ctx->opt.f16_mf == 0)
@@ -1834,16 +1838,20 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 1>(SV_F16_ARGS);
         if (buf_ok && ctx->opt.f16_buf == 1)
           return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, true>(SV_F16_ARGS);   // + buffer_load lds
+#endif
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);  // + 16 x 16 x 32 MFMA
       }
+#ifdef SEGVLAD_ABLATIONS
       if (ctx->opt.f16_small_mf == 1)   // (A/B: the small levels on the new shape + wave-private epilogue, non-persistent)
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true, 1, 1>(SV_F16_ARGS);
+#endif
       return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2, 0, true>(SV_F16_ARGS);
     case 251:   // 250 without the bias (A/B; norms too unbalanced for the biased margin)
     unbiased_250:
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
         return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2>(SV_F16_ARGS);
       return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 0, 2>(SV_F16_ARGS);
+#ifdef SEGVLAD_ABLATIONS
     case 40: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 1>(SV_F16_ARGS);  // database rows non-temporal
     case 41: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 2>(SV_F16_ARGS);  // queries non-temporal
     case 42: return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, false, 3>(SV_F16_ARGS);  // both
@@ -1851,26 +1859,27 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     case 2: return launch_f16_filter<128, 128, 2, 2, 64, 3>(SV_F16_ARGS);  //  80 KiB
     case 4: return launch_f16_filter<256, 256, 4, 2, 32, 3>(SV_F16_ARGS);  //  80 KiB
     case 60: return launch_f16_filter<64, 128, 1, 2, 64, 3>(SV_F16_ARGS);   //  64 KiB, 2 waves: one query image (<= 64 rows) per pass
+#endif
     case 62: return launch_f16_filter<64, 128, 1, 2, 64, 3, 0, false, 1>(SV_F16_ARGS);   // 60 + database rows non-temporal
     case 63: return launch_f16_filter<128, 128, 2, 2, 64, 3, 0, false, 1>(SV_F16_ARGS);  // 2 + database rows non-temporal
+#ifdef SEGVLAD_ABLATIONS
     case 5: return launch_f16_filter<256, 256, 2, 2, 64, 3>(SV_F16_ARGS);  // 4 waves of 128 x 128: 0.5 LDS fragment / MFMA
     case 55: return launch_f16_filter<256, 256, 2, 2, 64, 3, 0, false, 0, -1>(SV_F16_ARGS);  // + software-pipelined loop
     case 255:
       if ((int64_t)((M + 255) / 256) * ((n_sample + 255) / 256) >= 1024)
         return launch_f16_filter<256, 256, 2, 2, 64, 3, 0, true, 0, -1>(SV_F16_ARGS);       // + persistent
       return launch_f16_filter<256, 256, 2, 2, 64, 3, 0, false, 0, -1>(SV_F16_ARGS);
-#ifdef SEGVLAD_ABLATIONS
     case 15: return launch_f16_filter<256, 256, 2, 2, 64, 3, 1>(SV_F16_ARGS);
     case 155: return launch_f16_filter<256, 256, 2, 2, 64, 3, 1, false, 0, -1>(SV_F16_ARGS);
-#endif
     case 6: return launch_f16_filter<256, 256, 2, 2, 32, 3>(SV_F16_ARGS);
     case 7: return launch_f16_filter<256, 128, 4, 1, 32, 3>(SV_F16_ARGS);  // 56 KiB, 4 waves: 2 independent workgroups / CU
-#ifdef SEGVLAD_ABLATIONS
     case 17: return launch_f16_filter<256, 128, 4, 1, 32, 3, 1>(SV_F16_ARGS);
-#endif
     case 8: return launch_f16_filter<256, 128, 4, 1, 32, 2>(SV_F16_ARGS);
     case 9: return launch_f16_filter<128, 256, 2, 2, 32, 3>(SV_F16_ARGS);
     default: return launch_f16_filter<128, 128, 2, 2, 32, 2>(SV_F16_ARGS); //  32 KiB
+#else
+    default: return ctx->fail(SEGVLAD_ERR_ARG, "fp16 filter configuration %d exists in development builds only (SEGVLAD_BUILD_ABLATIONS=1)", c);
+#endif
   }
 #undef SV_F16_ARGS
 }

@@ -283,12 +283,43 @@ def _offsets_from_ranges(segRangeQuery, n_query):
     return off, order, contiguous
 
 
+def _images_by_count(image_ids, keep):
+    """Image ids present in `image_ids` (1-D; np.bincount refuses anything deeper, like the reference's call), the `keep`
+    most frequent ones first (func_vpr.py:95-97 / 102-104 / 120-122: argsort of the counts of the present ids, last `keep`,
+    flipped -- ties therefore resolve as numpy's argsort leaves them)."""
+    counts = np.bincount(image_ids)
+    present = np.nonzero(counts)[0]
+    return present[np.argsort(counts[present])[-keep:][::-1]]
+
+
+def _get_matches_top1(matches, sims, rows, imIndsRef, n, method):
+    """The three per-segment-top-1 methods of get_matches (func_vpr.py:86-117): `matches` / `sims` hold ONE neighbour per
+    query segment (1-D), `rows` are the segment rows of one query image.  Host numpy, as in the reference (these methods
+    are not what any driver calls -- place_rec_main.py:84 -- and run once per query image on a few dozen values)."""
+    if method == "max_sim":
+        # the (up to) 50 most similar segments of the image, best first; their reference images; first n distinct
+        best = np.flip(np.argsort(sims[rows])[-50:])
+        return first_k_unique_indices(imIndsRef[matches[rows][best]], n)
+    seg_images = imIndsRef[matches[rows]]
+    if method == "max_seg":
+        return _images_by_count(seg_images, n)
+    # "max_seg_sim": the 6 most voted images, re-ranked by the best similarity any of the image's segments reached with them
+    cand = _images_by_count(seg_images, 6)
+    s_rows = sims[rows]
+    best_sim = [np.max(s_rows[np.nonzero(seg_images == c)[0]]) for c in cand]
+    return cand[np.flip(np.argsort(best_sim))][:n]
+
+
 def get_matches(matches, gt, sims, segRangeQuery, imIndsRef, n=1, method="max_sim"):
-    """func_vpr.py:80-243.  ``len(gt)`` sets the number of query images.  Implemented on the device:
-    "max_seg_topk_wt_borda_Im" (the method every driver uses, place_rec_main.py:84) and the integer
-    variant "max_seg_topk".  The other branches of the reference are analysis-only; three of them call
-    functions that are defined nowhere (func_vpr.py:128,137,173,191,200,236)."""
+    """func_vpr.py:80-243.  ``len(gt)`` sets the number of query images.  On the device: "max_seg_topk_wt_borda_Im" (the
+    method every driver uses, place_rec_main.py:84) and the integer variant "max_seg_topk".  On the host, as in the
+    reference: the per-segment-top-1 methods "max_sim" (the DEFAULT argument), "max_seg", "max_seg_sim"
+    (func_vpr.py:86-117; `matches` / `sims` are then 1-D, one neighbour per query segment -- a 2-D argument fails in the
+    same numpy / set call as the reference's).  The remaining branches of the reference call functions that are defined
+    nowhere (func_vpr.py:128,137,173,191,200,236) and raise NotImplementedError here."""
     nq_img = len(gt)
+    if method in ("max_sim", "max_seg", "max_seg_sim"):
+        return [_get_matches_top1(matches, sims, segRangeQuery[i], imIndsRef, n, method) for i in range(nq_img)]
     if method not in ("max_seg_topk_wt_borda_Im", "max_seg_topk"):
         raise NotImplementedError(f"get_matches(method={method!r}) is not part of the SegVLAD hot path")
     off, order, contiguous = _offsets_from_ranges(segRangeQuery, nq_img)

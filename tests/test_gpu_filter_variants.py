@@ -26,14 +26,27 @@ def _check_variants(R, Q, k, variants, defaults):
     ref = eng.search(Q, k)
     assert eng.search_stats()["filter"] == "fp32"
     eng.set_option("knn_filter", "auto")
+    from revisit_anything_amd._lib import SEGVLAD_ERR_ARG, SegVLADError
+
+    ran = 0
     for v in variants:
-        for key, val in {**defaults, **v}.items():
-            eng.set_option(key, val)
+        try:
+            for key, val in {**defaults, **v}.items():
+                eng.set_option(key, val)
+        except SegVLADError as e:
+            # a measured-and-not-kept variant: instantiated by the development build only (csrc/segvlad_dev.h; run this file
+            # with SEGVLAD_LIB_PATH=.../libsegvlad_hip_abl.so to cover them); the shipped library refuses the value
+            assert e.code == SEGVLAD_ERR_ARG and "development" in str(e), e
+            for key, val in defaults.items():
+                eng.set_option(key, val)
+            continue
+        ran += 1
         d2, idx = eng.search(Q, k)
         st = eng.search_stats()
         assert st["filter"] == "f16" and st["levels"] >= 1, (v, st)
         assert torch.equal(idx, ref[1]) and torch.equal(d2, ref[0]), f"variant {v} differs from the fp32 filter"
     eng.close()
+    assert ran >= 1
 
 
 BATCH_DEFAULTS = {"f16_epi": -1, "f16_mf": -1, "f16_walk": -1, "f16_pp": -1, "f16_small_mf": 0, "f16_gm": -1, "f16_buf": -1, "f16_dsplit": 0}

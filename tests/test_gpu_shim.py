@@ -242,8 +242,8 @@ def test_get_matches_golden_contiguous_and_permuted(fv):
     p = fv.get_matches(z["tie_matches"], [[0]], z["tie_sims"], [np.arange(2)], z["tie_imInds"], n=4,
                        method="max_seg_topk_wt_borda_Im")
     assert [int(v) for v in p[0]] == z["tie_pred"].tolist()
-    with pytest.raises(NotImplementedError):
-        fv.get_matches(z["matches"], gt, z["sims"], segRange, z["imInds"], n=1, method="max_sim")
+    with pytest.raises(NotImplementedError):   # a branch that calls an undefined helper in the reference (func_vpr.py:128)
+        fv.get_matches(z["matches"], gt, z["sims"], segRange, z["imInds"], n=1, method="max_seg_topk_borda")
 
 
 def test_weighted_borda_count_host_helper(fv):

@@ -169,3 +169,39 @@ def test_pipeline_falls_back_to_qhull_when_the_device_adjacency_declines():
                 SegVLADError("a message that merely mentions the LDS budget and the word degenerate")):   # no code, wrong type
         with pytest.raises(SegVLADError):
             SegVLADPipeline(Stub(exc), 112, 140, order=1, use_pca=False).describe("tok", "masks", offs)
+
+
+def test_get_matches_top1_methods_equal_the_reference_body():
+    """get_matches(method="max_sim" -- the DEFAULT argument --, "max_seg", "max_seg_sim"), func_vpr.py:86-117: one neighbour
+    per query segment (1-D matches / sims), host numpy like the reference.  Fixture: tools/make_golden.py top1 (the reference's
+    own body executed on seeded inputs with distinct similarities and distinct vote counts per image)."""
+    z = np.load(os.path.join(G, "get_matches_top1.npz"))
+    off = z["off"]
+    n_q = len(off) - 1
+    seg_range = [np.arange(off[i], off[i + 1]) for i in range(n_q)]
+    gt = [[0]] * n_q
+
+    def padded(p, n):
+        return np.array([[int(v) for v in x] + [-1] * (n - len(x)) for x in p], dtype=np.int64)
+
+    for meth in ("max_sim", "max_seg", "max_seg_sim"):
+        for n in (1, 5):
+            got = func_vpr.get_matches(z["matches"], gt, z["sims"], seg_range, z["imInds"], n=n, method=meth)
+            assert np.array_equal(padded(got, n), z[f"{meth}_n{n}"]), (meth, n)
+    got = func_vpr.get_matches(z["matches"], gt, z["sims"], seg_range, z["imInds"], n=3)     # method omitted
+    assert np.array_equal(padded(got, 3), z["default_n3"])
+    # 2-D (top-50) inputs fail where the reference's numpy calls fail
+    r = np.random.Generator(np.random.PCG64(1))
+    m2 = r.integers(0, len(z["imInds"]), size=(40, 50))
+    s2 = r.random((40, 50)).astype(np.float32)
+    import pytest
+
+    for meth, err in zip(("max_sim", "max_seg", "max_seg_sim"), z["errors_2d"]):
+        with pytest.raises(Exception) as ei:
+            func_vpr.get_matches(m2, [[0]], s2, [np.arange(7)], z["imInds"], n=2, method=meth)
+        assert type(ei.value).__name__ == str(err), (meth, type(ei.value).__name__, err)
+    # segRangeQuery need not be contiguous or sorted
+    perm = r.permutation(off[-1])
+    inv = np.argsort(perm)
+    got = func_vpr.get_matches(z["matches"][perm], gt, z["sims"][perm], [inv[sr] for sr in seg_range], z["imInds"], n=5, method="max_seg_sim")
+    assert np.array_equal(padded(got, 5), z["max_seg_sim_n5"])

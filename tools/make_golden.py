@@ -387,6 +387,58 @@ def main():
 # ---------------------------------------------------------------------------------------------------------------------
 # producers: the vendored SAM utilities and the reference's DINO token extraction, executed where they lie
 # ---------------------------------------------------------------------------------------------------------------------
+def gen_get_matches_top1(fv=None):
+    """The per-segment-top-1 methods of get_matches (func_vpr.py:86-117; "max_sim" is the DEFAULT argument), executed from the
+    reference's own body -> tests/golden/get_matches_top1.npz."""
+    if fv is None:
+        fv, _ = load_ref()
+    # ---- the per-segment-top-1 methods of get_matches (func_vpr.py:86-117; "max_sim" is the DEFAULT argument) -----------
+    # inputs are 1-D: one neighbour per query segment.  Similarities are distinct, vote counts are made distinct per
+    # query image (the reference ranks both with numpy's unstable argsort: a tie's order is an accident of the sort)
+    t1 = {}
+    r = np.random.Generator(np.random.PCG64(650))
+    n_ref_img, segs, n_q = 120, 10, 30
+    imInds1 = np.repeat(np.arange(n_ref_img), segs)
+    rows_per_q = r.integers(1, 70, size=n_q)          # images with more than 50 segments exercise max_sim's [-50:]
+    off1 = np.concatenate([[0], np.cumsum(rows_per_q)])
+    m1 = np.empty(int(off1[-1]), dtype=np.int64)
+    for i in range(n_q):
+        ns = int(rows_per_q[i])
+        pool = r.choice(n_ref_img, size=min(8, n_ref_img), replace=False)
+        # image j of the pool gets a distinct number of votes: ns split as descending distinct shares where possible
+        shares = np.sort(r.choice(np.arange(1, ns + 8), size=len(pool), replace=False))[::-1].astype(np.float64)
+        counts = np.floor(shares / shares.sum() * ns).astype(int)
+        counts[0] += ns - counts.sum()
+        img = np.repeat(pool, counts)
+        r.shuffle(img)
+        m1[off1[i]:off1[i + 1]] = img * segs + r.integers(0, segs, size=ns)
+    s1 = r.permutation(int(off1[-1])).astype(np.float32) / np.float32(off1[-1]) * np.float32(1.7) + np.float32(0.2)
+    segRange1 = [np.arange(off1[i], off1[i + 1]) for i in range(n_q)]
+    gt1 = [[0]] * n_q
+    for meth in ("max_sim", "max_seg", "max_seg_sim"):
+        for n in (1, 5):
+            p = fv.get_matches(m1, gt1, s1, segRange1, imInds1, n=n, method=meth)
+            t1[f"{meth}_n{n}"] = np.array([list(x) + [-1] * (n - len(x)) for x in p], dtype=np.int64)
+    # the default argument IS max_sim
+    p = fv.get_matches(m1, gt1, s1, segRange1, imInds1, n=3)
+    t1["default_n3"] = np.array([list(x) + [-1] * (3 - len(x)) for x in p], dtype=np.int64)
+    # which counts tie inside a query image's top-n (such entries are compared as sets by the tests)
+    t1.update(matches=m1, sims=s1, off=off1, imInds=imInds1)
+    # 2-D (top-50) inputs: what the reference raises
+    errs = []
+    for meth in ("max_sim", "max_seg", "max_seg_sim"):
+        try:
+            m2 = r.integers(0, n_ref_img * segs, size=(40, 50)).astype(np.int64)
+            s2 = np.sort(r.uniform(0.2, 1.9, size=(40, 50)).astype(np.float32), axis=1)[:, ::-1].copy()
+            fv.get_matches(m2, [[0]], s2, [np.arange(7)], imInds1, n=2, method=meth)
+            errs.append("none")
+        except Exception as e:  # noqa: BLE001
+            errs.append(type(e).__name__)
+    t1["errors_2d"] = np.array(errs)
+    np.savez_compressed(f"{OUT}/get_matches_top1.npz", **t1)
+    print("get_matches_top1:", {k: v.shape for k, v in t1.items() if k.endswith("n5")}, list(t1["errors_2d"]))
+
+
 def stub_extractor(seed: int, D: int):
     """Deterministic stand-in for the DINOv2 value-facet extractor (weights are not available): [1, 3, h, w] normalised
     image -> [1, (h/14)(w/14), D]: per-patch channel means and mean squares through a seeded linear map + tanh.  The tests
@@ -596,7 +648,11 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "sam":
         os.makedirs(OUT, exist_ok=True)
         gen_sam_generate()
+    elif len(sys.argv) > 1 and sys.argv[1] == "top1":
+        os.makedirs(OUT, exist_ok=True)
+        gen_get_matches_top1()
     else:
         main()
+        gen_get_matches_top1()
         gen_producers()
         gen_sam_generate()
