@@ -1305,7 +1305,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   if (nq == 0) return SEGVLAD_OK;
   if (!Q || !d2_out || !idx_out) return ctx->fail(SEGVLAD_ERR_ARG, "search: null pointer");
   if (ctx->db_d == 0) return ctx->fail(SEGVLAD_ERR_STATE, "search: the index is empty and has no dimension yet");
-  if (ctx->opt.debug_fail_search) return ctx->fail(SEGVLAD_ERR_STATE, "search: failing on request (option debug_fail_search)");
+  if (ctx->opt.debug_fail_search == 1) return ctx->fail(SEGVLAD_ERR_STATE, "search: failing on request (option debug_fail_search)");
   const int d = ctx->db_d;
   const int64_t n = ctx->db_n;
   ctx->f16_scale_dev = nullptr;

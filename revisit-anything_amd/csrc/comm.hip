@@ -219,7 +219,13 @@ int segvlad_allgather_rows(segvlad_ctx* ctx, const float* local_rows, int n_loca
   int rc = sv_in(ctx, local_rows, (size_t)n_local * d * 4, &din);
   if (rc == SEGVLAD_OK) rc = sv_out(ctx, all_rows, (size_t)ctx->comm_world * n_local * d * 4, &dout);
   if (rc != SEGVLAD_OK) return comm_abort_local(ctx, "allgather_rows", rc);
-  SV_RCCL(g_rccl.AllGather(din, dout, (size_t)n_local * d, ncclFloat, reinterpret_cast<ncclComm_t>(ctx->comm), ctx->stream));
+  {
+    const ncclResult_t r = g_rccl.AllGather(din, dout, (size_t)n_local * d, ncclFloat, reinterpret_cast<ncclComm_t>(ctx->comm), ctx->stream);
+    if (r != ncclSuccess) {
+      (void)ctx->fail(SEGVLAD_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+      return comm_abort_local(ctx, "allgather_rows", SEGVLAD_ERR_COMM);
+    }
+  }
   return sv_finish(ctx);
 }
 
@@ -257,41 +263,74 @@ int segvlad_search_sharded(segvlad_ctx* ctx, const float* Q, int nq, int k, int6
     if (local_rc != SEGVLAD_OK) snprintf(local_err, sizeof(local_err), "%s", ctx->err);
     sv_begin(ctx);
   }
+  if (ctx->opt.debug_fail_search == 2) {   // tests: a failure that can no longer join the collective
+    (void)ctx->fail(SEGVLAD_ERR_STATE, "search_sharded: failing in front of the collective on request (option debug_fail_search = 2)");
+    return comm_abort_local(ctx, "search_sharded", SEGVLAD_ERR_STATE);
+  }
+  // From here to the all-gather the peers may already be INSIDE the collective: a failure on this rank must not simply return
+  // (a failed local search may have left a sticky HIP error, and then the very next memset fails as well): it aborts the
+  // communicator, so that the peers' collective fails instead of waiting for ever.
+#define SV_PRE(expr)                                                                                        \
+  do {                                                                                                      \
+    hipError_t _e = (expr);                                                                                 \
+    if (_e != hipSuccess) {                                                                                 \
+      (void)ctx->fail(SEGVLAD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return comm_abort_local(ctx, "search_sharded", SEGVLAD_ERR_HIP);                                      \
+    }                                                                                                       \
+  } while (0)
   if (ctx->db_n <= 0 || local_rc != SEGVLAD_OK) {   // an empty (or failed) shard contributes (inf, -1)
-    SV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ld2), 0x7f800000, (size_t)total, ctx->stream));
-    SV_HIP(hipMemsetAsync(lidx, 0xff, (size_t)total * 8, ctx->stream));
+    SV_PRE(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ld2), 0x7f800000, (size_t)total, ctx->stream));
+    SV_PRE(hipMemsetAsync(lidx, 0xff, (size_t)total * 8, ctx->stream));
   }
   void *od, *oi;
   int rc_out = sv_out(ctx, d2_out, (size_t)total * 4, &od);
   if (rc_out == SEGVLAD_OK) rc_out = sv_out(ctx, idx_out, (size_t)total * 8, &oi);
   if (rc_out != SEGVLAD_OK) return comm_abort_local(ctx, "search_sharded", rc_out);
-  std::vector<uint32_t> hflags((size_t)world, 0u);
+  // the status words of all ranks land in a buffer the CONTEXT owns: the copy is asynchronous, and an error path that left
+  // this frame before the stream was synchronised would have had the copy write into a dead stack vector
+  ctx->sh_flags_host.assign((size_t)world, 0u);
+  int post_rc = SEGVLAD_OK;   // failures behind the collective: remembered, the stream is synchronised either way
   {
     StageScope sc(ctx, "shard_exchange");
     hipLaunchKernelGGL(pack_topk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ld2, lidx, total, id_base,
                        ctx->s_sh_rec.as<uint32_t>());
-    SV_HIP(hipGetLastError());
-    SV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->s_sh_rec.as<uint32_t>() + 3 * total), local_rc != SEGVLAD_OK ? 1 : 0, 3,
+    SV_PRE(hipGetLastError());
+    SV_PRE(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->s_sh_rec.as<uint32_t>() + 3 * total), local_rc != SEGVLAD_OK ? 1 : 0, 3,
                              ctx->stream));   // the trailer record: {status, status, status}
-    SV_RCCL(g_rccl.AllGather(ctx->s_sh_rec.p, ctx->s_sh_all.p, (size_t)(total + 1) * 12, ncclUint8, reinterpret_cast<ncclComm_t>(ctx->comm),
-                             ctx->stream));
+    {
+      const ncclResult_t r = g_rccl.AllGather(ctx->s_sh_rec.p, ctx->s_sh_all.p, (size_t)(total + 1) * 12, ncclUint8,
+                                              reinterpret_cast<ncclComm_t>(ctx->comm), ctx->stream);
+      if (r != ncclSuccess) {   // not enqueued on this rank (or the peers are gone): nothing to wait for, nobody to leave waiting
+        (void)ctx->fail(SEGVLAD_ERR_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+        return comm_abort_local(ctx, "search_sharded", SEGVLAD_ERR_COMM);
+      }
+    }
+#undef SV_PRE
     const int64_t all = (int64_t)world * total;
     hipLaunchKernelGGL(unpack_topk_kernel, dim3((unsigned)((all + 255) / 256)), dim3(256), 0, ctx->stream, ctx->s_sh_all.as<uint32_t>(),
                        world, nq, k, ctx->s_sh_d2c.as<float>(), ctx->s_sh_idc.as<int64_t>(), flags);
-    SV_HIP(hipGetLastError());
-    SV_HIP(hipMemcpyAsync(hflags.data(), flags, (size_t)world * 4, hipMemcpyDeviceToHost, ctx->stream));
+    hipError_t he2 = hipGetLastError();
+    if (he2 == hipSuccess)
+      he2 = hipMemcpyAsync(ctx->sh_flags_host.data(), flags, (size_t)world * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (he2 != hipSuccess) post_rc = ctx->fail(SEGVLAD_ERR_HIP, "search_sharded: behind the collective: %s", hipGetErrorString(he2));
     sc.count(3);
   }
-  {
+  if (post_rc == SEGVLAD_OK) {
     StageScope sc(ctx, "shard_merge");
-    SV_TRY(sv_launch_merge_topk(ctx, ctx->s_sh_d2c.as<float>(), ctx->s_sh_idc.as<int64_t>(), nq, world * k, k, (float*)od, (int64_t*)oi));
+    post_rc = sv_launch_merge_topk(ctx, ctx->s_sh_d2c.as<float>(), ctx->s_sh_idc.as<int64_t>(), nq, world * k, k, (float*)od, (int64_t*)oi);
     sc.count();
   }
-  SV_HIP(hipStreamSynchronize(ctx->stream));   // the status words of all ranks (4 bytes each)
+  {
+    const hipError_t hs = hipStreamSynchronize(ctx->stream);   // the status words of all ranks (4 bytes each)
+    if (hs != hipSuccess && post_rc == SEGVLAD_OK)
+      post_rc = ctx->fail(SEGVLAD_ERR_HIP, "search_sharded: hipStreamSynchronize: %s", hipGetErrorString(hs));
+  }
+  if (post_rc != SEGVLAD_OK) return post_rc;
   const int rc_fin = sv_finish(ctx);
   if (local_rc != SEGVLAD_OK) return ctx->fail(local_rc, "search_sharded: this rank's local search failed: %s", local_err);
   for (int r = 0; r < world; ++r)
-    if (hflags[(size_t)r]) return ctx->fail(SEGVLAD_ERR_COMM, "search_sharded: rank %d failed its local search (every rank returns an error)", r);
+    if (ctx->sh_flags_host[(size_t)r])
+      return ctx->fail(SEGVLAD_ERR_COMM, "search_sharded: rank %d failed its local search (every rank returns an error)", r);
   return rc_fin;
 }
 

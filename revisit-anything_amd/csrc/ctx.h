@@ -149,7 +149,8 @@ struct SvOptions {
   int knn_heuristic = 1;  // 1: low-rank (verified) thresholds in the level scheme; 0: rigorous k-th-rank thresholds only
   int assign_narrow = 0;  // 1: force the narrow assignment kernel
   int agg_kpb = 4;        // clusters per aggregation workgroup
-  int debug_fail_search = 0;   // tests only: segvlad_search fails at once (SEGVLAD_ERR_STATE) -- the sharded entry's error path
+  int debug_fail_search = 0;   // tests only: 1 = segvlad_search fails at once (SEGVLAD_ERR_STATE) -- the sharded entry's error path;
+                               // 2 = segvlad_search_sharded fails BEHIND its local search, where it can only abort the communicator
   int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises); 7: token_norms_kernel waits for every
                           //    outstanding memory operation at every step (verification of its counted waits: same bits)
   int small_plan = 1;     // <= 128 queries (one query image per pass): one filter level behind an exact sample of 2048..4096
@@ -273,6 +274,7 @@ struct segvlad_ctx {
   // row-sharded index over several GPUs (comm.hip): an RCCL communicator bound at run time
   void* comm = nullptr;   // ncclComm_t
   int comm_rank = 0, comm_world = 1;
+  std::vector<uint32_t> sh_flags_host;   // the ranks' status words of a sharded search (target of an asynchronous copy)
   // staging for host<->device pointers: a small ring, indexed by use inside one call
   std::vector<DevBuf> stage;
   struct Pending { void* host; void* dev; size_t bytes; };
