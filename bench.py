@@ -517,7 +517,9 @@ def run(a, top=True):
 
     # ---- per-stage device time (HIP events on the engine stream, summed over the timed steps) ----------------
     stages = {}
-    for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "knn_redo",
+    # ("describe": segvlad_describe as the stream sees it -- since round 5 the mask branch, incidence + adjacency, runs on the
+    #  context's side stream beside the assignment pass, so the parts' times no longer add up to the stage's)
+    for s in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca", "describe", "knn_level0", "knn_gemm", "knn_select", "knn_redo",
               "knn_fallback", "vote"):
         for e_ in ({eng, eng_d} if a.pipeline else {eng}):
             try:
@@ -634,6 +636,15 @@ def run(a, top=True):
                          "'planes' form (22.7 vs 32.9 MB), so fractions are not comparable across the two -- stage_ms is"}
     if vlad_roof["achieved"]:
         vlad_roof["frac"] = vlad_roof["achieved"] / PEAK_HBM_GBS
+        # (verdict r04) the same stage priced on the bytes NO implementation can avoid -- the tokens and the masks in, the
+        # projected descriptors (or the K*D-wide ones) out -- instead of this implementation's own intermediate planes
+        irr = 4 * D * N + S * Hm * Wm + (4 * S * P if use_pca else 4 * S * K * D)
+        vlad_roof["irreducible_bytes_per_image"] = irr
+        vlad_roof["frac_on_irreducible_bytes"] = irr * nq_local / (vlad_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        if "describe" in stages:   # the whole describe call as the stream sees it (mask branch beside the assignment pass; PCA included)
+            dms = stages["describe"]["ms_per_step"]
+            vlad_roof["describe_ms_wall"] = dms
+            vlad_roof["describe_frac_on_irreducible_bytes"] = irr * nq_local / (dms * 1e-3) / 1e9 / PEAK_HBM_GBS
     if pca_form == "project":
         # round 4: the block norms + residual planes come from the Gram kernels (tasks of <= 32 / <= 64 tokens), the
         # block-sum kernel keeps the larger tasks: the quoted traffic is the sum over the three launches

@@ -123,6 +123,19 @@ int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
                        const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
                        uint8_t* labels_out, float* gap_out);
 
+/* ---- the describe stage of a batch in ONE call: the per-image chain of place_rec_main.py:244-263 (preload_masks -> masks ->
+ *      nbrMasksAGGFastSingle -> seg_vlad_gpu_single) plus, with y != NULL, the per-batch apply_pca_transform_from_pkl (:269).
+ *      = segvlad_incidence_centroids + segvlad_adjacency_flagged + segvlad_images / segvlad_images_pca with the same arguments
+ *      and the same results; the mask branch runs on a second stream of the context beside the token-assignment pass.
+ *      All bulk pointers are DEVICE memory, seg_offsets [B+1] HOST.  The intermediates come back in caller-owned buffers
+ *      (inc_bits_out [S_tot][ceil(N/64)], centroids_out [S_tot][2] fp64, adj_out concatenated [S_b][S_b] bytes, img_flags_out [B]:
+ *      bit 0 empty mask, bit 1 non-generic centroids -- see segvlad_adjacency_flagged: a caller that needs the reference's result
+ *      bit for bit patches the flagged images' adjacency with Qhull and describes again through segvlad_images[_pca]).
+ *      desc_out [S_tot][K*D] and / or y [S_tot][P] (one of them may be NULL).                                            */
+int segvlad_describe(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B, int N,
+                     const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
+                     uint8_t* img_flags_out, float* desc_out, float* y, int l2norm);
+
 /* ---- the K-parametric entry: vlad_matmuls_per_cluster(num_c, masks, res, clus_labels, adjMat)
  *      func_vpr.py:1181-1210.  res [N][D] fp32 residuals (token-major, as the reference passes them),
  *      labels [N] u8 (< num_c <= 256), inc_bits [S][ceil(N/64)], adj [S][S] bytes or NULL,
@@ -178,7 +191,7 @@ int segvlad_vote(segvlad_ctx* ctx, const int64_t* idx, const float* sims, const 
                  int32_t* pred_out, double* score_out);
 
 /* ---- instrumentation: with profiling on, every kernel group of a stage ("incidence", "adjacency",
- *      "assign", "prep", "aggregate", "pca", "knn_level0", "knn_gemm", "knn_select", "knn_fallback", "vote") is bracketed by a HIP event pair
+ *      "assign", "prep", "aggregate", "pca", "describe" (segvlad_describe as a whole: its parts overlap), "knn_level0", "knn_gemm", "knn_select", "knn_fallback", "vote") is bracketed by a HIP event pair
  *      on the context stream.  segvlad_stage_ms returns the SUM of the elapsed times (ms) and the number
  *      of kernel launches recorded for the stage since the last segvlad_profile_reset; it returns
  *      SEGVLAD_ERR_STATE if the stage has not run.  Replaces the (discarded) time.time() pair of

@@ -637,8 +637,10 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
   SV_HIP(ctx->s_gscale.reserve((size_t)(S_tot + 1) * sizeof(float)));
   SV_HIP(ctx->s_segoff.reserve((size_t)(B + 1) * sizeof(int32_t)));
   SV_HIP(ctx->s_adjoff.reserve((size_t)(B + 1) * sizeof(int64_t)));
-  SV_HIP(hipMemcpyAsync(ctx->s_segoff.p, seg_offsets, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-  SV_HIP(hipMemcpyAsync(ctx->s_adjoff.p, adj_off.data(), (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  if (!ctx->mask_branch_on_side) {   // (segvlad_describe: the adjacency call on the side stream has put both in place)
+    SV_HIP(hipMemcpyAsync(ctx->s_segoff.p, seg_offsets, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SV_HIP(hipMemcpyAsync(ctx->s_adjoff.p, adj_off.data(), (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  }
   // (pageable sources: the runtime stages them before hipMemcpyAsync returns, so the local vector
   //  and the caller's array may be reused as soon as this call returns)
 
@@ -647,6 +649,10 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
     SV_TRY(sv_launch_assign(ctx, (const float*)d_tok, B, N, ctx->s_xt.as<float>(), (uint8_t*)d_lab, ctx->s_rnorm.as<float>(),
                             (float*)d_gap));
     sc.count();
+  }
+  if (ctx->mask_branch_on_side) {   // segvlad_describe: incidence + centroids + adjacency ran beside the assignment pass
+    ctx->mask_branch_on_side = false;
+    SV_TRY(sv_join_side(ctx));
   }
   if (S_tot > 0) {
     {
@@ -725,10 +731,9 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
   return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, out, labels_out, gap_out, block_norms_out, nullptr, 0);
 }
 
-int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
-                       const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
-                       uint8_t* labels_out, float* gap_out) {
-  CHECK_CTX();
+static int images_pca_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                           const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
+                           uint8_t* labels_out, float* gap_out) {
   if (ctx->P == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images_pca: call segvlad_pca_set first");
   if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images_pca: call segvlad_set_vocab first");
   if (ctx->KD != ctx->K * ctx->D)
@@ -749,6 +754,57 @@ int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
   }
   SV_TRY(images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc, labels_out, gap_out, nullptr, nullptr, 0));
   return S_tot > 0 ? segvlad_pca_apply(ctx, desc, S_tot, y, l2norm) : SEGVLAD_OK;
+}
+
+int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
+                       const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
+                       uint8_t* labels_out, float* gap_out) {
+  CHECK_CTX();
+  return images_pca_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, y, l2norm, desc_out, labels_out, gap_out);
+}
+
+// ---- the whole describe stage of a batch in ONE call: masks + tokens -> (projected) segment descriptors ----------------------
+// place_rec_main.py:244-270 per image (masks -> adjacency -> seg_vlad_gpu_single) and per batch (apply_pca_transform_from_pkl).
+// The mask branch (incidence + centroids -> adjacency: two latency-bound launches, 0.34 ms per 200 images) does not depend on
+// the tokens, the assignment pass (0.95 ms, HBM-bound) does not depend on the masks: the former runs on the context's side
+// stream BESIDE the latter and is joined in front of `prep`, the first kernel that needs both.
+int segvlad_describe(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B, int N,
+                     const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
+                     uint8_t* img_flags_out, float* desc_out, float* y, int l2norm) {
+  CHECK_CTX();
+  if (B < 0 || order < 1) return ctx->fail(SEGVLAD_ERR_ARG, "describe: need B >= 0 and order >= 1");
+  if (B == 0) return SEGVLAD_OK;
+  if (!masks || !tokens || !seg_offsets || !inc_bits_out || !centroids_out || !adj_out || !img_flags_out || (!desc_out && !y))
+    return ctx->fail(SEGVLAD_ERR_ARG, "describe: null pointer");
+  if (sv_is_device_ptr(seg_offsets)) return ctx->fail(SEGVLAD_ERR_ARG, "describe: seg_offsets must be host memory");
+  const void* bulk[] = {masks, tokens, inc_bits_out, centroids_out, adj_out, img_flags_out, desc_out, y};
+  for (const void* p : bulk)
+    if (p && !sv_is_device_ptr(p))
+      return ctx->fail(SEGVLAD_ERR_ARG, "describe: bulk pointers must be device memory (the separate entry points stage host data)");
+  if (N != (H / (patch > 0 ? patch : 1)) * (W / (patch > 0 ? patch : 1)))
+    return ctx->fail(SEGVLAD_ERR_ARG, "describe: N=%d tokens do not match the %dx%d image at patch %d", N, H, W, patch);
+  const int S_tot = seg_offsets[B];
+  if (S_tot <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "describe: no segments");
+  StageScope whole(ctx, "describe");   // the stage as the stream sees it (its parts overlap: their times do not add up to it)
+  // ---- mask branch on the side stream: the same two calls, issued there -------------------------------------------------------
+  SV_TRY(sv_fork_side(ctx));
+  hipStream_t main_stream = ctx->stream;
+  ctx->stream = ctx->side;
+  int rc = incidence_impl(ctx, masks, S_tot, Hm, Wm, H, W, patch, inc_bits_out, centroids_out, true);
+  if (rc == SEGVLAD_OK) rc = adjacency_impl(ctx, centroids_out, seg_offsets, B, order, adj_out, nullptr, img_flags_out);
+  ctx->stream = main_stream;
+  if (rc != SEGVLAD_OK) {
+    (void)sv_join_side(ctx);   // (nothing of the branch stays behind on the side stream unobserved)
+    return rc;
+  }
+  ctx->mask_branch_on_side = true;   // images_impl joins in front of prep
+  rc = y ? images_pca_impl(ctx, tokens, B, N, inc_bits_out, seg_offsets, adj_out, y, l2norm, desc_out, nullptr, nullptr)
+         : images_impl(ctx, tokens, B, N, inc_bits_out, seg_offsets, adj_out, desc_out, nullptr, nullptr, nullptr, nullptr, 0);
+  if (ctx->mask_branch_on_side) {   // an early return in front of the join
+    ctx->mask_branch_on_side = false;
+    (void)sv_join_side(ctx);
+  }
+  return rc;
 }
 
 // ---- K-parametric aggregation of given residuals + labels (vlad_matmuls_per_cluster) --------------------

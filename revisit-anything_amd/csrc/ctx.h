@@ -212,6 +212,7 @@ struct segvlad_ctx {
   // `stream` behind an event and joined back before anything else is enqueued (sv_fork_side / sv_join_side); created on first use
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool mask_branch_on_side = false;   // segvlad_describe: incidence / adjacency are in flight on `side`; images_impl joins before prep
   char err[512] = {0};
   bool profiling = false;
   bool scope_mute = false;   // set while a redo / fallback pass runs: its inner stages are part of "knn_redo" / "knn_fallback" only

@@ -332,6 +332,45 @@ class SegVLADEngine:
             res["gap"] = gap
         return res
 
+    def describe(self, masks, tokens, seg_offsets: Sequence[int], H: int, W: int, patch: int = 14, order: int = 3, pca: bool = True,
+                 l2norm: bool = True, want_desc: bool = False) -> dict:
+        """segvlad_describe: the describe stage of a batch in one call -- incidence + centroids + device adjacency on the
+        context's side stream beside the token-assignment pass, then seg-VLAD (+ PCA).  Device tensors only.  Returns
+        dict(out=[S_tot,P] or [S_tot,K*D], bits, cent, adj, flags [B] uint8 on the device: bit 0 empty mask, bit 1 non-generic
+        centroids -- pipeline.py patches flagged images with Qhull), desc? with pca and want_desc."""
+        if self.K == 0:
+            raise SegVLADError("describe: set_vocab first")
+        if pca and self.P == 0:
+            raise SegVLADError("describe: pca_set first")
+        m = masks if masks.dtype == torch.uint8 else masks.to(torch.uint8)
+        m = m.contiguous()
+        t = tokens.to(torch.float32).contiguous()
+        if t.ndim == 2:
+            t = t[None]
+        B, D, N = t.shape
+        if D != self.D:
+            raise ValueError(f"tokens have D={D}, vocabulary has D={self.D}")
+        so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+        assert so.shape == (B + 1,)
+        S_tot = int(so[-1])
+        assert m.shape[0] == S_tot
+        sizes = (so[1:] - so[:-1]).astype(np.int64)
+        bits = self._empty((S_tot, (N + 63) // 64), torch.int64)
+        cent = self._empty((S_tot, 2), torch.float64)
+        adj = self._empty((int((sizes * sizes).sum()),), torch.uint8)
+        flags = self._empty((B,), torch.uint8)
+        y = self._empty((S_tot, self.P), torch.float32) if pca else None
+        desc = self._empty((S_tot, self.K * self.D), torch.float32) if (want_desc or not pca) else None
+        self._stream()
+        self._check(self.lib.segvlad_describe(self._h, _ptr(m), int(m.shape[1]), int(m.shape[2]), int(H), int(W), int(patch), _ptr(t), B, N,
+                                              _ptr(so), int(order), _ptr(bits), _ptr(cent), _ptr(adj), _ptr(flags), _ptr(desc), _ptr(y),
+                                              int(bool(l2norm))), "describe")
+        self._keep = [m, t]
+        res = {"out": y if pca else desc, "bits": bits, "cent": cent, "adj": adj, "flags": flags}
+        if pca and want_desc:
+            res["desc"] = desc
+        return res
+
     def cluster_aggregate(self, num_c: int, res, labels, inc_bits, adj=None) -> torch.Tensor:
         """vlad_matmuls_per_cluster surface: res [N,D] fp32 residuals, labels [N] (< num_c), inc_bits [S,nw]."""
         r = _as(res, np.float32, torch.float32)

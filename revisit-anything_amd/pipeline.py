@@ -65,6 +65,25 @@ class SegVLADPipeline:
         Returns [S_tot, P] (PCA'd, row-normalised when l2norm) or [S_tot, K*D]."""
         eng = self.eng
         lazy = None   # (device flags, centroids) of a device adjacency whose per-image flags have not been looked at yet
+        if (self.order and adj is None and not self.host_adjacency and self._eager_flags == 0 and hasattr(eng, "describe")
+                and isinstance(tokens, torch.Tensor) and tokens.is_cuda and isinstance(masks, torch.Tensor) and masks.is_cuda
+                and (self.fuse_pca or not self.use_pca)):
+            # ONE call: the mask branch (incidence + centroids -> adjacency) on the context's side stream beside the assignment
+            # pass (segvlad_describe).  The adjacency flags are read afterwards, exactly as in the lazy path below.
+            try:
+                r = eng.describe(masks, tokens, seg_offsets, self.H, self.W, self.patch, self.order, pca=self.use_pca, l2norm=l2norm)
+            except SegVLADError as e:
+                if e.code != SEGVLAD_ERR_LIMIT:   # (more segments in an image than the in-LDS Delaunay holds: the paths below)
+                    raise
+                r = None
+            if r is not None:
+                out, bits, adj_d = r["out"], r["bits"], r["adj"]
+                if self.check_empty:
+                    patched = self._check_flags(r["flags"], adj_d, r["cent"], seg_offsets)
+                    if patched is not adj_d:
+                        self._eager_flags = 16
+                        out = self._describe_with(tokens, bits, seg_offsets, patched, l2norm)
+                return out
         if self.order and adj is None:
             bits, cent = eng.incidence_centroids(masks, self.H, self.W, self.patch)   # one pass over the mask bytes
             if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)

@@ -1,0 +1,86 @@
+"""segvlad_describe (round 5): the describe stage of a batch in ONE call, with the mask branch (incidence + centroids ->
+adjacency) on the context's side stream beside the token-assignment pass.  It issues the SAME kernels as the separate entry
+points, so every output must equal theirs bit for bit -- ragged batches, PCA and raw descriptors, repeated calls (the side
+stream is forked and joined every time), and the pipeline's flag handling on top of it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(K=32, D=256, P=64, seed=0):
+    from revisit_anything_amd import synth
+    from revisit_anything_amd.engine import SegVLADEngine
+
+    eng = SegVLADEngine(0)
+    C = synth.make_vocab(K, D, seed=1000 + seed)
+    eng.set_vocab(C)
+    mean, comps, var = synth.make_pca_model(K * D, P, seed=5000 + seed)
+    eng.pca_set(mean, comps, var, whiten=True)
+    return eng, C
+
+
+def _batch(C, B, S_list, H, W, seed):
+    from revisit_anything_amd import synth
+
+    N = (H // 14) * (W // 14)
+    tok = np.stack([synth.make_tokens(C, N, seed=seed + b, noise=0.2) for b in range(B)])
+    masks = np.concatenate([synth.make_blob_masks(S_list[b], H // 2, W // 2, seed=seed + 100 + b) for b in range(B)])
+    off = np.concatenate([[0], np.cumsum(S_list)]).astype(np.int32)
+    return torch.from_numpy(tok).cuda(), torch.from_numpy(masks.astype(np.uint8)).cuda(), off
+
+
+@pytest.mark.parametrize("pca", [True, False])
+def test_describe_equals_the_separate_calls_bit_for_bit(pca):
+    eng, C = _setup()
+    H, W = 112, 140
+    for rep, S_list in enumerate(([12, 7, 15, 9], [5, 5, 5, 5, 5, 5], [20])):
+        tok, masks, off = _batch(C, len(S_list), S_list, H, W, seed=10 * rep)
+        bits, cent = eng.incidence_centroids(masks, H, W, 14)
+        adj, flags = eng.adjacency_flagged(cent, off, 3, device_flags=True)
+        ref = (eng.seg_vlad_pca(tok, bits, off, adj, l2norm=True) if pca else eng.seg_vlad(tok, bits, off, adj))["out"]
+        r = eng.describe(masks, tok, off, H, W, 14, 3, pca=pca, l2norm=True)
+        assert torch.equal(r["bits"], bits) and torch.equal(r["adj"], adj) and torch.equal(r["flags"], flags)
+        assert torch.equal(r["cent"].view(torch.int64), cent.view(torch.int64))
+        assert torch.equal(r["out"], ref)
+        r2 = eng.describe(masks, tok, off, H, W, 14, 3, pca=pca, l2norm=True)       # again: fork / join per call
+        assert torch.equal(r2["out"], ref)
+    eng.close()
+
+
+def test_pipeline_describe_through_the_fused_call_equals_the_stepwise_pipeline():
+    from revisit_anything_amd.pipeline import SegVLADPipeline
+
+    eng, C = _setup(seed=1)
+    H, W = 112, 140
+    tok, masks, off = _batch(C, 5, [9, 14, 6, 11, 8], H, W, seed=77)
+    fused = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True)
+    step = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True)
+    step._eager_flags = 10 ** 9          # keeps the stepwise path (flags read before describing)
+    a = fused.describe(tok, masks, off)
+    b = step.describe(tok, masks, off)
+    assert torch.equal(a, b)
+    # an empty mask is reported like before
+    masks2 = masks.clone()
+    masks2[3] = 0
+    with pytest.raises(ValueError):
+        fused.describe(tok, masks2, off)
+    eng.close()
+
+
+def test_describe_argument_errors():
+    from revisit_anything_amd._lib import SEGVLAD_ERR_ARG, SegVLADError
+
+    eng, C = _setup(seed=2)
+    H, W = 112, 140
+    tok, masks, off = _batch(C, 2, [4, 6], H, W, seed=5)
+    with pytest.raises(SegVLADError) as ei:
+        eng.describe(masks, tok, off, H, W, 14, 0)              # order 0 has no mask branch: segvlad_images(adj = NULL)
+    assert ei.value.code == SEGVLAD_ERR_ARG
+    with pytest.raises(SegVLADError) as ei:
+        eng.describe(masks, tok, off, H + 14, W, 14, 3)         # token grid does not match the image
+    assert ei.value.code == SEGVLAD_ERR_ARG
+    out = eng.describe(masks, tok, off, H, W, 14, 3)["out"]     # the context is still usable
+    assert torch.isfinite(out).all()
+    eng.close()
