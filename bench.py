@@ -449,6 +449,8 @@ def run(a, top=True):
     for e_ in {eng, eng_d}:
         e_.set_profiling(False)
     step_ms_events = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    print(f"[bench] adjacency flag checks so far {getattr(pipe, 'n_flag_checks', 0)}, flagged images {getattr(pipe, 'n_flagged_images', 0)}, "
+          f"eager countdown {pipe._eager_flags}", file=sys.stderr)
     pipelined = None
     if also_pipelined:   # the same K steps with describe(i+1) issued under search(i): same index, same inputs, same fences
         out_p = steps_pipelined(2)

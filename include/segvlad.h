@@ -135,6 +135,24 @@ int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
 int segvlad_describe(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B, int N,
                      const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
                      uint8_t* img_flags_out, float* desc_out, float* y, int l2norm);
+/*      The same stage as THREE calls, for a caller that patches flagged images with Qhull WHILE the device works:
+ *      segvlad_describe_begin   enqueues the mask branch (side stream; its flags and centroids are also copied to pinned host
+ *                               memory behind it) and the assignment pass (the context's stream), and returns.  pca != 0: the
+ *                               projected form will be asked of segvlad_describe_end (checked here).
+ *      segvlad_describe_flags   waits for the MASK BRANCH only -- the assignment pass keeps the device busy -- and hands the
+ *                               per-image flags [B] (and, if asked for, the centroids [S_tot][2]) to HOST buffers.
+ *      segvlad_describe_end     n_patch adjacency blocks recomputed by the caller (patch_images [n_patch] HOST, ascending image
+ *                               indices; patch_blocks HOST: their [S_b][S_b] byte matrices, concatenated) are written over the
+ *                               device's, then prep -> aggregation (-> projection) run: the result is that of segvlad_images[_pca]
+ *                               with the patched adjacency.  Same tokens / inc_bits / seg_offsets / adj buffers as in begin.
+ *      A begin must be followed by an end (flags is optional) before any other describe / images call on the context.       */
+int segvlad_describe_begin(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B,
+                           int N, const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
+                           uint8_t* img_flags_out, int pca);
+int segvlad_describe_flags(segvlad_ctx* ctx, uint8_t* flags_host, double* centroids_host);
+int segvlad_describe_end(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits, const int32_t* seg_offsets,
+                         uint8_t* adj, int n_patch, const int32_t* patch_images, const uint8_t* patch_blocks, float* desc_out, float* y,
+                         int l2norm);
 
 /* ---- the K-parametric entry: vlad_matmuls_per_cluster(num_c, masks, res, clus_labels, adjMat)
  *      func_vpr.py:1181-1210.  res [N][D] fp32 residuals (token-major, as the reference passes them),

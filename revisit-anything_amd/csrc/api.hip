@@ -354,6 +354,12 @@ int segvlad_destroy(segvlad_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);
   }
+  if (ctx->h_pin) {
+    (void)hipHostFree(ctx->h_pin);
+    (void)hipEventDestroy(ctx->ev_scalars);
+  }
+  if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+  if (ctx->ev_desc) (void)hipEventDestroy(ctx->ev_desc);
   ctx->for_each_buf([](DevBuf& b) { b.release(); });
   for (auto& kv : ctx->timers)
     for (hipEvent_t e : kv.second.ev)
@@ -547,9 +553,28 @@ int segvlad_adjacency_flagged(segvlad_ctx* ctx, const double* centroids, const i
 
 // ---- segment VLAD -----------------------------------------------------------------------------------
 // pca_y != NULL: fused projection (segvlad_images_pca); out may then be NULL
+// The assignment pass on its own (segvlad_describe_begin): its outputs -- token-major copy, norms, labels -- stay in the
+// context's scratch for images_impl(phase = 2).
+static int assign_phase(segvlad_ctx* ctx, const float* tokens, int B, int N) {
+  if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images: call segvlad_set_vocab first");
+  if (B <= 0 || N <= 0 || !tokens) return ctx->fail(SEGVLAD_ERR_ARG, "images: B=%d N=%d", B, N);
+  const int D = ctx->D;
+  const void* d_tok;
+  SV_TRY(sv_in(ctx, tokens, (size_t)B * D * N * sizeof(float), &d_tok));
+  SV_HIP(ctx->s_xt.reserve((size_t)B * N * D * sizeof(float)));
+  SV_HIP(ctx->s_rnorm.reserve((size_t)B * N * sizeof(float)));
+  SV_HIP(ctx->s_labels.reserve((size_t)B * N));
+  StageScope sc(ctx, "assign");
+  SV_TRY(sv_launch_assign(ctx, (const float*)d_tok, B, N, ctx->s_xt.as<float>(), ctx->s_labels.as<uint8_t>(), ctx->s_rnorm.as<float>(), nullptr));
+  sc.count();
+  return SEGVLAD_OK;
+}
+
+// phase 0: everything.  2: from `prep` on, the assignment pass having run in an earlier call (assign_phase, same tokens) -- its
+// outputs live in the context's scratch, every reservation below is idempotent.
 static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
                        const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out, float* gap_out,
-                       float* block_norms_out, float* pca_y, int l2norm) {
+                       float* block_norms_out, float* pca_y, int l2norm, int phase = 0) {
   if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images: call segvlad_set_vocab first");
   if (B < 0 || N <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "images: B=%d N=%d", B, N);
   if (B == 0) return SEGVLAD_OK;
@@ -644,7 +669,7 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
   // (pageable sources: the runtime stages them before hipMemcpyAsync returns, so the local vector
   //  and the caller's array may be reused as soon as this call returns)
 
-  {
+  if (phase != 2) {
     StageScope sc(ctx, "assign");
     SV_TRY(sv_launch_assign(ctx, (const float*)d_tok, B, N, ctx->s_xt.as<float>(), (uint8_t*)d_lab, ctx->s_rnorm.as<float>(),
                             (float*)d_gap));
@@ -733,7 +758,7 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
 
 static int images_pca_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits,
                            const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
-                           uint8_t* labels_out, float* gap_out) {
+                           uint8_t* labels_out, float* gap_out, int phase = 0) {
   if (ctx->P == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images_pca: call segvlad_pca_set first");
   if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "images_pca: call segvlad_set_vocab first");
   if (ctx->KD != ctx->K * ctx->D)
@@ -742,7 +767,8 @@ static int images_pca_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, 
   if (B > 0 && seg_offsets && !sv_is_device_ptr(seg_offsets) && seg_offsets[B] > 0 && !y)
     return ctx->fail(SEGVLAD_ERR_ARG, "images_pca: null y");
   const bool x3 = ctx->pca_w_scale > 0.f && !ctx->opt.pca_fp32;
-  if (x3) return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc_out, labels_out, gap_out, nullptr, y, l2norm);
+  if (x3) return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc_out, labels_out, gap_out, nullptr, y, l2norm, phase);
+  if (phase != 0) return ctx->fail(SEGVLAD_ERR_STATE, "describe: the split call needs the fp16x3 projection (pca_arith)");
   // shapes the split GEMM does not take (or the fp32 knob): descriptor to HBM, then the plain projection
   if (B <= 0 || !seg_offsets || sv_is_device_ptr(seg_offsets))
     return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc_out, labels_out, gap_out, nullptr, nullptr, 0);
@@ -768,43 +794,154 @@ int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
 // The mask branch (incidence + centroids -> adjacency: two latency-bound launches, 0.34 ms per 200 images) does not depend on
 // the tokens, the assignment pass (0.95 ms, HBM-bound) does not depend on the masks: the former runs on the context's side
 // stream BESIDE the latter and is joined in front of `prep`, the first kernel that needs both.
-int segvlad_describe(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B, int N,
-                     const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
-                     uint8_t* img_flags_out, float* desc_out, float* y, int l2norm) {
-  CHECK_CTX();
+static int describe_begin_impl(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B,
+                               int N, const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out,
+                               uint8_t* adj_out, uint8_t* img_flags_out, bool pca) {
+  if (ctx->mask_branch_on_side) return ctx->fail(SEGVLAD_ERR_STATE, "describe_begin: the previous describe_begin has no describe_end yet");
   if (B < 0 || order < 1) return ctx->fail(SEGVLAD_ERR_ARG, "describe: need B >= 0 and order >= 1");
-  if (B == 0) return SEGVLAD_OK;
-  if (!masks || !tokens || !seg_offsets || !inc_bits_out || !centroids_out || !adj_out || !img_flags_out || (!desc_out && !y))
+  if (!masks || !tokens || !seg_offsets || !inc_bits_out || !centroids_out || !adj_out || !img_flags_out)
     return ctx->fail(SEGVLAD_ERR_ARG, "describe: null pointer");
   if (sv_is_device_ptr(seg_offsets)) return ctx->fail(SEGVLAD_ERR_ARG, "describe: seg_offsets must be host memory");
-  const void* bulk[] = {masks, tokens, inc_bits_out, centroids_out, adj_out, img_flags_out, desc_out, y};
+  const void* bulk[] = {masks, tokens, inc_bits_out, centroids_out, adj_out, img_flags_out};
   for (const void* p : bulk)
-    if (p && !sv_is_device_ptr(p))
+    if (!sv_is_device_ptr(p))
       return ctx->fail(SEGVLAD_ERR_ARG, "describe: bulk pointers must be device memory (the separate entry points stage host data)");
-  if (N != (H / (patch > 0 ? patch : 1)) * (W / (patch > 0 ? patch : 1)))
+  if (patch <= 0 || N != (H / patch) * (W / patch))
     return ctx->fail(SEGVLAD_ERR_ARG, "describe: N=%d tokens do not match the %dx%d image at patch %d", N, H, W, patch);
-  const int S_tot = seg_offsets[B];
-  if (S_tot <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "describe: no segments");
-  StageScope whole(ctx, "describe");   // the stage as the stream sees it (its parts overlap: their times do not add up to it)
-  // ---- mask branch on the side stream: the same two calls, issued there -------------------------------------------------------
+  const int S_tot = B > 0 ? seg_offsets[B] : 0;
+  if (B == 0 || S_tot <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "describe: no images / no segments");
+  if (pca && (ctx->P == 0 || ctx->pca_w_scale <= 0.f || ctx->opt.pca_fp32))
+    return ctx->fail(SEGVLAD_ERR_STATE, "describe: needs segvlad_pca_set and the fp16x3 projection (pca_arith)");
+  // pinned landing zone of the flags and the centroids (read by segvlad_describe_flags while the assignment pass runs)
+  const size_t need = (size_t)B + (size_t)S_tot * 16 + 64;
+  if (need > ctx->h_desc_cap) {
+    if (ctx->h_desc) SV_HIP(hipHostFree(ctx->h_desc));
+    ctx->h_desc = nullptr;
+    ctx->h_desc_cap = 0;
+    SV_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_desc), need + need / 2, hipHostMallocDefault));
+    ctx->h_desc_cap = need + need / 2;
+  }
+  if (!ctx->ev_desc) SV_HIP(hipEventCreateWithFlags(&ctx->ev_desc, hipEventDisableTiming));
+  // stage "describe": from here to the end of segvlad_describe_end, as the context's stream sees it (the parts overlap)
+  ctx->desc_timer = nullptr;
+  if (ctx->profiling && !ctx->scope_mute) {
+    StageTimer* t = &ctx->timers["describe"];
+    if (t->used * 2 >= (int)t->ev.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      t->ev.push_back(a);
+      t->ev.push_back(b);
+    }
+    ctx->desc_slot = t->used++;
+    ctx->desc_timer = t;
+    (void)hipEventRecord(t->ev[2 * ctx->desc_slot], ctx->stream);
+  }
+  // ---- mask branch on the side stream: the same two calls as the separate entry points, issued there -----------------------
   SV_TRY(sv_fork_side(ctx));
   hipStream_t main_stream = ctx->stream;
   ctx->stream = ctx->side;
   int rc = incidence_impl(ctx, masks, S_tot, Hm, Wm, H, W, patch, inc_bits_out, centroids_out, true);
   if (rc == SEGVLAD_OK) rc = adjacency_impl(ctx, centroids_out, seg_offsets, B, order, adj_out, nullptr, img_flags_out);
+  if (rc == SEGVLAD_OK) {
+    hipError_t e = hipMemcpyAsync(ctx->h_desc, img_flags_out, (size_t)B, hipMemcpyDeviceToHost, ctx->side);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(ctx->h_desc + (((size_t)B + 63) & ~(size_t)63), centroids_out, (size_t)S_tot * 16, hipMemcpyDeviceToHost, ctx->side);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_desc, ctx->side);
+    if (e != hipSuccess) rc = ctx->fail(SEGVLAD_ERR_HIP, "describe: flags read-back: %s", hipGetErrorString(e));
+  }
   ctx->stream = main_stream;
   if (rc != SEGVLAD_OK) {
     (void)sv_join_side(ctx);   // (nothing of the branch stays behind on the side stream unobserved)
     return rc;
   }
-  ctx->mask_branch_on_side = true;   // images_impl joins in front of prep
-  rc = y ? images_pca_impl(ctx, tokens, B, N, inc_bits_out, seg_offsets, adj_out, y, l2norm, desc_out, nullptr, nullptr)
-         : images_impl(ctx, tokens, B, N, inc_bits_out, seg_offsets, adj_out, desc_out, nullptr, nullptr, nullptr, nullptr, 0);
-  if (ctx->mask_branch_on_side) {   // an early return in front of the join
+  ctx->mask_branch_on_side = true;   // images_impl (phase 2 / 0) joins in front of prep
+  ctx->desc_B = B;
+  ctx->desc_S = S_tot;
+  // ---- main stream: the assignment pass -------------------------------------------------------------------------------------------
+  rc = assign_phase(ctx, tokens, B, N);
+  if (rc != SEGVLAD_OK) {
     ctx->mask_branch_on_side = false;
     (void)sv_join_side(ctx);
   }
   return rc;
+}
+
+int segvlad_describe_begin(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B,
+                           int N, const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
+                           uint8_t* img_flags_out, int pca) {
+  CHECK_CTX();
+  return describe_begin_impl(ctx, masks, Hm, Wm, H, W, patch, tokens, B, N, seg_offsets, order, inc_bits_out, centroids_out, adj_out,
+                             img_flags_out, pca != 0);
+}
+
+int segvlad_describe_flags(segvlad_ctx* ctx, uint8_t* flags_host, double* centroids_host) {
+  CHECK_CTX();
+  if (!ctx->mask_branch_on_side) return ctx->fail(SEGVLAD_ERR_STATE, "describe_flags: call segvlad_describe_begin first");
+  if (!flags_host) return ctx->fail(SEGVLAD_ERR_ARG, "describe_flags: null pointer");
+  SV_HIP(hipEventSynchronize(ctx->ev_desc));   // the MASK BRANCH only: the assignment pass on the main stream keeps running
+  memcpy(flags_host, ctx->h_desc, (size_t)ctx->desc_B);
+  if (centroids_host) memcpy(centroids_host, ctx->h_desc + (((size_t)ctx->desc_B + 63) & ~(size_t)63), (size_t)ctx->desc_S * 16);
+  return SEGVLAD_OK;
+}
+
+int segvlad_describe_end(segvlad_ctx* ctx, const float* tokens, int B, int N, const uint64_t* inc_bits, const int32_t* seg_offsets,
+                         uint8_t* adj, int n_patch, const int32_t* patch_images, const uint8_t* patch_blocks, float* desc_out, float* y,
+                         int l2norm) {
+  CHECK_CTX();
+  if (!ctx->mask_branch_on_side) return ctx->fail(SEGVLAD_ERR_STATE, "describe_end: call segvlad_describe_begin first");
+  auto bail = [&](int rc) {   // leaves the context usable: the mask branch is joined, the split call is over
+    if (ctx->desc_timer) {
+      (void)hipEventRecord(ctx->desc_timer->ev[2 * ctx->desc_slot + 1], ctx->stream);
+      ctx->desc_timer = nullptr;
+    }
+    ctx->mask_branch_on_side = false;
+    (void)sv_join_side(ctx);
+    return rc;
+  };
+  if (!tokens || !inc_bits || !seg_offsets || !adj || (!desc_out && !y) || B != ctx->desc_B || seg_offsets[B] != ctx->desc_S ||
+      n_patch < 0 || (n_patch > 0 && (!patch_images || !patch_blocks)))
+    return bail(ctx->fail(SEGVLAD_ERR_ARG, "describe_end: arguments do not match segvlad_describe_begin's"));
+  if (n_patch > 0) {
+    // adjacency blocks the caller recomputed on the host (Qhull, for images whose centroids are in a non-generic configuration):
+    // written over the device kernel's behind the mask branch, in front of prep
+    if (sv_join_side(ctx) != SEGVLAD_OK) return bail(SEGVLAD_ERR_HIP);
+    std::vector<int64_t> aoff((size_t)B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+      const int64_t sb = seg_offsets[b + 1] - seg_offsets[b];
+      aoff[(size_t)b + 1] = aoff[(size_t)b] + sb * sb;
+    }
+    size_t src = 0;
+    for (int j = 0; j < n_patch; ++j) {
+      const int b = patch_images[j];
+      if (b < 0 || b >= B) return bail(ctx->fail(SEGVLAD_ERR_ARG, "describe_end: patch image %d out of range", b));
+      const size_t bytes = (size_t)(aoff[(size_t)b + 1] - aoff[(size_t)b]);
+      const hipError_t e = hipMemcpyAsync(adj + aoff[(size_t)b], patch_blocks + src, bytes, hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) return bail(ctx->fail(SEGVLAD_ERR_HIP, "describe_end: adjacency patch: %s", hipGetErrorString(e)));
+      src += bytes;
+    }
+  }
+  const int rc = y ? images_pca_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, y, l2norm, desc_out, nullptr, nullptr, 2)
+                   : images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, desc_out, nullptr, nullptr, nullptr, nullptr, 0, 2);
+  if (ctx->desc_timer) {
+    (void)hipEventRecord(ctx->desc_timer->ev[2 * ctx->desc_slot + 1], ctx->stream);
+    ctx->desc_timer->launches += 1;
+    ctx->desc_timer = nullptr;
+  }
+  if (ctx->mask_branch_on_side) return bail(rc);   // an early return in front of the join
+  return rc;
+}
+
+int segvlad_describe(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B, int N,
+                     const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
+                     uint8_t* img_flags_out, float* desc_out, float* y, int l2norm) {
+  CHECK_CTX();
+  if (!desc_out && !y) return ctx->fail(SEGVLAD_ERR_ARG, "describe: null pointer");
+  if ((desc_out && !sv_is_device_ptr(desc_out)) || (y && !sv_is_device_ptr(y)))
+    return ctx->fail(SEGVLAD_ERR_ARG, "describe: bulk pointers must be device memory (the separate entry points stage host data)");
+  SV_TRY(describe_begin_impl(ctx, masks, Hm, Wm, H, W, patch, tokens, B, N, seg_offsets, order, inc_bits_out, centroids_out, adj_out,
+                             img_flags_out, y != nullptr));
+  return segvlad_describe_end(ctx, tokens, B, N, inc_bits_out, seg_offsets, adj_out, 0, nullptr, nullptr, desc_out, y, l2norm);
 }
 
 // ---- K-parametric aggregation of given residuals + labels (vlad_matmuls_per_cluster) --------------------
@@ -1121,7 +1258,10 @@ static int heur_rank_small(int target, int ratio, double pfail) {
 // chunk); rovf_rows_in [m]: second-tier flags, zero on entry; n_rovf_seen: the caller's copy of fail_count[1] so far.
 static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, const float* qp, const uint16_t* q16a,
                         const uint16_t* q16b, const float* qn, int m, float* out_d2, int64_t* out_idx, uint32_t* fail_rows,
-                        uint32_t* fail_count, uint32_t* rovf_rows_in, uint32_t* n_fail_host, uint32_t* n_rovf_seen) {
+                        uint32_t* fail_count, uint32_t* rovf_rows_in, uint32_t* n_fail_host, uint32_t* n_rovf_seen, int phase = 0) {
+  // phase 0: the whole pass.  1: the exact sample level only; 2: everything behind it -- a batch search enqueues phase 1 (which
+  // needs neither the query plane nor the filter's margin) BEFORE it waits for the two scalars that fix them, so that the device
+  // has that level to run while the host waits (m > 128 only: the single-image plan's fused level 0 is one chain with its pass)
   const int d = pl.d, k = pl.k, levels = pl.levels;
   const int64_t n = pl.n;
   const float* R = ctx->db_rows.as<float>();
@@ -1150,7 +1290,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   const uint32_t* poison_dev = nullptr;   // see sv_launch_refine_exact
   const int r0 = rank[0];
   bool l0_fused = false;
-  {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
+  if (phase != 2) {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
       StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
       if (m <= 128 && n0 <= 4096 && pl.kind != 3) {
@@ -1184,6 +1324,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     }
     if (!l0_fused) sc.count();
   }
+  if (phase == 1) return SEGVLAD_OK;
   const bool l0_small = n0 <= 4096 && pl.kind != 3;
   const float* thr_ptr = l0_small ? thr : thr + (r0 - 1);
   int64_t thr_ld = l0_small ? 1 : r0;
@@ -1476,6 +1617,30 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // flag block: [nq] row flags, 2 counts (flagged, second-tier), [mrows] second-tier flags of the current chunk -- one fill
   const size_t ovf_bytes = (((size_t)nq + 2 + mrows) * 4 + 255) & ~(size_t)255;   // (a whole number of 256-byte blocks: one fill kernel)
   bool ovf_zeroed = false;
+  // the per-chunk scratch and the flag block, reserved (and the flags zeroed) once -- by the early exact level of a batch
+  // search (below) or in front of the chunk loop
+  bool scratch_ready = false, level0_done = false;
+  const bool heuristic_pre = heuristic;
+  SearchPlan plh_pre = plh;
+  auto reserve_scratch = [&]() -> int {
+    if (scratch_ready) return SEGVLAD_OK;
+    SV_HIP(ctx->s_cand_cnt.reserve(mrows * 4));
+    SV_HIP(ctx->s_cand_d2.reserve(mrows * SV_CAP * 4));
+    SV_HIP(ctx->s_cand_id.reserve(mrows * SV_CAP * 4));
+    SV_HIP(ctx->s_thr_d2.reserve(mrows * k * 4));
+    SV_HIP(ctx->s_thr_idx.reserve(mrows * k * 8));
+    // the exact level's distance block: the larger of the two plans' samples (the single-image plan's stride can be SMALLER than
+    // the rigorous plan's: 64 against 256 for a 250 k-row shard)
+    const int64_t stride_min = heuristic ? std::min(pl.stride0, plh.stride0) : pl.stride0;
+    const int64_t n0 = (n + stride_min - 1) / stride_min;
+    SV_HIP(ctx->s_dist.reserve(mrows * ((n0 + 3) & ~3ll) * 4));
+    // layout: [nq] row flags, 2 counts (flagged, second-tier), [mrows] second-tier flags of the current chunk -- one memset
+    SV_HIP(ctx->s_ovf.reserve(ovf_bytes));
+    if (!ovf_zeroed) SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ovf_bytes, ctx->stream));
+    ovf_zeroed = true;
+    scratch_ready = true;
+    return SEGVLAD_OK;
+  };
   if (f16_path || bf16_path) {
     if (ctx->db_rn_max_rows < n) {
       float m = 0.f;
@@ -1525,7 +1690,17 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       SV_TRY(ensure_qn());
       float qmax = 0.f;
       if (want_q2min) {   // both scalars behind one read-back
-        SV_TRY(sv_maxabs_and_norm_min(ctx, (const float*)dq, (int64_t)nq * d, qn, nq, &qmax, &q2min_pre));
+        SV_TRY(sv_maxabs_and_norm_min_begin(ctx, (const float*)dq, (int64_t)nq * d, qn, nq));
+        // the exact sample level of the first chunk goes out BEFORE the host waits for the two scalars: it needs neither the
+        // query plane nor the margin they fix, and the device runs it while the host round trip is under way (round 5; the
+        // wait used to leave the device idle in front of every batch search)
+        if (heuristic_pre && nq > 128 && ctx->opt.debug_search == 0) {
+          SV_TRY(reserve_scratch());
+          SV_TRY(levels_chunk(ctx, plh_pre, true, (const float*)dq, nullptr, nullptr, qn, std::min(nq, SV_CHUNK), nullptr, nullptr,
+                              ctx->s_ovf.as<uint32_t>(), ctx->s_ovf.as<uint32_t>() + nq, nullptr, nullptr, nullptr, 1));
+          level0_done = true;
+        }
+        SV_TRY(sv_maxabs_and_norm_min_end(ctx, (int64_t)nq * d, nq, &qmax, &q2min_pre));
         have_q2min = true;
       } else {
         SV_TRY(sv_maxabs(ctx, (const float*)dq, (int64_t)nq * d, &qmax));
@@ -1568,24 +1743,15 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_TRY(sv_launch_split_bf16(ctx, (const float*)dq, (int64_t)nq * d, ctx->s_qh.as<uint16_t>(), ctx->s_ql.as<uint16_t>()));
   }
   SV_TRY(ensure_qn());   // (every path that has not produced the norms on its way)
-  SV_HIP(ctx->s_cand_cnt.reserve(mrows * 4));
-  SV_HIP(ctx->s_cand_d2.reserve(mrows * SV_CAP * 4));
-  SV_HIP(ctx->s_cand_id.reserve(mrows * SV_CAP * 4));
-  SV_HIP(ctx->s_thr_d2.reserve(mrows * k * 4));
-  SV_HIP(ctx->s_thr_idx.reserve(mrows * k * 8));
-  // the exact level's distance block: the larger of the two plans' samples (the single-image plan's stride can be SMALLER than
-  // the rigorous plan's: 64 against 256 for a 250 k-row shard)
-  const int64_t stride_min = heuristic ? std::min(pl.stride0, plh.stride0) : pl.stride0;
-  const int64_t n0 = (n + stride_min - 1) / stride_min;
-  SV_HIP(ctx->s_dist.reserve(mrows * ((n0 + 3) & ~3ll) * 4));
+  if (ovf_zeroed && !scratch_ready) {   // (the single-image query preparation zeroed the flag block in its own launch)
+    SV_HIP(ctx->s_ovf.reserve(ovf_bytes));
+  }
+  SV_TRY(reserve_scratch());
   // Flags: [nq] rows + 1 count.  A heuristic pass flags the queries whose low-rank thresholds did not verify (-> redo
   // with the rigorous thresholds, below); a rigorous pass flags list overflows (-> exact distance-matrix path, alone).
   plh.c_eps = pl.c_eps;
   plh.inv_scale = pl.inv_scale;
   plh.rn_max = pl.rn_max;
-  // layout: [nq] row flags, 2 counts (flagged, second-tier), [mrows] second-tier flags of the current chunk -- one memset
-  SV_HIP(ctx->s_ovf.reserve(ovf_bytes));
-  if (!ovf_zeroed) SV_HIP(hipMemsetAsync(ctx->s_ovf.p, 0, ovf_bytes, ctx->stream));
   uint32_t* flag_rows = ctx->s_ovf.as<uint32_t>();
   uint32_t* flag_count = flag_rows + nq;
   uint32_t* rovf_flags = flag_count + 2;
@@ -1600,7 +1766,8 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_TRY(levels_chunk(ctx, heuristic ? plh : pl, heuristic, (const float*)dq + (size_t)q0 * d,
                         pl.kind == 3 ? nullptr : plane_a(ctx->s_qf16, ctx->s_qh, q0),
                         pl.kind == 2 ? ctx->s_ql.as<uint16_t>() + (size_t)q0 * d : nullptr, qn + q0, m, (float*)dd2 + (size_t)q0 * k,
-                        (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count, rovf_flags, &n_flag, &n_rovf_seen));
+                        (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count, rovf_flags, &n_flag, &n_rovf_seen,
+                        (q0 == 0 && level0_done) ? 2 : 0));
   }
   if (n_flag && !heuristic) {
     int nf = 0;

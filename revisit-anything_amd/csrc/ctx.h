@@ -212,6 +212,14 @@ struct segvlad_ctx {
   // `stream` behind an event and joined back before anything else is enqueued (sv_fork_side / sv_join_side); created on first use
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  uint32_t* h_pin = nullptr;          // 64 pinned bytes: scalars read back behind an event instead of a stream synchronisation
+  hipEvent_t ev_scalars = nullptr;
+  unsigned char* h_desc = nullptr;    // pinned: the per-image flags and the centroids of a segvlad_describe_begin
+  size_t h_desc_cap = 0;
+  hipEvent_t ev_desc = nullptr;       // behind their copies on the side stream
+  int desc_B = 0, desc_S = 0;
+  StageTimer* desc_timer = nullptr;   // the "describe" stage's open event pair (begin -> end)
+  int desc_slot = 0;
   bool mask_branch_on_side = false;   // segvlad_describe: incidence / adjacency are in flight on `side`; images_impl joins before prep
   char err[512] = {0};
   bool profiling = false;
@@ -413,6 +421,8 @@ int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_
 int sv_maxabs(segvlad_ctx* ctx, const float* x, int64_t n, float* out_host);
 int sv_maxabs_and_norm_min(segvlad_ctx* ctx, const float* x, int64_t n, const float* norms, int64_t n_norms, float* maxabs_host,
                            float* norm_min_host);
+int sv_maxabs_and_norm_min_begin(segvlad_ctx* ctx, const float* x, int64_t n, const float* norms, int64_t n_norms);
+int sv_maxabs_and_norm_min_end(segvlad_ctx* ctx, int64_t n, int64_t n_norms, float* maxabs_host, float* norm_min_host);
 // gemm_f16x3_kernels.hip
 int sv_launch_split_f16x2(segvlad_ctx* ctx, const float* X, int64_t n_rows, int d, const float* sub, float scale, uint16_t* h1,
                           uint16_t* h2);

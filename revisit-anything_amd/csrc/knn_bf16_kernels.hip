@@ -3053,6 +3053,42 @@ int sv_maxabs_and_norm_min(segvlad_ctx* ctx, const float* x, int64_t n, const fl
   return SEGVLAD_OK;
 }
 
+// The same two scalars WITHOUT the wait in between: _begin enqueues the reductions and the copy into pinned words of the
+// context and records an event behind them; _end blocks on that event only.  What the caller enqueues between the two runs on
+// the device while the host waits.
+int sv_maxabs_and_norm_min_begin(segvlad_ctx* ctx, const float* x, int64_t n, const float* norms, int64_t n_norms) {
+  SV_HIP(ctx->s_minmax.reserve(32));
+  if (!ctx->h_pin) {
+    SV_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), 64, hipHostMallocDefault));
+    SV_HIP(hipEventCreateWithFlags(&ctx->ev_scalars, hipEventDisableTiming));
+  }
+  uint32_t* mm = ctx->s_minmax.as<uint32_t>() + 4;   // [4] = max |x| bits (init 0), [5] = min key (init all ones)
+  static const uint32_t init[2] = {0u, 0xffffffffu};
+  SV_HIP(hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, ctx->stream));
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (n > 0) hipLaunchKernelGGL(maxabs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, n, mm);
+  int nb = (int)((n_norms + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  if (n_norms > 0) hipLaunchKernelGGL(min_kernel, dim3(nb), dim3(256), 0, ctx->stream, norms, n_norms, mm + 1);
+  SV_HIP(hipGetLastError());
+  SV_HIP(hipMemcpyAsync(ctx->h_pin, mm, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SV_HIP(hipEventRecord(ctx->ev_scalars, ctx->stream));
+  return SEGVLAD_OK;
+}
+
+int sv_maxabs_and_norm_min_end(segvlad_ctx* ctx, int64_t n, int64_t n_norms, float* maxabs_host, float* norm_min_host) {
+  SV_HIP(hipEventSynchronize(ctx->ev_scalars));
+  const uint32_t h0 = ctx->h_pin[0], h1 = ctx->h_pin[1];
+  memcpy(maxabs_host, &h0, 4);
+  if (n <= 0) *maxabs_host = 0.f;
+  const uint32_t u = (h1 & 0x80000000u) ? (h1 & 0x7fffffffu) : ~h1;
+  float f;
+  memcpy(&f, &u, 4);
+  *norm_min_host = (n_norms > 0 && h1 != 0xffffffffu) ? f : 0.f;
+  return SEGVLAD_OK;
+}
+
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host) {
   SV_HIP(ctx->s_minmax.reserve(16));
   uint32_t* mm = ctx->s_minmax.as<uint32_t>() + 2;

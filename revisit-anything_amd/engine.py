@@ -371,6 +371,67 @@ class SegVLADEngine:
             res["desc"] = desc
         return res
 
+    # ---- the same stage as begin / flags / end: the caller patches flagged images with Qhull WHILE the assignment pass runs ----
+    def describe_begin(self, masks, tokens, seg_offsets: Sequence[int], H: int, W: int, patch: int = 14, order: int = 3,
+                       pca: bool = True) -> dict:
+        """segvlad_describe_begin: enqueues the mask branch (side stream) and the assignment pass, returns the handle
+        describe_flags / describe_end take (it owns the intermediates: bits, cent, adj, flags)."""
+        if self.K == 0:
+            raise SegVLADError("describe: set_vocab first")
+        if pca and self.P == 0:
+            raise SegVLADError("describe: pca_set first")
+        m = (masks if masks.dtype == torch.uint8 else masks.to(torch.uint8)).contiguous()
+        t = tokens.to(torch.float32).contiguous()
+        if t.ndim == 2:
+            t = t[None]
+        B, D, N = t.shape
+        if D != self.D:
+            raise ValueError(f"tokens have D={D}, vocabulary has D={self.D}")
+        so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+        assert so.shape == (B + 1,) and m.shape[0] == int(so[-1])
+        S_tot = int(so[-1])
+        sizes = (so[1:] - so[:-1]).astype(np.int64)
+        h = {"m": m, "t": t, "so": so, "B": B, "N": N, "S_tot": S_tot, "pca": bool(pca), "order": int(order),
+             "bits": self._empty((S_tot, (N + 63) // 64), torch.int64), "cent": self._empty((S_tot, 2), torch.float64),
+             "adj": self._empty((int((sizes * sizes).sum()),), torch.uint8), "flags": self._empty((B,), torch.uint8)}
+        self._stream()
+        self._check(self.lib.segvlad_describe_begin(self._h, _ptr(m), int(m.shape[1]), int(m.shape[2]), int(H), int(W), int(patch), _ptr(t),
+                                                    B, N, _ptr(so), int(order), _ptr(h["bits"]), _ptr(h["cent"]), _ptr(h["adj"]),
+                                                    _ptr(h["flags"]), int(bool(pca))), "describe_begin")
+        return h
+
+    def describe_flags(self, h: dict):
+        """segvlad_describe_flags: (flags [B] uint8, centroids [S_tot,2] fp64) on the HOST; waits for the mask branch only."""
+        flags = np.empty(h["B"], np.uint8)
+        cent = np.empty((h["S_tot"], 2), np.float64)
+        self._check(self.lib.segvlad_describe_flags(self._h, flags.ctypes.data_as(C.c_void_p), cent.ctypes.data_as(C.c_void_p)),
+                    "describe_flags")
+        return flags, cent
+
+    def describe_cancel(self, h: dict):
+        """Ends a describe_begin without results (the mask branch is joined, the context is usable again)."""
+        self.lib.segvlad_describe_end(self._h, _ptr(h["t"]), h["B"], h["N"], _ptr(h["bits"]), _ptr(h["so"]), _ptr(h["adj"]), 0, None, None,
+                                      None, None, 0)
+
+    def describe_end(self, h: dict, patch_images=None, patch_blocks=None, l2norm: bool = True, want_desc: bool = False) -> dict:
+        """segvlad_describe_end: patch_images (ascending image indices) / patch_blocks (their [S_b,S_b] uint8 adjacency matrices,
+        host arrays) replace the device adjacency of those images; then prep -> aggregation (-> projection)."""
+        pca = h["pca"]
+        y = self._empty((h["S_tot"], self.P), torch.float32) if pca else None
+        desc = self._empty((h["S_tot"], self.K * self.D), torch.float32) if (want_desc or not pca) else None
+        n_patch = 0 if patch_images is None else len(patch_images)
+        pi = pb = None
+        if n_patch:
+            pi = np.ascontiguousarray(patch_images, dtype=np.int32)
+            pb = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.uint8).reshape(-1) for b in patch_blocks]))
+        self._stream()
+        self._check(self.lib.segvlad_describe_end(self._h, _ptr(h["t"]), h["B"], h["N"], _ptr(h["bits"]), _ptr(h["so"]), _ptr(h["adj"]),
+                                                  n_patch, _ptr(pi), _ptr(pb), _ptr(desc), _ptr(y), int(bool(l2norm))), "describe_end")
+        res = {"out": y if pca else desc, "bits": h["bits"], "cent": h["cent"], "adj": h["adj"], "flags": h["flags"]}
+        if pca and want_desc:
+            res["desc"] = desc
+        return res
+
     def cluster_aggregate(self, num_c: int, res, labels, inc_bits, adj=None) -> torch.Tensor:
         """vlad_matmuls_per_cluster surface: res [N,D] fp32 residuals, labels [N] (< num_c), inc_bits [S,nw]."""
         r = _as(res, np.float32, torch.float32)

@@ -65,25 +65,37 @@ class SegVLADPipeline:
         Returns [S_tot, P] (PCA'd, row-normalised when l2norm) or [S_tot, K*D]."""
         eng = self.eng
         lazy = None   # (device flags, centroids) of a device adjacency whose per-image flags have not been looked at yet
-        if (self.order and adj is None and not self.host_adjacency and self._eager_flags == 0 and hasattr(eng, "describe")
+        if (self.order and adj is None and not self.host_adjacency and hasattr(eng, "describe_begin")
                 and isinstance(tokens, torch.Tensor) and tokens.is_cuda and isinstance(masks, torch.Tensor) and masks.is_cuda
                 and (self.fuse_pca or not self.use_pca)):
-            # ONE call: the mask branch (incidence + centroids -> adjacency) on the context's side stream beside the assignment
-            # pass (segvlad_describe).  The adjacency flags are read afterwards, exactly as in the lazy path below.
+            # THREE calls (segvlad_describe_begin / _flags / _end): the mask branch (incidence + centroids -> adjacency) runs on the
+            # context's side stream beside the assignment pass; its per-image flags and centroids reach the host while that pass
+            # keeps the device busy, so an empty mask is reported, and the images with a non-generic centroid configuration get
+            # Qhull's adjacency (the reference's own library, ~0.2 ms of host work per image), WITHOUT an idle device -- rounds 3-4
+            # read the flags between two launches (a synchronisation in the middle of the stage) or described the batch twice.
             try:
-                r = eng.describe(masks, tokens, seg_offsets, self.H, self.W, self.patch, self.order, pca=self.use_pca, l2norm=l2norm)
+                h = eng.describe_begin(masks, tokens, seg_offsets, self.H, self.W, self.patch, self.order, pca=self.use_pca)
             except SegVLADError as e:
                 if e.code != SEGVLAD_ERR_LIMIT:   # (more segments in an image than the in-LDS Delaunay holds: the paths below)
                     raise
-                r = None
-            if r is not None:
-                out, bits, adj_d = r["out"], r["bits"], r["adj"]
+                h = None
+            if h is not None:
+                imgs, blocks = None, None
                 if self.check_empty:
-                    patched = self._check_flags(r["flags"], adj_d, r["cent"], seg_offsets)
-                    if patched is not adj_d:
-                        self._eager_flags = 16
-                        out = self._describe_with(tokens, bits, seg_offsets, patched, l2norm)
-                return out
+                    flags, cent = eng.describe_flags(h)
+                    if (flags & 1).any():
+                        eng.describe_cancel(h)
+                        raise ValueError(f"{int((flags & 1).sum())} image(s) with an empty mask: centroid undefined")
+                    imgs = np.nonzero(flags & 2)[0]
+                    self.n_flag_checks = getattr(self, "n_flag_checks", 0) + 1
+                    self.n_flagged_images = getattr(self, "n_flagged_images", 0) + int(len(imgs))
+                    so = np.asarray(seg_offsets)
+                    try:
+                        blocks = [adjacency_from_centroids(cent[so[b]:so[b + 1]], self.order).numpy().astype(np.uint8) for b in imgs]
+                    except Exception:
+                        eng.describe_cancel(h)
+                        raise
+                return eng.describe_end(h, imgs, blocks, l2norm=l2norm)["out"]
         if self.order and adj is None:
             bits, cent = eng.incidence_centroids(masks, self.H, self.W, self.patch)   # one pass over the mask bytes
             if self.host_adjacency:   # scipy/Qhull on the host, exactly the reference's library (slow: ~0.4 ms/image)
@@ -132,6 +144,8 @@ class SegVLADPipeline:
         if (flags & 1).any():
             raise ValueError(f"{int((flags & 1).sum())} image(s) with an empty mask: centroid undefined")
         bad = np.nonzero(flags & 2)[0]
+        self.n_flag_checks = getattr(self, "n_flag_checks", 0) + 1
+        self.n_flagged_images = getattr(self, "n_flagged_images", 0) + int(len(bad))
         if len(bad):
             return self._patch_with_qhull(adj.clone(), cent, np.asarray(seg_offsets), bad)
         return adj

@@ -56,8 +56,7 @@ def test_pipeline_describe_through_the_fused_call_equals_the_stepwise_pipeline()
     H, W = 112, 140
     tok, masks, off = _batch(C, 5, [9, 14, 6, 11, 8], H, W, seed=77)
     fused = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True)
-    step = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True)
-    step._eager_flags = 10 ** 9          # keeps the stepwise path (flags read before describing)
+    step = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True, host_adjacency=True)   # Qhull for every image, stepwise calls
     a = fused.describe(tok, masks, off)
     b = step.describe(tok, masks, off)
     assert torch.equal(a, b)
@@ -83,4 +82,41 @@ def test_describe_argument_errors():
     assert ei.value.code == SEGVLAD_ERR_ARG
     out = eng.describe(masks, tok, off, H, W, 14, 3)["out"]     # the context is still usable
     assert torch.isfinite(out).all()
+    eng.close()
+
+
+def test_split_describe_with_patched_adjacency_equals_images_pca_on_the_patched_adjacency():
+    """begin / flags / end: the flags and centroids reach the host while the assignment pass runs; blocks handed to `end`
+    replace the device adjacency of their images, and the result is segvlad_images_pca's on that adjacency."""
+    from revisit_anything_amd.func_vpr import adjacency_from_centroids
+
+    eng, C = _setup(seed=3)
+    H, W = 112, 140
+    S_list = [9, 13, 7, 10]
+    tok, masks, off = _batch(C, 4, S_list, H, W, seed=31)
+    bits, cent = eng.incidence_centroids(masks, H, W, 14)
+    adj, flags = eng.adjacency_flagged(cent, off, 3, device_flags=True)
+    h = eng.describe_begin(masks, tok, off, H, W, 14, 3, pca=True)
+    f_host, c_host = eng.describe_flags(h)
+    assert np.array_equal(f_host, flags.cpu().numpy()) and np.array_equal(c_host, cent.cpu().numpy())
+    # patch images 1 and 3 with ANOTHER adjacency (order 1 instead of 3: visibly different descriptors)
+    imgs = [1, 3]
+    blocks = [adjacency_from_centroids(c_host[off[b]:off[b + 1]], 1).numpy().astype(np.uint8) for b in imgs]
+    out = eng.describe_end(h, imgs, blocks, l2norm=True)["out"]
+    adj2 = adj.clone()
+    aoff = np.concatenate([[0], np.cumsum(np.asarray(S_list) ** 2)])
+    for b, blk in zip(imgs, blocks):
+        adj2[int(aoff[b]):int(aoff[b + 1])] = torch.from_numpy(blk.reshape(-1)).cuda()
+    ref = eng.seg_vlad_pca(tok, bits, off, adj2, l2norm=True)["out"]
+    assert torch.equal(out, ref)
+    assert not torch.equal(out, eng.seg_vlad_pca(tok, bits, off, adj, l2norm=True)["out"])
+    # a begin without an end is refused, a cancel frees the context
+    h2 = eng.describe_begin(masks, tok, off, H, W, 14, 3, pca=True)
+    from revisit_anything_amd._lib import SEGVLAD_ERR_STATE, SegVLADError
+
+    with pytest.raises(SegVLADError) as ei:
+        eng.describe_begin(masks, tok, off, H, W, 14, 3, pca=True)
+    assert ei.value.code == SEGVLAD_ERR_STATE
+    eng.describe_cancel(h2)
+    assert torch.equal(eng.describe(masks, tok, off, H, W, 14, 3)["out"], eng.seg_vlad_pca(tok, bits, off, adj, l2norm=True)["out"])
     eng.close()
