@@ -904,6 +904,8 @@ def shard_sim(a, W):
     q_off_l, q_off_all = (np.arange(nQ_l + 1) * S).astype(np.int32), (np.arange(nQ + 1) * S).astype(np.int32)
     kv = 50
 
+    eng.hint_query_groups(q_off_all)   # (what ShardedSegmentIndex.retrieve tells the engine: an image's rows as one refinement group)
+
     def rank_step():
         pipe.describe(q_tok, q_msk, q_off_l)                                     # this rank's slice of the query images
         d2, idx = eng.search(qd_all, kv)                                         # all query segments against the shard

@@ -249,9 +249,11 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *                                                      unknown).  The exact level of a batch search re-evaluates the refine
  *                                                      bands of a group of rows -- an image's rows with the hint, 32-row
  *                                                      blocks without -- as ONE fp32 GEMM over the union of their database
- *                                                      rows when the bands overlap (the segments of an image share most of
- *                                                      their neighbours), row by row when they do not
- *        "refine_group"  1 | 0                         that grouped refinement | every row on its own (rounds 1-4); same bits
+ *                                                      rows when that is the cheaper way (the segments of an image share most
+ *                                                      of their neighbours: a cost model with measured constants decides per
+ *                                                      group), row by row otherwise
+ *        "refine_group"  1 | 0 | 2                     that grouped refinement | every row on its own (rounds 1-4) | every group
+ *                                                      whose union fits, whatever the cost model says (tests); same bits
  *      Every other key is a DEVELOPMENT switch (kernel tuning, A/B variants, debugging, the tests' own hooks), documented in
  *      revisit-anything_amd/csrc/segvlad_dev.h and NOT part of this ABI: none changes a result, the shipped library holds
  *      only the kernels they default to and rejects the values that select another (SEGVLAD_ERR_ARG).

@@ -851,8 +851,13 @@ static int describe_begin_impl(segvlad_ctx* ctx, const uint8_t* masks, int Hm, i
     if (e != hipSuccess) rc = ctx->fail(SEGVLAD_ERR_HIP, "describe: flags read-back: %s", hipGetErrorString(e));
   }
   ctx->stream = main_stream;
+  auto close_timer = [&]() {
+    if (ctx->desc_timer) (void)hipEventRecord(ctx->desc_timer->ev[2 * ctx->desc_slot + 1], ctx->stream);
+    ctx->desc_timer = nullptr;
+  };
   if (rc != SEGVLAD_OK) {
     (void)sv_join_side(ctx);   // (nothing of the branch stays behind on the side stream unobserved)
+    close_timer();
     return rc;
   }
   ctx->mask_branch_on_side = true;   // images_impl (phase 2 / 0) joins in front of prep
@@ -863,6 +868,7 @@ static int describe_begin_impl(segvlad_ctx* ctx, const uint8_t* masks, int Hm, i
   if (rc != SEGVLAD_OK) {
     ctx->mask_branch_on_side = false;
     (void)sv_join_side(ctx);
+    close_timer();
   }
   return rc;
 }

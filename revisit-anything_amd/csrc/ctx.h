@@ -159,7 +159,8 @@ struct SvOptions {
   int pj_nw = 8;          // waves (32-column slices) per workgroup of the P-space aggregation: 8, or 4 (three workgroups per
                           // CU instead of one: measured SLOWER, 3.72 vs 3.40 ms for the PCA stage of 200 images)
   int refine_group = 1;   // batch searches: the refine bands of 32 consecutive query rows evaluated as ONE exact fp32 GEMM over the union of
-                          // their rows when the bands overlap (refine_group_kernels.hip); 0 = every row on its own (rounds 1-4)
+                          // their rows when that is cheaper (refine_group_kernels.hip); 0 = every row on its own (rounds 1-4); 2 = every group whose union
+                          // fits, whatever the cost model says (tests)
   int query_group = 0;    // hint: the query rows of a batch come in runs of this many rows per query image (1 .. 64; else unknown):
                           // the grouped refinement then takes an image's rows as one group instead of 32-row blocks
   int pca_path = 0;       // fused images_pca: 0 auto, 1 "planes" (descriptor planes x W), 2 "project" (project tokens, then aggregate)
@@ -265,7 +266,7 @@ struct segvlad_ctx {
   X(s_ref_cnt) X(s_ref_id) X(s_qscale) X(s_qf16) X(s_xh1) X(s_xh2) X(s_desc) X(s_tokorder) X(s_laboff) X(s_rnsorted) X(s_ovf)     \
   X(s_fb_q) X(s_fb_d2) X(s_fb_idx) X(s_fb_rows) X(s_rd_rows) X(s_rd_q) X(s_rd_d2) X(s_rd_idx) X(s_rd_flags) X(s_rd_p1) X(s_rd_p2)  \
   X(s_sel_todo) X(s_vote_keys) X(s_pz) X(s_rowbase) X(s_tilegrp) X(s_bn) X(s_l0part) X(s_ref_lim) X(s_sh_d2) X(s_sh_idx)          \
-  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work)
+  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work) X(s_grp_pos)
 #define SV_DECL_BUF(n) DevBuf n;
   SV_PERSISTENT_BUFS(SV_DECL_BUF)
   SV_SCRATCH_BUFS(SV_DECL_BUF)

@@ -10,15 +10,16 @@
 // Here G consecutive query rows form a group (G = option "query_group" when it is 1 .. 64 -- the caller's hint that the query
 // rows come in runs of G per image, so that groups coincide with images -- else 32):
 //   refine_union_kernel        sorted union of the group's band lists (LDS bitonic sort + unique); a group whose union
-//                              is not at most half of its list slots (nothing shared: random queries), or longer than
+//                              is not cheaper to evaluate than its bands row by row (a cost model with measured constants:
+//                              nothing shared -- random queries --, or short bands against a long union), or longer than
 //                              RG_UCAP, keeps the per-row kernels (its rows are flagged in `perrow`)
 //   refine_group_gemm_kernel   exact distances of ALL 32 x U pairs of a grouped group on v_mfma_f32_32x32x2_f32: per output
 //                              element the sequential chain acc = fma(q[k], r[k], acc), k = 0 .. d - 1, from acc = 0 --
 //                              bit for bit the chain of refine_exact_kernel and of the distance-matrix path
 //                              (gemm_kernels.hip, same instruction, same k order) -- then sv_d2 with the same norms.
-//                              A row outside a query's own band only adds an exact distance that cannot enter its top k
-//                              (the band contains the top k, ties included), so the result is the per-row kernels'.
-//   refine_group_select_kernel per query row: (distance, id) sort of its U keys, top k.
+//                              (The pairs outside a query's own band are computed and never read.)
+//   refine_group_select_kernel per query row: the keys of its OWN band out of the group's key matrix (the union kernel leaves the
+//                              union column of every band entry), (distance, id) sort, top k.
 // Workgroup of the GEMM: 4 waves, wave w owns 32 union rows (MT = 1 or 2 accumulator tiles of 32 x 32: groups of <= 32 / <= 64
 // query rows), the query rows are shared through LDS; operands staged k-major ([k][row], odd row stride) exactly like
 // gemm_kernels.hip; global loads run THREE k-tiles ahead in three named register stages (a step's loads carry no condition in
@@ -65,9 +66,10 @@ __device__ __forceinline__ void rg_bitonic(T* a, int n, int tid) {
 // ---- union of a group's band lists ---------------------------------------------------------------------------------------
 constexpr int RG_UT = 1024;   // threads of the union kernel (the sort is its time)
 __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __restrict__ ref_cnt, const uint32_t* __restrict__ ref_id,
-                                                           int rcap, int m, int G, int ucap, uint32_t* __restrict__ grp_cnt,
+                                                           int rcap, int m, int G, int d, int force, int ucap, uint32_t* __restrict__ grp_cnt,
                                                            uint32_t* __restrict__ grp_ids, uint32_t* __restrict__ perrow,
-                                                           uint32_t* __restrict__ work /* [0] = count, then items */) {
+                                                           uint32_t* __restrict__ work /* [0] = count, then items */,
+                                                           uint16_t* __restrict__ grp_pos /* [m][rcap]: union column of every band entry */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* buf = reinterpret_cast<uint32_t*>(smem);   // [pow2 >= G * rcap]
   __shared__ uint32_t off[RG_GMAX + 1];
@@ -112,12 +114,38 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
         all += wtot[x];
       }
       const uint32_t pos = o + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-      if (first && pos < (uint32_t)ucap) grp_ids[(size_t)b * ucap + pos] = buf[j];
+      const uint32_t idj = first ? buf[j] : 0u;
+      if (first && pos < (uint32_t)ucap) grp_ids[(size_t)b * ucap + pos] = idj;
       base += all;
-      __syncthreads();
+      __syncthreads();            // every read of this chunk (buf[j], buf[j - 1]) precedes its writes, which land at positions <= j
+      if (first) buf[pos] = idj;  // the unique ids, compacted to the front of the LDS list
     }
+    __syncthreads();
     U = (int)base;
-    grouped = U <= ucap && 2 * U <= total;
+    // Is the union cheaper?  Measured on MI355X (ns, d = 1024; the first two terms grow with d): the per-row kernels ~0.46 per
+    // (query, row) pair of the bands; the union GEMM ~0.038 per slot of its 64 x 128 tiles, whatever their fill; the per-query
+    // sort of a band's keys ~0.022 per slot of its power-of-two list (~1.5 slots per band entry).  (200-deep bands of an image's 50 segments on a 1 M-row index:
+    // 10 900 pairs against 938 union rows -> grouped; the same image 50 deep on a 125 k-row shard: 2 500 pairs -> row by row.)
+    const float dd = (float)d * (1.f / 1024.f);
+    const float cost_grp = (float)((U + 127) >> 7) * 8192.f * 0.038f * dd + 1.5f * (float)total * 0.022f;
+    const float cost_row = (float)total * 0.46f * dd;
+    grouped = U <= ucap && (force || cost_grp < cost_row);
+    if (grouped) {
+      // where each band entry sits in the union: the per-query select then sorts a query's OWN band (<= rcap keys), not the union
+      for (int t = w; t < nrows; t += RG_UT / 64) {
+        const int c = (int)(off[t + 1] - off[t]);
+        for (int j = l; j < c; j += 64) {
+          const uint32_t id = ref_id[(size_t)(q0 + t) * rcap + j];
+          int lo = 0, hi = U;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (buf[mid] < id) lo = mid + 1;
+            else hi = mid;
+          }
+          grp_pos[(size_t)(q0 + t) * rcap + j] = (uint16_t)lo;
+        }
+      }
+    }
   }
   if (tid == 0) {
     grp_cnt[b] = grouped ? (uint32_t)U : 0u;
@@ -254,24 +282,26 @@ __global__ __launch_bounds__(256) void refine_group_gemm_kernel(const float* __r
   }
 }
 
-// ---- per query row: sort its U keys, top k ----------------------------------------------------------------------------------
+// ---- per query row: the keys of ITS band out of the group's key matrix, (distance, id) sort, top k ----------------------------
 __global__ __launch_bounds__(256) void refine_group_select_kernel(const uint32_t* __restrict__ grp_cnt, const uint64_t* __restrict__ keys,
-                                                                  int G, int ucap, int k, float* __restrict__ d2_out,
-                                                                  int64_t* __restrict__ idx_out) {
+                                                                  const uint32_t* __restrict__ ref_cnt,
+                                                                  const uint16_t* __restrict__ grp_pos, int rcap, int G, int ucap, int k,
+                                                                  float* __restrict__ d2_out, int64_t* __restrict__ idx_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* a = reinterpret_cast<uint64_t*>(smem);   // [np2 <= ucap]
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);   // [np2 <= pow2(rcap)]
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x;
-  const int U = (int)grp_cnt[row / G];
-  if (U == 0) return;   // the per-row kernels' group
+  if (grp_cnt[row / G] == 0) return;   // the per-row kernels' group
+  int n = (int)ref_cnt[row];
+  if (n > rcap) n = 0;
   int np2 = 2;
-  while (np2 < U) np2 <<= 1;
-  for (int j = tid; j < np2; j += 256) a[j] = j < U ? keys[(size_t)row * ucap + j] : ~0ull;
+  while (np2 < n) np2 <<= 1;
+  for (int j = tid; j < np2; j += 256) a[j] = j < n ? keys[(size_t)row * ucap + grp_pos[(size_t)row * rcap + j]] : ~0ull;
   rg_bitonic<uint64_t>(a, np2, tid);
   for (int j = tid; j < k; j += 256) {
     float dd = INFINITY;
     int64_t id = -1;
-    if (j < U) {
+    if (j < n) {
       dd = rg_key2f((uint32_t)(a[j] >> 32));
       id = (int64_t)(uint32_t)a[j];
     }
@@ -298,7 +328,7 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
   const int G = rg_group_rows(ctx);
   int lpad = 64;
   while (lpad < G * rcap) lpad <<= 1;
-  const bool can = ctx->opt.refine_group != 0 && d % RG_KS == 0 && nq > 128 && (size_t)lpad * 4 <= 128 * 1024 && k <= ucap &&
+  const bool can = ctx->opt.refine_group != 0 && d % RG_KS == 0 && nq > 128 && (size_t)lpad * 4 <= 128 * 1024 && rcap <= 4096 &&
                    (reinterpret_cast<uintptr_t>(Q) & 15) == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0;
   if (!can) {
     if (launches) *launches = 1;
@@ -309,6 +339,7 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
   SV_HIP(ctx->s_grp_ids.reserve((size_t)nb * ucap * 4));
   SV_HIP(ctx->s_grp_rows.reserve((size_t)nq * 4));
   SV_HIP(ctx->s_grp_keys.reserve((size_t)nq * ucap * 8));
+  SV_HIP(ctx->s_grp_pos.reserve((size_t)nq * rcap * 2));
   uint32_t* gcnt = ctx->s_grp_cnt.as<uint32_t>();
   uint32_t* gids = ctx->s_grp_ids.as<uint32_t>();
   uint32_t* prow = ctx->s_grp_rows.as<uint32_t>();
@@ -320,8 +351,8 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
   SV_HIP(hipMemsetAsync(work, 0, 4, ctx->stream));
   const size_t ulds = (size_t)lpad * 4;
   if (ulds + 1024 > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_union_kernel), ulds));
-  hipLaunchKernelGGL(refine_union_kernel, dim3(nb), dim3(RG_UT), ulds, ctx->stream, ref_cnt, ref_id, rcap, nq, G, ucap, gcnt, gids, prow,
-                     work);
+  hipLaunchKernelGGL(refine_union_kernel, dim3(nb), dim3(RG_UT), ulds, ctx->stream, ref_cnt, ref_id, rcap, nq, G, d,
+                     ctx->opt.refine_group == 2 ? 1 : 0, ucap, gcnt, gids, prow, work, ctx->s_grp_pos.as<uint16_t>());
   SV_HIP(hipGetLastError());
   {
     const int mt = G > 32 ? 2 : 1;
@@ -331,9 +362,13 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
     hipLaunchKernelGGL(gk, dim3(max_items), dim3(256), glds, ctx->stream, Q, R, d, nq, G, qn, rn, gcnt, gids, ucap, gkeys, work);
     SV_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(refine_group_select_kernel, dim3(nq), dim3(256), (size_t)ucap * 8, ctx->stream, gcnt, gkeys, G, ucap, k, d2_out,
-                     idx_out);
-  SV_HIP(hipGetLastError());
+  {
+    int rpad = 2;
+    while (rpad < rcap) rpad <<= 1;
+    hipLaunchKernelGGL(refine_group_select_kernel, dim3(nq), dim3(256), (size_t)rpad * 8, ctx->stream, gcnt, gkeys, ref_cnt,
+                       ctx->s_grp_pos.as<uint16_t>(), rcap, G, ucap, k, d2_out, idx_out);
+    SV_HIP(hipGetLastError());
+  }
   if (launches) *launches = 4;
   return sv_launch_refine_exact(ctx, Q, R, nq, d, qn, rn, ref_cnt, ref_id, rcap, k, d2_out, idx_out, prow);
 }

@@ -300,7 +300,9 @@ int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
 // Qhull's (which decides such cases by its own perturbation rules).
 // S <= 3 reproduces the reference's special case: every row = e0 (+ e1).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict__ cent,
+constexpr int ADJ_T = 1024;   // threads per image: S (S - 1) / 2 point pairs, ~1 per thread at S = 50 (round 5: 256 threads walked ~10
+                              // pairs each -- half of them skipped -- one fp64 division chain after the other: 150-210 us per launch)
+__global__ __launch_bounds__(ADJ_T) void adjacency_kernel(const double* __restrict__ cent,
                                                         const int32_t* __restrict__ seg_off,
                                                         const int64_t* __restrict__ adj_off, int order, int S_max,
                                                         uint8_t* __restrict__ adj, uint32_t* __restrict__ n_bad,
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
   const int tid = threadIdx.x;
   if (S == 0) return;
   uint8_t* out = adj + adj_off[b];
-  for (int s = tid; s < S; s += 256) {
+  for (int s = tid; s < S; s += ADJ_T) {
     px[s] = cent[2 * (size_t)(s0 + s)];
     py[s] = cent[2 * (size_t)(s0 + s) + 1];
     if (px[s] != px[s]) {  // NaN centroid = empty mask (reference: ValueError)
@@ -325,24 +327,25 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
       if (img_flags) img_flags[b] = (uint8_t)(img_flags[b] | 1u);   // (same value from every writer; bit 1 is set later, by one thread)
     }
   }
-  for (int j = tid; j < S * SW; j += 256) A1[j] = 0;
+  for (int j = tid; j < S * SW; j += ADJ_T) A1[j] = 0;
   __shared__ int degenerate;
   if (tid == 0) degenerate = 0;
   __syncthreads();
   if (S <= 3) {
-    for (int j = tid; j < S * S; j += 256) {
+    for (int j = tid; j < S * S; j += ADJ_T) {
       const int w = j % S;
       out[j] = (w == 0 || (w == 1 && S > 1)) ? 1 : 0;
     }
     return;
   }
-  for (int e = tid; e < S * S; e += 256) {
-    const int u = e / S, v = e - u * S;
-    if (u == v) {
-      atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (u >> 6)]), 1ull << (u & 63));
-      continue;
-    }
-    if (u > v) continue;
+  for (int u = tid; u < S; u += ADJ_T) atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (u >> 6)]), 1ull << (u & 63));
+  const int npairs = S * (S - 1) / 2;
+  for (int e = tid; e < npairs; e += ADJ_T) {
+    // pair e of the strict upper triangle, row-major: row u starts at u (2 S - u - 1) / 2
+    int u = (int)(((double)(2 * S - 1) - sqrt((double)(2 * S - 1) * (double)(2 * S - 1) - 8.0 * (double)e)) * 0.5);
+    while (u > 0 && u * (2 * S - u - 1) / 2 > e) --u;
+    while ((u + 1) * (2 * S - u - 2) / 2 <= e) ++u;
+    const int v = u + 1 + (e - u * (2 * S - u - 1) / 2);
     const double ux = px[u], uy = py[u], vx = px[v], vy = py[v];
     const double ex = vx - ux, ey = vy - uy;
     if (ex == 0.0 && ey == 0.0) degenerate = 1;   // duplicate centroid
@@ -385,10 +388,10 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
     if (n_bad) atomicAdd(n_bad, 65536u);
     if (img_flags) img_flags[b] = (uint8_t)(img_flags[b] | 2u);
   }
-  for (int j = tid; j < S * SW; j += 256) P[j] = A1[j];
+  for (int j = tid; j < S * SW; j += ADJ_T) P[j] = A1[j];
   __syncthreads();
   for (int it = 1; it < order; ++it) {  // P <- (P . A1) > 0
-    for (int j = tid; j < S * SW; j += 256) {
+    for (int j = tid; j < S * SW; j += ADJ_T) {
       const int v = j / SW, w = j - v * SW;
       uint64_t acc = 0;
       for (int uw = 0; uw < SW; ++uw) {
@@ -402,10 +405,10 @@ __global__ __launch_bounds__(256) void adjacency_kernel(const double* __restrict
       Q[j] = acc;
     }
     __syncthreads();
-    for (int j = tid; j < S * SW; j += 256) P[j] = Q[j];
+    for (int j = tid; j < S * SW; j += ADJ_T) P[j] = Q[j];
     __syncthreads();
   }
-  for (int j = tid; j < S * S; j += 256) {
+  for (int j = tid; j < S * S; j += ADJ_T) {
     const int v = j / S, w = j - v * S;
     out[j] = (uint8_t)((P[v * SW + (w >> 6)] >> (w & 63)) & 1ull);
   }
@@ -420,7 +423,7 @@ int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg
     return ctx->fail(SEGVLAD_ERR_LIMIT, "adjacency: %d segments in one image exceed the LDS budget (%zu B)", S_max, lds);
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(adjacency_kernel), (size_t)lds));
-  hipLaunchKernelGGL(adjacency_kernel, dim3(B), dim3(256), lds, ctx->stream, cent, seg_off_dev, adj_off_dev, order, S_max,
+  hipLaunchKernelGGL(adjacency_kernel, dim3(B), dim3(ADJ_T), lds, ctx->stream, cent, seg_off_dev, adj_off_dev, order, S_max,
                      adj, n_bad, img_flags);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;

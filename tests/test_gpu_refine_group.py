@@ -19,7 +19,7 @@ def _unit(x):
     return torch.nn.functional.normalize(x, dim=1)
 
 
-def _both(R, Q, k, expect_grouped=None, hint=0):
+def _both(R, Q, k, expect_grouped=None, hint=0, expect_policy=None):
     eng = _engine()
     eng.set_option("search_stats", 1)
     eng.set_option("query_group", hint)
@@ -28,9 +28,15 @@ def _both(R, Q, k, expect_grouped=None, hint=0):
     d0, i0 = eng.search(Q, k)
     st0 = eng.search_stats()
     assert st0["grp_groups"] == 0
-    eng.set_option("refine_group", 1)
+    eng.set_option("refine_group", 2)      # every group whose union fits (the default, 1, asks a cost model first)
     d1, i1 = eng.search(Q, k)
     st1 = eng.search_stats()
+    eng.set_option("refine_group", 1)
+    d3, i3 = eng.search(Q, k)
+    st3 = eng.search_stats()
+    assert torch.equal(i0, i3) and torch.equal(d0, d3), "the default policy's result differs from the per-row refinement"
+    if expect_policy is not None:
+        assert expect_policy[0] <= st3["grp_groups"] <= expect_policy[1], st3
     eng.set_option("knn_filter", "fp32")
     d2, i2 = eng.search(Q, k)
     eng.close()
@@ -67,7 +73,7 @@ def test_random_queries_keep_the_per_row_kernels():
     g.manual_seed(52)
     R = _unit(torch.randn(80_000, 256, device="cuda:0", generator=g))
     Q = _unit(torch.randn(700, 256, device="cuda:0", generator=g))     # 21 full groups + one of 28 rows
-    _both(R, Q, 50, expect_grouped=(0, 0))
+    _both(R, Q, 50, expect_policy=(0, 0))     # nothing shared: the cost model keeps every group row by row
 
 
 def test_mixed_batch_ragged_tail_and_k_beyond_the_union():
