@@ -972,15 +972,16 @@ def cpu_baseline(a, db_rows, fac, tau, C_np, use_pca, P, N, S, K, D, H, W, pipe,
         cores = os.cpu_count() or 1
     n_v = max(1, min(int(a.verify_images), q_tok.shape[0]))
     t_desc = 0.0
-    descs = []
+    descs, o_labels = [], []
     for qi in range(n_v):
         t, m = q_tok[qi].cpu().numpy(), q_msk[qi * S:(qi + 1) * S].cpu().numpy().astype(bool)
         t0 = time.perf_counter()
         inc = O.incidence(m, H, W)
         adj = O.nbr_masks_agg_fast_single([x for x in m], a.order) if a.order else None
-        v = O.seg_vlad(t, inc, C_np, adj)
+        v, aux = O.seg_vlad(t, inc, C_np, adj, return_aux=True)
         t_desc += time.perf_counter() - t0
         descs.append(v)
+        o_labels.append(aux["labels"])
     # PCA transform of the sampled descriptors with the same synthetic model (regenerated on the host)
     t_pca = 0.0
     if use_pca:
@@ -1041,7 +1042,18 @@ def cpu_baseline(a, db_rows, fac, tau, C_np, use_pca, P, N, S, K, D, H, W, pipe,
     def pad5(rows):
         return np.array([[int(x) for x in r] + [-1] * (5 - len(r)) for r in rows], dtype=np.int64)
 
+    # the tie audit of the assignment (verdict r04, weak 12): the device's labels against the oracle's over the verified images'
+    # tokens, and how many of them sit in the band where an fp32 arg-max may legitimately differ from the reference's (top-1
+    # minus top-2 cosine below 1e-6: the `gap` output of segvlad_images)
+    bits_v = pipe.eng.incidence(q_msk[:n_v * S], H, W, 14)
+    av = pipe.eng.seg_vlad(q_tok[:min(n_v, 4)], bits_v[:min(n_v, 4) * S], offs[:min(n_v, 4) + 1], None, want_labels=True, want_gap=True)
+    lab_dev = av["labels"].cpu().numpy().reshape(-1)
+    gap_dev = av["gap"].cpu().numpy().reshape(-1)
+    lab_or = np.concatenate([np.asarray(x).reshape(-1) for x in o_labels[:min(n_v, 4)]])
+    del av
     check = {"images": n_v, "top1_identical": top1_same, "top5_identical": top5_same,
+             "assignment_audit": {"tokens": int(lab_dev.size), "labels_differing_from_the_oracle": int((lab_dev != lab_or).sum()),
+                                  "tokens_with_gap_below_1e-6": int((gap_dev < 1e-6).sum()), "smallest_gap": float(gap_dev.min())},
              "sims_max_abs_diff": float(np.abs(s_dev - osims).max()), "neighbour_id_mismatches": int(len(qq)),
              "neighbour_id_mismatches_are_near_ties": near_tie,
              "desc_max_abs_diff": float(np.abs(qd_dev.cpu().numpy() - Qo).max()),

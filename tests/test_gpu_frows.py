@@ -68,11 +68,16 @@ def test_pca_fit_device_backend_matches_sklearn_exact_solver(eng):
     y = O().pca_transform(Xt, mean, comps, var, True)
     d_ref = ((y_ref[:, None] - y_ref[None]) ** 2).sum(-1)
     d = ((y[:, None] - y[None]) ** 2).sum(-1)
+    # (2e-3: two different MODELS are compared here -- six subspace iterations against sklearn's exact solver: eigenvalues
+    #  to 2e-4, components to 1e-4, and whitening divides by sqrt(lambda) -- not two evaluations of one model)
     assert np.abs(d - d_ref).max() < 2e-3 * d_ref.max()
-    # and the fitted model, loaded into the engine, projects like sklearn
+    # and the fitted model, loaded into the engine, projects like sklearn's (again model against model) ...
     eng.pca_set(mean, comps, var, whiten=True)
     yd = eng.pca_apply(X[:50]).cpu().numpy()
     assert np.abs(np.abs(yd) - np.abs(y_ref)).max() < 2e-3 * np.abs(y_ref).max()
+    # ... while the device's APPLY of that model is held to the fp64 evaluation of the SAME model at the tolerance of every
+    # other projection test (5e-5 relative)
+    assert np.abs(yd - y).max() < 5e-5 * np.abs(y).max()
 
 
 def test_pca_fit_on_the_device_at_a_reduced_real_shape_and_the_pickle_flow(eng, tmp_path):
@@ -136,7 +141,8 @@ def test_pca_fit_on_the_device_at_a_reduced_real_shape_and_the_pickle_flow(eng, 
     y_ref = ref.transform(Xh[:40].astype(np.float64))
     assert np.abs(np.abs(y_sk) - np.abs(y_ref)).max() < 5e-3 * np.abs(y_ref).max()
     y_dev = func_vpr.apply_pca_transform_from_pkl(torch.from_numpy(Xh[:40]), path).numpy()
-    assert np.abs(y_dev - y_sk).max() < 2e-3 * np.abs(y_sk).max()
+    # one model, two evaluations (the device's fp32-class split GEMM against sklearn's fp64 transform of the same pickle)
+    assert np.abs(y_dev - y_sk).max() < 5e-5 * np.abs(y_sk).max()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -247,7 +253,7 @@ def test_fit_from_store_is_the_reference_pca_run_in_one_call(eng, tmp_path):
     model = pickle.load(open(path, "rb"))
     assert type(model).__name__ == "PCA" and model.whiten and model.n_components_ == 12 and model.n_features_in_ == K * D
     y_dev = func_vpr.apply_pca_transform_from_pkl(torch.from_numpy(Xs[:20]), path).numpy()
-    assert np.abs(y_dev - model.transform(Xs[:20].astype(np.float64))).max() < 2e-3 * np.abs(y_dev).max()
+    assert np.abs(y_dev - model.transform(Xs[:20].astype(np.float64))).max() < 5e-5 * np.abs(y_dev).max()   # one model, two evaluations
     with pytest.raises(ValueError):
         pca_fit.fit_from_store(None, None, [], SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True))
 
