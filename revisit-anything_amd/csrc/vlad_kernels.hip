@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
                                                                     int Dpad, float* __restrict__ block_norms, float xscale,
                                                                     _Float16* __restrict__ h1, _Float16* __restrict__ h2,
                                                                     const int32_t* __restrict__ rowbase, int64_t dummy_row,
-                                                                    int skip_le) {
+                                                                    int skip_le, const uint8_t* __restrict__ redo_task) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
   const int tid = threadIdx.x, l = tid & 63, i = l & 31, kk = l >> 5;
@@ -1186,7 +1186,8 @@ __global__ __launch_bounds__(64 * TNK_WAVES, 2) void token_norms_kernel(const fl
   const int nd = Dpad >> 7, total = nd * npairs;
   const size_t tb = (size_t)b * N + o0;
   if ((n >= TNK_LCAP) != BIG) return;   // the other instantiation's task
-  if (n <= skip_le) return;             // gram_norms_kernel's task (skip_le = -1: none)
+  // gram_norms_kernel's task (skip_le = -1: none) -- unless that kernel found one of the task's segments CANCELLING (redo_task)
+  if (n <= skip_le && !(redo_task && n > 0 && redo_task[(size_t)b * K + k])) return;
   if (n == 0) {   // an empty cluster: zero norms, no rows
     for (int s = l; s < S; s += 64) block_norms[(size_t)(s0 + s) * K + k] = 0.f;
     return;
@@ -1368,7 +1369,8 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
                                                                          const int32_t* __restrict__ seg_off, int N, int D, int K, int SC,
                                                                          float* __restrict__ block_norms, float xscale,
                                                                          _Float16* __restrict__ h1, _Float16* __restrict__ h2,
-                                                                         const int32_t* __restrict__ rowbase, int safe_waits) {
+                                                                         const int32_t* __restrict__ rowbase, int safe_waits,
+                                                                         uint8_t* __restrict__ redo_task) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
   constexpr int WAVES = T == 1 ? 4 : 2;
@@ -1499,6 +1501,20 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
     }
   }
   // ---- per segment: m^T G m over this lane's 16 entries G(a, b)[frag_row(r, kk)][i] of every tile, then across the wave ------
+  // CANCELLATION: the quadratic form carries ~n 2^-22 of the COVERED DIAGONAL sum_t m_t G_tt, not of its own value;
+  // when a segment's residuals nearly cancel (m^T G m << the diagonal sum) that is no longer small against the norm it divides
+  // by.  Such a task is flagged (redo_task) and token_norms_kernel recomputes it with the fp32 block sums, which have no such
+  // term (1/16: relative error of the norm <= ~1e-4 at 64 tokens on this side of the threshold).
+  float dgl[T];   // this lane's diagonal entry G_tt of token 32 tt + i, if the lane holds it (one of the two half-waves does)
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt) {
+    dgl[tt] = 0.f;
+    const int gd = tt == 0 ? 0 : NG - 1;   // tiles (0,0) and (T-1,T-1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (frag_row(r, kk) == i) dgl[tt] = acc[gd][r];
+  }
+  bool cancels = false;
   const float inv_x2 = 1.f / (xscale * xscale);
   const int SCb = (S + 63) >> 6;
   for (int sc = 0; sc < SCb; ++sc) {
@@ -1532,10 +1548,21 @@ __global__ __launch_bounds__(T == 1 ? 256 : 128, 2) void gram_norms_kernel(const
         p += dpp_f32<0x140>(p);
         p += __shfl_xor(p, 16);
         p += __shfl_xor(p, 32);
+        float dg = 0.f;   // the covered diagonal
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) dg += ((W[tt] >> i) & 1u) ? dgl[tt] : 0.f;
+        dg += dpp_f32<0xB1>(dg);
+        dg += dpp_f32<0x4E>(dg);
+        dg += dpp_f32<0x141>(dg);
+        dg += dpp_f32<0x140>(dg);
+        dg += __shfl_xor(dg, 16);
+        dg += __shfl_xor(dg, 32);
+        cancels = cancels || (p < 0.0625f * dg);
       }
       if (l == 0) block_norms[(size_t)(s0 + 64 * sc + s) * K + k] = sqrtf(fmaxf(p, 0.f) * inv_x2);
     }
   }
+  if (cancels && l == 0 && redo_task) redo_task[(size_t)b * K + k] = 1;   // (wave-uniform: p and dg are wave sums)
 }
 
 int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* colmask, const float* centres, int K, int D,
@@ -1548,7 +1575,11 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
   // tasks of <= 64 tokens: the Gram kernels (option tnk_gram, default on; D a multiple of 32); the rest: the block-sum kernels
   const bool gram = ctx->opt.tnk_gram != 0 && (D % 32) == 0;
   const int skip_le = gram ? 64 : -1;
+  uint8_t* redo_task = nullptr;   // [B][K]: Gram tasks with a cancelling segment, recomputed by the block-sum kernel below
   if (gram) {
+    SV_HIP(ctx->s_tnk_redo.reserve((size_t)B * K));
+    redo_task = ctx->s_tnk_redo.as<uint8_t>();
+    SV_HIP(hipMemsetAsync(redo_task, 0, (size_t)B * K, ctx->stream));
     // the two-tile tasks are few (6 % of the tokens at 24 per cluster): their launch is one task's latency with most of the chip
     // idle -- on the context's side stream it runs beside the one-tile launch instead of in front of it (tnk_fork)
     const bool fork = N > 32 && ctx->opt.tnk_fork != 0;
@@ -1563,7 +1594,7 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
       hipLaunchKernelGGL(gk, dim3((K + waves - 1) / waves, B), dim3(64 * waves), glds, (T == 2 && fork) ? ctx->side : ctx->stream, xt,
                          ctx->s_rnsorted.as<float>(), ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres,
                          seg_off_dev, N, D, K, SC, block_norms, xscale, reinterpret_cast<_Float16*>(h1),
-                         reinterpret_cast<_Float16*>(h2), rowbase, dummy_row < 0 ? 1 : 0);
+                         reinterpret_cast<_Float16*>(h2), rowbase, dummy_row < 0 ? 1 : 0, redo_task);
       SV_HIP(hipGetLastError());
     }
     if (fork) SV_TRY(sv_join_side(ctx));
@@ -1576,7 +1607,7 @@ int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* col
     hipLaunchKernelGGL(kern, dim3((K + TNK_WAVES - 1) / TNK_WAVES, B), dim3(64 * TNK_WAVES), lds, ctx->stream, xt,
                        ctx->s_rnsorted.as<float>(), ctx->s_tokorder.as<int32_t>(), ctx->s_laboff.as<int32_t>(), colmask, centres,
                        seg_off_dev, N, D, K, SC, Dpad, block_norms, xscale, reinterpret_cast<_Float16*>(h1),
-                       reinterpret_cast<_Float16*>(h2), rowbase, dummy_row, skip_le);
+                       reinterpret_cast<_Float16*>(h2), rowbase, dummy_row, skip_le, redo_task);
     SV_HIP(hipGetLastError());
   }
   return SEGVLAD_OK;

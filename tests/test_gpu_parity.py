@@ -873,6 +873,70 @@ def test_block_norms_from_the_gram_matrix_equal_the_block_sums(eng):
     assert not np.array_equal(y32, ys["1"])
 
 
+def test_gram_block_norms_with_cancelling_segments_at_d1536(eng):
+    """||sum_t m_t r_t||^2 as the quadratic form m^T G m carries an error relative to the covered DIAGONAL of the
+    Gram matrix, not to its own value -- harmless while a segment's residuals add up like a random walk, not when they nearly
+    cancel.  Here they do, by construction: the tokens of a cluster come in antipodal pairs around the centre (x = cos(t) u +-
+    sin(t) v with ||C_k|| = cos(t): residuals +- sin(t) v, the second partner tilted by 10 %), so a segment that covers whole
+    pairs has ||sum||^2 = 0.5 % of the diagonal sum, 32 tokens per task.  The Gram kernel flags such tasks and the fp32
+    block-sum kernel recomputes them: against the fp64 oracle at D = 1536 at the tolerance of the benign case, and the two
+    forms agree as closely as there.  (Measured with the guard off: the Gram form's errors add up like a random walk over the
+    n^2 entries -- ~n 2^-22 of the diagonal, 2.5e-5 of the norm at this 0.5 % ratio -- so even here the unguarded result
+    stays inside the tolerance; the guard keeps it there for ratios a test does not construct.)"""
+    D, K, P, pairs = 1536, 8, 64, 16
+    rng = np.random.Generator(np.random.PCG64(881))
+    C = synth().make_vocab(K, D, seed=880)
+    toks = np.empty((2 * pairs * K, D), np.float32)
+    for k in range(K):
+        nc = np.linalg.norm(C[k])
+        u = C[k] / nc
+        sin_t = np.sqrt(max(1.0 - nc * nc, 0.0))
+        for j in range(pairs):
+            v = rng.standard_normal(D)
+            v -= (v @ u) * u
+            v /= np.linalg.norm(v)
+            w = rng.standard_normal(D)
+            w -= (w @ u) * u
+            v2 = v + 0.1 * w / np.linalg.norm(w)
+            v2 -= (v2 @ u) * u
+            v2 /= np.linalg.norm(v2)
+            toks[(k * pairs + j) * 2] = nc * u + sin_t * v
+            toks[(k * pairs + j) * 2 + 1] = nc * u - sin_t * v2
+    N = toks.shape[0]
+    tok_dn = np.ascontiguousarray(toks.T)                              # [D, N] as stored
+    S = 12
+    inc = np.zeros((S, N), bool)
+    for s in range(S):                                                 # whole pairs only: every covered task cancels
+        pick = rng.random(pairs * K) < (0.9 if s < 4 else 0.4)
+        inc[s] = np.repeat(pick, 2)
+    inc[5, 1] = not inc[5, 1]                                          # ... and one segment that splits a pair (no cancellation there)
+    adj = np.eye(S, dtype=bool)
+    mean, comps, var = synth().make_pca_model(K * D, P, seed=882)
+    eng.set_vocab(C)
+    eng.pca_set(mean, comps, var, whiten=True)
+    offs = np.array([0, S], np.int32)
+    bits = O().pack_bits_u64(inc).view(np.int64)
+    desc, aux = O().seg_vlad(tok_dn, inc, C, adj, return_aux=True)
+    bn = aux["block_norms"]
+    lab = eng.seg_vlad(tok_dn[None], bits, offs, cat_adj([adj]), want_labels=True)["labels"].cpu().numpy()[0]
+    assert np.array_equal(lab, np.repeat(np.arange(K), 2 * pairs))    # every token sits with its centre
+    diag = np.array([[((np.linalg.norm(toks[t] - C[k]) ** 2) if inc[s, t] and lab[t] == k else 0.0) for t in range(N)] for s in range(S) for k in range(K)]).sum(1).reshape(S, K)
+    ratio = (bn ** 2) / np.maximum(diag, 1e-30)
+    assert (ratio[:4] < 0.02).all() and ratio[5].max() > 0.02         # the construction cancels where it should
+    ref = O().pca_transform(desc, mean, comps, var, True)
+    eng.set_option("pca_path", "project")
+    try:
+        ys = {}
+        for gram in ("1", "0"):
+            eng.set_option("tnk_gram", gram)
+            ys[gram] = eng.seg_vlad_pca(tok_dn[None], bits, offs, cat_adj([adj]), l2norm=False)["out"].cpu().numpy()
+            assert np.abs(ys[gram] - ref).max() <= 3e-5 * np.abs(ref).max(), (gram, np.abs(ys[gram] - ref).max() / np.abs(ref).max())
+        assert np.abs(ys["1"] - ys["0"]).max() <= 2e-6 * np.abs(ref).max()
+    finally:
+        eng.set_option("tnk_gram", "1")
+        eng.set_option("pca_path", "auto")
+
+
 # ------------------------------------------------------------------------------------------------
 # fused segment-VLAD -> PCA (segvlad_images_pca): the aggregation kernel emits the projection GEMM's fp16 planes
 # ------------------------------------------------------------------------------------------------
