@@ -702,7 +702,10 @@ static int images_impl(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
       SV_TRY(sv_launch_gemm_f16x3_grouped(ctx, ctx->s_xh1.as<uint16_t>(), ctx->s_xh2.as<uint16_t>(), ctx->pca_w1.as<uint16_t>(),
                                           ctx->pca_w2.as<uint16_t>(), (int)rows_pad, ctx->P, D, K, ctx->s_tilegrp.as<int32_t>(),
                                           1.f / (xscale * ctx->pca_w_scale), ctx->s_pz.as<float>()));
-      // |z_tp| = |W_k[p, :] . r_t| <= sqrt(D) max|W| (1 + max ||C_k||): a power-of-two scale that keeps z * zscale inside fp16
+      // |z_tp| = |W_k[p, :] . r_t| <= sqrt(D) max|W| (1 + max ||C_k||): a power-of-two scale that keeps z * zscale inside fp16.
+      // Both premises hold BY CONSTRUCTION, not by the caller's grace: r_t = x^_t - C_k with x^_t normalised by the kernels
+      // themselves (||x^_t|| = 1 whatever the caller's tokens are), and vocab_norm_max is set by the one function that can change the
+      // centres (segvlad_set_vocab); a bound that is not finite and positive switches the 16-bit form off (zscale = 0: fp32 MFMA)
       // (the elementwise bound of W is the one pca_set left in pca_w_scale; typical |z| sits ~2^-7 below the bound, still
       // 2^10 above the point where the low half of the split would go subnormal)
       float zscale = 0.f;

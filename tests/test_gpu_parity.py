@@ -937,6 +937,36 @@ def test_gram_block_norms_with_cancelling_segments_at_d1536(eng):
         eng.set_option("pca_path", "auto")
 
 
+def test_project_form_with_large_norm_centres_keeps_its_fp16_scales_in_range(eng):
+    """the 16-bit P-space sums scale the projected residuals by a power of two from the bound
+    |z| <= sqrt(D) max|W| (1 + max ||C_k||) -- valid because the kernels normalise every token themselves and set_vocab keeps
+    max ||C_k|| current.  Centres far from the unit sphere (norms up to ~40: nothing k-means on unit tokens would produce, but
+    segvlad_set_vocab takes any) must move the scales, not overflow them: finite results, the oracle's tolerance."""
+    D, K, N, P, S = 128, 16, 16 * 20, 48, 24
+    rng = np.random.Generator(np.random.PCG64(771))
+    C = (synth().make_vocab(K, D, seed=770) * rng.uniform(5.0, 40.0, size=(K, 1))).astype(np.float32)
+    Cn = C / np.linalg.norm(C, axis=1, keepdims=True)
+    tok = synth().make_tokens(Cn.astype(np.float32), N, seed=772, noise=0.3)
+    inc = rng.random((S, N)) < 0.3
+    adj = np.eye(S, dtype=bool) | (rng.random((S, S)) < 0.1)
+    mean, comps, var = synth().make_pca_model(K * D, P, seed=773)
+    eng.set_vocab(C)
+    eng.pca_set(mean, comps, var, whiten=True)
+    offs = np.array([0, S], np.int32)
+    bits = O().pack_bits_u64(inc).view(np.int64)
+    ref = O().pca_transform(O().seg_vlad(tok, inc, C, adj), mean, comps, var, True)
+    eng.set_option("pca_path", "project")
+    try:
+        for pj in ("1", "0"):
+            eng.set_option("pj_f16", pj)
+            y = eng.seg_vlad_pca(tok[None], bits, offs, cat_adj([adj]), l2norm=False)["out"].cpu().numpy()
+            assert np.isfinite(y).all()
+            assert np.abs(y - ref).max() <= 5e-5 * np.abs(ref).max(), (pj, np.abs(y - ref).max() / np.abs(ref).max())
+    finally:
+        eng.set_option("pj_f16", "1")
+        eng.set_option("pca_path", "auto")
+
+
 # ------------------------------------------------------------------------------------------------
 # fused segment-VLAD -> PCA (segvlad_images_pca): the aggregation kernel emits the projection GEMM's fp16 planes
 # ------------------------------------------------------------------------------------------------
