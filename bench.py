@@ -759,6 +759,16 @@ def run(a, top=True):
         "pca_path": pca_path, "sibling_group": a.group, "recall_at_1_within_sibling_group": recalls_group[0],
         "search_stats": sstats, "per_rank_stages_ms": per_rank,
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in stages.items()},
+        # The step as a sum of NON-overlapping parts (round 5).  "describe" is the describe stage as the stream sees it: its mask
+        # branch (incidence, adjacency) runs on a second stream BESIDE the assignment pass, so those three timers overlap -- each is
+        # inflated by the contention and their sum exceeds the stage (do not add them); the stage itself, the search's three timers
+        # and the vote do not overlap.  gap = what the host leaves between them (launch latency, the search's two read-backs).
+        "step_accounting_ms": (lambda d_, s_: {"describe": round(d_, 4), "search": round(s_, 4), "vote": round(stages.get("vote", {}).get("ms_per_step", 0.0), 4),
+                                              "sum": round(d_ + s_ + stages.get("vote", {}).get("ms_per_step", 0.0), 4),
+                                              "step": round(dt / a.steps * 1e3, 4),
+                                              "gap": round(dt / a.steps * 1e3 - d_ - s_ - stages.get("vote", {}).get("ms_per_step", 0.0), 4)})(
+            stages["describe"]["ms_per_step"] if "describe" in stages else sum(stages[x]["ms_per_step"] for x in ("incidence", "adjacency", "assign", "prep", "aggregate", "pca") if x in stages),
+            sum(stages[x]["ms_per_step"] for x in ("knn_level0", "knn_gemm", "knn_select", "knn_redo", "knn_fallback") if x in stages)),
         "roofline": roof, "roofline_vlad": vlad_roof, "roofline_pca": pca_roof, "roofline_knn_stream": stream_roof,
     }
 

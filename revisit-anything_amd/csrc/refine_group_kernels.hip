@@ -9,7 +9,7 @@
 //
 // Here G consecutive query rows form a group (G = option "query_group" when it is 1 .. 64 -- the caller's hint that the query
 // rows come in runs of G per image, so that groups coincide with images -- else 32):
-//   refine_union_kernel        sorted union of the group's band lists (LDS bitonic sort + unique); a group whose union
+//   refine_union_kernel        sorted union of the group's band lists (LDS hash set, then a sort of the distinct ids); a group whose union
 //                              is not cheaper to evaluate than its bands row by row (a cost model with measured constants:
 //                              nothing shared -- random queries --, or short bands against a long union), or longer than
 //                              RG_UCAP, keeps the per-row kernels (its rows are flagged in `perrow`)
@@ -66,12 +66,13 @@ __device__ __forceinline__ void rg_bitonic(T* a, int n, int tid) {
 // ---- union of a group's band lists ---------------------------------------------------------------------------------------
 constexpr int RG_UT = 1024;   // threads of the union kernel (the sort is its time)
 __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __restrict__ ref_cnt, const uint32_t* __restrict__ ref_id,
-                                                           int rcap, int m, int G, int d, int force, int ucap, uint32_t* __restrict__ grp_cnt,
+                                                           int rcap, int m, int G, int d, int force, int ucap, int tcap /* hash slots: a power of two */,
+                                                           uint32_t* __restrict__ grp_cnt,
                                                            uint32_t* __restrict__ grp_ids, uint32_t* __restrict__ perrow,
                                                            uint32_t* __restrict__ work /* [0] = count, then items */,
                                                            uint16_t* __restrict__ grp_pos /* [m][rcap]: union column of every band entry */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* buf = reinterpret_cast<uint32_t*>(smem);   // [pow2 >= G * rcap]
+  uint32_t* buf = reinterpret_cast<uint32_t*>(smem);   // [tcap] hash set of the group's band ids
   __shared__ uint32_t off[RG_GMAX + 1];
   __shared__ uint32_t wtot[RG_UT / 64];
   const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -91,21 +92,36 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
   const int total = (int)off[G];
   bool grouped = false;
   int U = 0;
-  if (total > 0) {
-    int np2 = 64;
-    while (np2 < total) np2 <<= 1;
+  // The distinct ids through an LDS hash set (open addressing, atomicCAS), then ONLY those are sorted: the first version sorted
+  // all band entries (13 500 -> 16 384 slots, 105 bitonic stages: ~150 us per group and 0.15-0.19 ms per 200 query images, as
+  // much as the GEMM it feeds); the set's contents do not depend on the insertion order, the sort makes their order canonical.
+  uint32_t* uniq = buf + tcap;                           // [ucap + RG_UT]: the distinct ids
+  __shared__ uint32_t s_over;
+  if (total > 0 && 4 * total <= 3 * tcap) {              // (load factor <= 0.75; beyond: the group stays with the per-row kernels)
+    const uint32_t mask = (uint32_t)tcap - 1u;
+    for (int j = tid; j < tcap; j += RG_UT) buf[j] = 0xffffffffu;
+    if (tid == 0) s_over = 0u;
+    __syncthreads();
     for (int t = w; t < nrows; t += RG_UT / 64) {
       const int c = (int)(off[t + 1] - off[t]);
-      for (int j = l; j < c; j += 64) buf[off[t] + j] = ref_id[(size_t)(q0 + t) * rcap + j];
+      for (int j = l; j < c; j += 64) {
+        const uint32_t id = ref_id[(size_t)(q0 + t) * rcap + j];
+        uint32_t h = (id * 2654435761u) & mask;
+        for (;;) {
+          const uint32_t prev = atomicCAS(&buf[h], 0xffffffffu, id);
+          if (prev == 0xffffffffu || prev == id) break;
+          h = (h + 1u) & mask;
+        }
+      }
     }
-    for (int j = total + tid; j < np2; j += RG_UT) buf[j] = 0xffffffffu;
-    rg_bitonic<uint32_t, RG_UT>(buf, np2, tid);
-    // unique, in order: positions from a ballot prefix per wave + the waves' totals
+    __syncthreads();
+    // compaction of the occupied slots (ballot prefix per wave + the waves' totals)
     uint32_t base = 0;
-    for (int j0 = 0; j0 < total; j0 += RG_UT) {
+    for (int j0 = 0; j0 < tcap; j0 += RG_UT) {
       const int j = j0 + tid;
-      const bool first = j < total && (j == 0 || buf[j] != buf[j - 1]);
-      const uint64_t mk = __builtin_amdgcn_ballot_w64(first);
+      const uint32_t v = buf[j];
+      const bool have = v != 0xffffffffu;
+      const uint64_t mk = __builtin_amdgcn_ballot_w64(have);
       if (l == 0) wtot[w] = (uint32_t)__popcll(mk);
       __syncthreads();
       uint32_t o = base, all = 0;
@@ -114,14 +130,18 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
         all += wtot[x];
       }
       const uint32_t pos = o + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-      const uint32_t idj = first ? buf[j] : 0u;
-      if (first && pos < (uint32_t)ucap) grp_ids[(size_t)b * ucap + pos] = idj;
+      if (have && pos < (uint32_t)ucap) uniq[pos] = v;
       base += all;
-      __syncthreads();            // every read of this chunk (buf[j], buf[j - 1]) precedes its writes, which land at positions <= j
-      if (first) buf[pos] = idj;  // the unique ids, compacted to the front of the LDS list
+      __syncthreads();
     }
-    __syncthreads();
     U = (int)base;
+    if (U <= ucap) {
+      int np2 = 64;
+      while (np2 < U) np2 <<= 1;
+      for (int j = U + tid; j < np2; j += RG_UT) uniq[j] = 0xffffffffu;
+      rg_bitonic<uint32_t, RG_UT>(uniq, np2, tid);
+      for (int j = tid; j < U; j += RG_UT) grp_ids[(size_t)b * ucap + j] = uniq[j];
+    }
     // Is the union cheaper?  Measured on MI355X (ns, d = 1024; the first two terms grow with d): the per-row kernels ~0.46 per
     // (query, row) pair of the bands; the union GEMM ~0.038 per slot of its 64 x 128 tiles, whatever their fill; the per-query
     // sort of a band's keys ~0.022 per slot of its power-of-two list (~1.5 slots per band entry).  (200-deep bands of an image's 50 segments on a 1 M-row index:
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
           int lo = 0, hi = U;
           while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (buf[mid] < id) lo = mid + 1;
+            if (uniq[mid] < id) lo = mid + 1;
             else hi = mid;
           }
           grp_pos[(size_t)(q0 + t) * rcap + j] = (uint16_t)lo;
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
 // workgroup in flight while the previous super-tile is multiplied out of LDS) and is parked in a single LDS buffer between two
 // barriers.  The loads are inline asm with an explicit wait: a compiler-visible load with a condition on it makes every LDS
 // access behind it wait for all of them.
-// LDS image: ROW-major, row stride RG_LDR = RG_KS + 4 floats, and inside every group of 8 k the even k first, then the odd:
+// LDS image: ROW-major, row stride KS + 4 floats, and inside every group of 8 k the even k first, then the odd:
 // [k0 k2 k4 k6 | k1 k3 k5 k7].  v_mfma_f32_32x32x2_f32 takes k = 2 s from lanes 0-31 and k = 2 s + 1 from lanes 32-63, so a
 // lane's operands of FOUR consecutive k-steps are one aligned 16-byte read (rows 16 apart share a bank group, which the
 // 16-lane service groups of a ds_read_b128 never hold together), and a loaded float4 goes out as two 8-byte writes.
@@ -176,51 +196,57 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
 typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
 typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
 #define RG_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-constexpr int RG_KS = 128;
-constexpr int RG_LDR = RG_KS + 4;
+constexpr int RG_KS = 128;    // deep rows (d > 4096): 512-byte row pieces, one workgroup per CU
+constexpr int RG_KS_SHALLOW = 64;   // d <= 4096 (rows of a few KiB, re-read out of L2): 256-byte pieces, half the LDS -- three
+                                    // workgroups per CU instead of one hide each other's load / store / barrier phases
 
-template <int MT>
+template <int MT, int KS>
 __global__ __launch_bounds__(256) void refine_group_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d, int m,
                                                                 int G, const float* __restrict__ qn, const float* __restrict__ rn,
                                                                 const uint32_t* __restrict__ grp_cnt,
                                                                 const uint32_t* __restrict__ grp_ids, int ucap,
                                                                 uint64_t* __restrict__ keys, const uint32_t* __restrict__ work) {
+  constexpr int LDR = KS + 4;         // row stride of the LDS image
+  constexpr int LPR = KS / 4;         // lanes (16-byte loads) per row piece
+  constexpr int RPI = 64 / LPR;       // rows per load instruction of a wave
   constexpr int NR = 32 * MT + 128;   // rows of a super-tile: the group's query rows, then 128 union rows
-  constexpr int NLD = NR / 8;         // 16-byte loads per thread and super-tile (a wave's instruction: 2 rows x 512 B)
+  constexpr int NLD = NR / (4 * RPI); // 16-byte loads per thread and super-tile
+  static_assert(NR % (4 * RPI) == 0 && (32 * MT) % (4 * RPI) == 0, "whole instructions of query rows / of union rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* tile = reinterpret_cast<float*>(smem);                        // [NR][RG_LDR]
-  uint32_t* ids = reinterpret_cast<uint32_t*>(tile + NR * RG_LDR);     // [128]
+  float* tile = reinterpret_cast<float*>(smem);                     // [NR][LDR]
+  uint32_t* ids = reinterpret_cast<uint32_t*>(tile + NR * LDR);     // [128]
   if (blockIdx.x >= work[0]) return;
   const uint32_t item = work[1 + blockIdx.x];
   const int b = (int)(item >> 5), c0 = (int)(item & 31u) * 128;
   const int U = (int)grp_cnt[b];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
+  const int lp = l % LPR, lr = l / LPR;   // loader coordinates: 16-byte piece of a row, row of the instruction
   const int q0 = b * G;
   const int q_end = min(q0 + G, m);
   if (tid < 128) ids[tid] = grp_ids[(size_t)b * ucap + (c0 + tid < U ? c0 + tid : 0)];   // (columns beyond U: a valid row, never stored)
   __syncthreads();
-  // load j of this thread: staged row rr = 8 j + 2 w + (l >> 5), floats 4 (l & 31) .. + 3 of the super-tile
+  // load j of this thread: staged row rr = 4 RPI j + RPI w + lr, floats 4 lp .. + 3 of the super-tile
   const float* src[NLD];
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
-    const int rr = 8 * j + 2 * w + kk;
+    const int rr = 4 * RPI * j + RPI * w + lr;
     src[j] = (rr < 32 * MT ? Q + (size_t)min(q0 + rr, q_end - 1) * d   // (rows beyond the group: never stored)
-                           : R + (size_t)ids[rr - 32 * MT] * d) + 4 * i;
+                           : R + (size_t)ids[rr - 32 * MT] * d) + 4 * lp;
   }
   rg_f32x4 v[NLD];
   auto gload = [&](int st) {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) RG_GLOAD(v[j], src[j] + (size_t)st * RG_KS);
+    for (int j = 0; j < NLD; ++j) RG_GLOAD(v[j], src[j] + (size_t)st * KS);
   };
-  // floats 4 i .. 4 i + 3 = k-group i >> 1, half i & 1: the even k to slots 2 (i & 1) .. + 1, the odd k four slots further
-  float* st_base = tile + (2 * w + kk) * RG_LDR + 8 * (i >> 1) + 2 * (i & 1);
+  // floats 4 lp .. 4 lp + 3 = k-group lp >> 1, half lp & 1: the even k to slots 2 (lp & 1) .. + 1, the odd k four slots further
+  float* st_base = tile + (RPI * w + lr) * LDR + 8 * (lp >> 1) + 2 * (lp & 1);
   auto sstore = [&]() {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) asm volatile("" : "+v"(v[j]));   // (the values exist from HERE on: behind the caller's wait; the
                                                                    //  re-packing moves below are not memory operations)
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      float* p = st_base + 8 * j * RG_LDR;
+      float* p = st_base + 4 * RPI * j * LDR;
       rg_f32x2 ev, od;
       ev[0] = v[j][0];
       ev[1] = v[j][2];
@@ -235,26 +261,26 @@ __global__ __launch_bounds__(256) void refine_group_gemm_kernel(const float* __r
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const float* a_frag = tile + i * RG_LDR + 4 * kk;                       // + 32 t rows, + 8 g floats
-  const float* b_frag = tile + (32 * MT + 32 * w + i) * RG_LDR + 4 * kk;
-  const int nst = d / RG_KS;
+  const float* a_frag = tile + i * LDR + 4 * kk;                       // + 32 t rows, + 8 g floats
+  const float* b_frag = tile + (32 * MT + 32 * w + i) * LDR + 4 * kk;
+  const int nst = d / KS;
   gload(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   sstore();
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
     if (st + 1 < nst) gload(st + 1);   // in flight while this super-tile is multiplied
-    // 16 groups of 8 k; the fragments of group g + 1 are requested before the MFMAs of group g are issued
+    // KS / 8 groups of 8 k; the fragments of group g + 1 are requested before the MFMAs of group g are issued
     rg_f32x4 fa[2][MT], fb[2];
     fb[0] = *reinterpret_cast<const rg_f32x4*>(b_frag);
 #pragma unroll
-    for (int t = 0; t < MT; ++t) fa[0][t] = *reinterpret_cast<const rg_f32x4*>(a_frag + 32 * t * RG_LDR);
+    for (int t = 0; t < MT; ++t) fa[0][t] = *reinterpret_cast<const rg_f32x4*>(a_frag + 32 * t * LDR);
 #pragma unroll
-    for (int g = 0; g < RG_KS / 8; ++g) {
-      if (g + 1 < RG_KS / 8) {
+    for (int g = 0; g < KS / 8; ++g) {
+      if (g + 1 < KS / 8) {
         fb[(g + 1) & 1] = *reinterpret_cast<const rg_f32x4*>(b_frag + 8 * (g + 1));
 #pragma unroll
-        for (int t = 0; t < MT; ++t) fa[(g + 1) & 1][t] = *reinterpret_cast<const rg_f32x4*>(a_frag + 32 * t * RG_LDR + 8 * (g + 1));
+        for (int t = 0; t < MT; ++t) fa[(g + 1) & 1][t] = *reinterpret_cast<const rg_f32x4*>(a_frag + 32 * t * LDR + 8 * (g + 1));
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -326,9 +352,11 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
   if (nq <= 0) return SEGVLAD_OK;
   const int ucap = SV_RG_UCAP;
   const int G = rg_group_rows(ctx);
-  int lpad = 64;
-  while (lpad < G * rcap) lpad <<= 1;
-  const bool can = ctx->opt.refine_group != 0 && d % RG_KS == 0 && nq > 128 && (size_t)lpad * 4 <= 128 * 1024 && rcap <= 4096 &&
+  // hash slots of the union kernel: load factor <= 0.75 for a group whose bands are all full, capped at 32 768 (128 KiB of LDS;
+  // a group with more band entries than 0.75 x that stays with the per-row kernels)
+  int tcap = 1024;
+  while (tcap < 32768 && 3 * (int64_t)tcap < 4 * (int64_t)G * rcap) tcap <<= 1;
+  const bool can = ctx->opt.refine_group != 0 && d % RG_KS == 0 && nq > 128 && rcap <= 4096 &&
                    (reinterpret_cast<uintptr_t>(Q) & 15) == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0;
   if (!can) {
     if (launches) *launches = 1;
@@ -349,15 +377,18 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
   SV_HIP(ctx->s_grp_work.reserve((size_t)(max_items + 1) * 4));
   uint32_t* work = ctx->s_grp_work.as<uint32_t>();
   SV_HIP(hipMemsetAsync(work, 0, 4, ctx->stream));
-  const size_t ulds = (size_t)lpad * 4;
+  const size_t ulds = ((size_t)tcap + (size_t)ucap + RG_UT) * 4;
   if (ulds + 1024 > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_union_kernel), ulds));
   hipLaunchKernelGGL(refine_union_kernel, dim3(nb), dim3(RG_UT), ulds, ctx->stream, ref_cnt, ref_id, rcap, nq, G, d,
-                     ctx->opt.refine_group == 2 ? 1 : 0, ucap, gcnt, gids, prow, work, ctx->s_grp_pos.as<uint16_t>());
+                     ctx->opt.refine_group == 2 ? 1 : 0, ucap, tcap, gcnt, gids, prow, work, ctx->s_grp_pos.as<uint16_t>());
   SV_HIP(hipGetLastError());
   {
     const int mt = G > 32 ? 2 : 1;
-    const size_t glds = (size_t)(32 * mt + 128) * RG_LDR * 4 + 128 * 4;
-    auto gk = mt == 2 ? refine_group_gemm_kernel<2> : refine_group_gemm_kernel<1>;
+    const bool deep = d > 4096;
+    const int ks = deep ? RG_KS : RG_KS_SHALLOW;
+    const size_t glds = (size_t)(32 * mt + 128) * (ks + 4) * 4 + 128 * 4;
+    auto gk = deep ? (mt == 2 ? refine_group_gemm_kernel<2, RG_KS> : refine_group_gemm_kernel<1, RG_KS>)
+                   : (mt == 2 ? refine_group_gemm_kernel<2, RG_KS_SHALLOW> : refine_group_gemm_kernel<1, RG_KS_SHALLOW>);
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(gk), glds));
     hipLaunchKernelGGL(gk, dim3(max_items), dim3(256), glds, ctx->stream, Q, R, d, nq, G, qn, rn, gcnt, gids, ucap, gkeys, work);
     SV_HIP(hipGetLastError());
