@@ -300,9 +300,11 @@ int sv_launch_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, i
 // Qhull's (which decides such cases by its own perturbation rules).
 // S <= 3 reproduces the reference's special case: every row = e0 (+ e1).
 // ------------------------------------------------------------------------------------------------
-constexpr int ADJ_T = 1024;   // threads per image: S (S - 1) / 2 point pairs, ~1 per thread at S = 50 (round 5: 256 threads walked ~10
-                              // pairs each -- half of them skipped -- one fp64 division chain after the other: 150-210 us per launch)
-__global__ __launch_bounds__(ADJ_T) void adjacency_kernel(const double* __restrict__ cent,
+// Threads per image (= blockDim.x, a launch parameter): up to 1024 -- S (S - 1) / 2 point pairs, ~1 per thread at S = 50 -- for
+// small batches, where the launch is one image's latency (round 5: 256 threads walked ~10 pairs each, half of them skipped, one
+// fp64 division chain after the other: 207 -> 39 us for 25 images); 256 for large batches, where 16-wave workgroups only wait for a
+// whole CU beside the assignment pass they are overlapped with (717 us for 200 images, 1024 threads, under that pass).
+__global__ __launch_bounds__(1024) void adjacency_kernel(const double* __restrict__ cent,
                                                         const int32_t* __restrict__ seg_off,
                                                         const int64_t* __restrict__ adj_off, int order, int S_max,
                                                         uint8_t* __restrict__ adj, uint32_t* __restrict__ n_bad,
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(ADJ_T) void adjacency_kernel(const double* __restri
   const int tid = threadIdx.x;
   if (S == 0) return;
   uint8_t* out = adj + adj_off[b];
-  for (int s = tid; s < S; s += ADJ_T) {
+  for (int s = tid; s < S; s += (int)blockDim.x) {
     px[s] = cent[2 * (size_t)(s0 + s)];
     py[s] = cent[2 * (size_t)(s0 + s) + 1];
     if (px[s] != px[s]) {  // NaN centroid = empty mask (reference: ValueError)
@@ -327,20 +329,20 @@ __global__ __launch_bounds__(ADJ_T) void adjacency_kernel(const double* __restri
       if (img_flags) img_flags[b] = (uint8_t)(img_flags[b] | 1u);   // (same value from every writer; bit 1 is set later, by one thread)
     }
   }
-  for (int j = tid; j < S * SW; j += ADJ_T) A1[j] = 0;
+  for (int j = tid; j < S * SW; j += (int)blockDim.x) A1[j] = 0;
   __shared__ int degenerate;
   if (tid == 0) degenerate = 0;
   __syncthreads();
   if (S <= 3) {
-    for (int j = tid; j < S * S; j += ADJ_T) {
+    for (int j = tid; j < S * S; j += (int)blockDim.x) {
       const int w = j % S;
       out[j] = (w == 0 || (w == 1 && S > 1)) ? 1 : 0;
     }
     return;
   }
-  for (int u = tid; u < S; u += ADJ_T) atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (u >> 6)]), 1ull << (u & 63));
+  for (int u = tid; u < S; u += (int)blockDim.x) atomicOr(reinterpret_cast<unsigned long long*>(&A1[u * SW + (u >> 6)]), 1ull << (u & 63));
   const int npairs = S * (S - 1) / 2;
-  for (int e = tid; e < npairs; e += ADJ_T) {
+  for (int e = tid; e < npairs; e += (int)blockDim.x) {
     // pair e of the strict upper triangle, row-major: row u starts at u (2 S - u - 1) / 2
     int u = (int)(((double)(2 * S - 1) - sqrt((double)(2 * S - 1) * (double)(2 * S - 1) - 8.0 * (double)e)) * 0.5);
     while (u > 0 && u * (2 * S - u - 1) / 2 > e) --u;
@@ -388,10 +390,10 @@ __global__ __launch_bounds__(ADJ_T) void adjacency_kernel(const double* __restri
     if (n_bad) atomicAdd(n_bad, 65536u);
     if (img_flags) img_flags[b] = (uint8_t)(img_flags[b] | 2u);
   }
-  for (int j = tid; j < S * SW; j += ADJ_T) P[j] = A1[j];
+  for (int j = tid; j < S * SW; j += (int)blockDim.x) P[j] = A1[j];
   __syncthreads();
   for (int it = 1; it < order; ++it) {  // P <- (P . A1) > 0
-    for (int j = tid; j < S * SW; j += ADJ_T) {
+    for (int j = tid; j < S * SW; j += (int)blockDim.x) {
       const int v = j / SW, w = j - v * SW;
       uint64_t acc = 0;
       for (int uw = 0; uw < SW; ++uw) {
@@ -405,10 +407,10 @@ __global__ __launch_bounds__(ADJ_T) void adjacency_kernel(const double* __restri
       Q[j] = acc;
     }
     __syncthreads();
-    for (int j = tid; j < S * SW; j += ADJ_T) P[j] = Q[j];
+    for (int j = tid; j < S * SW; j += (int)blockDim.x) P[j] = Q[j];
     __syncthreads();
   }
-  for (int j = tid; j < S * S; j += ADJ_T) {
+  for (int j = tid; j < S * S; j += (int)blockDim.x) {
     const int v = j / S, w = j - v * S;
     out[j] = (uint8_t)((P[v * SW + (w >> 6)] >> (w & 63)) & 1ull);
   }
@@ -423,7 +425,7 @@ int sv_launch_adjacency(segvlad_ctx* ctx, const double* cent, const int32_t* seg
     return ctx->fail(SEGVLAD_ERR_LIMIT, "adjacency: %d segments in one image exceed the LDS budget (%zu B)", S_max, lds);
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(adjacency_kernel), (size_t)lds));
-  hipLaunchKernelGGL(adjacency_kernel, dim3(B), dim3(ADJ_T), lds, ctx->stream, cent, seg_off_dev, adj_off_dev, order, S_max,
+  hipLaunchKernelGGL(adjacency_kernel, dim3(B), dim3(B <= 64 ? 1024 : 256), lds, ctx->stream, cent, seg_off_dev, adj_off_dev, order, S_max,
                      adj, n_bad, img_flags);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
