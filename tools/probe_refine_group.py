@@ -1,6 +1,6 @@
 """Stage times of the exact refinement, grouped (csrc/refine_group_kernels.hip) against per row, on planted data:
 `places` groups of `per` near-duplicate rows, a query image = `seg` noisy copies of one place's rows.
-  python tools/probe_refine_group.py [d] [places] [per] [k]        (SEGVLAD_RG_ABL: timing ablations of the GEMM, dev builds)"""
+  python tools/probe_refine_group.py [d] [places] [per] [k]"""
 import os
 import sys
 
@@ -47,6 +47,6 @@ for mode in (0, 1):
     same = None if ref is None else bool(torch.equal(ref[0], out[0]) and torch.equal(ref[1], out[1]))
     if ref is None:
         ref = out
-    print(f"[refine probe] d={d} rows={places * per} k={k} refine_group={mode} abl={os.environ.get('SEGVLAD_RG_ABL', '0')}: "
+    print(f"[refine probe] d={d} rows={places * per} k={k} refine_group={mode}: "
           f"{ {a: round(b, 3) for a, b in ms.items()} } refine_sum {st['refine_sum']} groups {st['grp_groups']} "
           f"union_sum {st['grp_union_sum']} identical_to_per_row {same}", flush=True)
