@@ -123,3 +123,19 @@ def test_image_sized_groups_via_the_hint(hint, d):
     Q = Q[:Q.shape[0] - 3]
     st = _both(R, Q, 40, hint=hint)
     assert st["grp_groups"] >= 1, st
+
+
+def test_two_chunks_of_query_rows_groups_cut_by_the_chunk_boundary():
+    """More than 16 384 query rows: the search walks them in two chunks (the first chunk's exact sample level is enqueued
+    before the host waits for the query scalars), the refinement groups restart at the chunk boundary -- 16 384 is no
+    multiple of the 50 rows of an image, so the boundary cuts an image in two -- and every row still gets its bits."""
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(71)
+    d, places, per, hint = 128, 1300, 50, 50
+    R = _places(g, places, per, d, 0.6)
+    n_img = 340                                            # 17 000 query rows
+    pick = torch.randint(0, places, (n_img,), device="cuda:0", generator=g)
+    rows = (pick[:, None] * per + torch.arange(hint, device="cuda:0")[None, :]).reshape(-1)
+    Q = _unit(R[rows] + 0.3 * torch.randn(rows.numel(), d, device="cuda:0", generator=g) / d ** 0.5)
+    st = _both(R, Q, 30, hint=hint)
+    assert st["n_queries"] == 17_000 and st["grp_groups"] >= 300, st
