@@ -1424,9 +1424,16 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
           StageScope sc(ctx, "knn_select");
           SV_TRY(sv_launch_refine2_compact(ctx, rovf_rows, ref_lim, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
                                            ctx->s_cand_id.as<uint32_t>(), m, SV_CAP));
-          SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP,
-                                        k, out_d2, out_idx, rovf_rows));
-          sc.count(2);
+          if (m > 128 && d > 4096) {   // deep rows: a second-tier list as its own union GEMM (parallel over its 128-row tiles)
+            int nl = 0;
+            SV_TRY(sv_launch_refine_grouped(ctx, qp, R, m, d, qn, rn, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP,
+                                            k, out_d2, out_idx, &nl, rovf_rows, (int)h_cnt[1]));
+            sc.count(1 + nl);
+          } else {
+            SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP,
+                                          k, out_d2, out_idx, rovf_rows));
+            sc.count(2);
+          }
           ctx->sstats.n_refine2 += h_cnt[1];
         }
         if (ctx->opt.search_stats) {

@@ -415,7 +415,7 @@ int sv_refine_small_repair(segvlad_ctx* ctx);
 constexpr int SV_RG_UCAP = 2048;   // longest union a group may hold (longer: its rows keep the per-row kernels)
 int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                              const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
-                             int* launches);
+                             int* launches, const uint32_t* only_rows = nullptr, int live_groups_hint = 0);
 int sv_refine_group_stats(segvlad_ctx* ctx, int nq, int64_t* groups, int64_t* grouped, int64_t* union_sum);
 int sv_row_norm_max(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);
 int sv_row_norm_min(segvlad_ctx* ctx, const float* norms, int64_t n, float* out_host);

@@ -11,6 +11,8 @@
 // LDS ([k][row], row stride 129) so that an MFMA operand read is 32 consecutive dwords per half-wave
 // (conflict-free ds_read_b32) and the transposing stores are conflict-free too; LDS is double
 // buffered (one barrier per k-tile), global loads run two k-tiles ahead in registers.
+#include <algorithm>
+
 #include "ctx.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -287,8 +289,15 @@ static int gemm_launch(segvlad_ctx* ctx, int mode, const float* A, const float* 
   // a handful of distance tiles (the sampled exact level of a single-image pass: 50 queries x 244 rows = 2 tiles whose
   // 1024-deep fp32 k-loop is 90 us of pure latency): split K over 8-16 workgroups per tile.  Only where the caller allows
   // it -- the distances then feed thresholds; the matrix path, whose sums are the reference for bit-identity, never splits.
-  const bool d2_split = split_d2 && mode == 1 && tiles <= 32 && Kd >= 16 * BK;
-  if (d2_split) {
+  // ... and a sample level over DEEP rows (raw K*D descriptors: 10 000 queries x 195 sample rows x 98 304 = 158 tiles with a
+  // 3072-tile k-loop each, 0.6 of a wave of workgroups on the chip: 8.8 ms at 43 TF): K split so that ~3 workgroups per CU exist
+  const bool deep_split = split_d2 && mode == 1 && tiles > 32 && tiles < 512 && Kd >= 8192;
+  const bool d2_split = split_d2 && mode == 1 && (tiles <= 32 || deep_split) && Kd >= 16 * BK;
+  if (deep_split) {
+    splits = (int)std::min<int64_t>(16, std::max<int64_t>(2, 768 / tiles));
+    k_per_split = (((Kd + splits - 1) / splits) + BK - 1) / BK * BK;
+    splits = (Kd + k_per_split - 1) / k_per_split;
+  } else if (d2_split) {
     // (four k-tiles of 32 per workgroup; two or one -- 16 / 32 slices -- measured slower: 46 vs 41 us for GEMM + reduce)
     splits = Kd / (4 * BK) < 16 ? Kd / (4 * BK) : 16;
     k_per_split = (((Kd + splits - 1) / splits) + BK - 1) / BK * BK;

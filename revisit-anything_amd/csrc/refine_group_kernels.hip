@@ -70,7 +70,8 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
                                                            uint32_t* __restrict__ grp_cnt,
                                                            uint32_t* __restrict__ grp_ids, uint32_t* __restrict__ perrow,
                                                            uint32_t* __restrict__ work /* [0] = count, then items */,
-                                                           uint16_t* __restrict__ grp_pos /* [m][rcap]: union column of every band entry */) {
+                                                           uint16_t* __restrict__ grp_pos /* [m][rcap]: union column of every band entry */,
+                                                           const uint32_t* __restrict__ only_rows /* G = 1: rows to look at, or null */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* buf = reinterpret_cast<uint32_t*>(smem);   // [tcap] hash set of the group's band ids
   __shared__ uint32_t off[RG_GMAX + 1];
@@ -78,6 +79,11 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
   const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int q0 = b * G;
   const int nrows = min(G, m - q0);
+  if (only_rows && !only_rows[q0]) {   // (second tier: one-row groups, only the flagged rows exist)
+    if (tid == 0) grp_cnt[b] = 0u;
+    if (tid < nrows) perrow[q0 + tid] = 0u;
+    return;
+  }
   if (tid == 0) {
     uint32_t s = 0;
     for (int t = 0; t < G; ++t) {
@@ -181,11 +187,13 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
 }
 
 // ---- G query rows x the union's rows: exact fp32 distances as sortable keys -----------------------------------------------
-// Every row is fetched in pieces of RG_KS floats (512 B): one load instruction of a wave covers two rows x 512 contiguous
-// bytes.  A super-tile of RG_KS k travels in ONE register stage ((MT + 4) x 4 sixteen-byte loads per thread: 96 KiB per
-// workgroup in flight while the previous super-tile is multiplied out of LDS) and is parked in a single LDS buffer between two
-// barriers.  The loads are inline asm with an explicit wait: a compiler-visible load with a condition on it makes every LDS
-// access behind it wait for all of them.
+// Every row is fetched in pieces of RG_KS floats (128 B): one load instruction of a wave covers eight rows x 128 contiguous
+// bytes.  A super-tile of RG_KS k travels in ONE register stage ((MT + 4) x 4 / 4 sixteen-byte loads per thread, in flight
+// while the previous super-tile is multiplied out of LDS) and is parked in a single LDS buffer between two barriers; with
+// 27 KiB of LDS a CU holds five workgroups, which hide each other's load / store / barrier phases.  (Measured, 200 groups of
+// 200-row unions: 512-byte pieces and one workgroup per CU 8.63 ms at d = 98 304 / 0.384 ms at d = 1024, 256-byte pieces
+// 7.70 / 0.378, 128-byte pieces 7.51 / 0.362.)  The loads are inline asm with an explicit wait: a compiler-visible load with
+// a condition on it makes every LDS access behind it wait for all of them.
 // LDS image: ROW-major, row stride KS + 4 floats, and inside every group of 8 k the even k first, then the odd:
 // [k0 k2 k4 k6 | k1 k3 k5 k7].  v_mfma_f32_32x32x2_f32 takes k = 2 s from lanes 0-31 and k = 2 s + 1 from lanes 32-63, so a
 // lane's operands of FOUR consecutive k-steps are one aligned 16-byte read (rows 16 apart share a bank group, which the
@@ -196,9 +204,7 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
 typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
 typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
 #define RG_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-constexpr int RG_KS = 128;    // deep rows (d > 4096): 512-byte row pieces, one workgroup per CU
-constexpr int RG_KS_SHALLOW = 64;   // d <= 4096 (rows of a few KiB, re-read out of L2): 256-byte pieces, half the LDS -- three
-                                    // workgroups per CU instead of one hide each other's load / store / barrier phases
+constexpr int RG_KS = 32;
 
 template <int MT, int KS>
 __global__ __launch_bounds__(256) void refine_group_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ R, int d, int m,
@@ -347,20 +353,23 @@ static int rg_group_rows(const segvlad_ctx* ctx) {
 // grouping does not apply to) through the per-row kernels.  Same outputs as sv_launch_refine_exact, bit for bit.
 int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                              const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
-                             int* launches) {
+                             int* launches, const uint32_t* only_rows, int live_groups_hint) {
   if (launches) *launches = 0;
   if (nq <= 0) return SEGVLAD_OK;
   const int ucap = SV_RG_UCAP;
-  const int G = rg_group_rows(ctx);
+  // only_rows (the second tier: a few flagged rows, each with a list of up to 8192 entries): one-row groups, always through the
+  // union GEMM when the band fits it -- what is bought there is PARALLELISM (a list walked by one workgroup of the per-row kernel
+  // is one latency chain: 4.6 ms for one 600-row band of 98 304-d rows), not shared rows
+  const int G = only_rows ? 1 : rg_group_rows(ctx);
   // hash slots of the union kernel: load factor <= 0.75 for a group whose bands are all full, capped at 32 768 (128 KiB of LDS;
   // a group with more band entries than 0.75 x that stays with the per-row kernels)
   int tcap = 1024;
   while (tcap < 32768 && 3 * (int64_t)tcap < 4 * (int64_t)G * rcap) tcap <<= 1;
-  const bool can = ctx->opt.refine_group != 0 && d % RG_KS == 0 && nq > 128 && rcap <= 4096 &&
+  const bool can = ctx->opt.refine_group != 0 && d % RG_KS == 0 && nq > 128 && (rcap <= 4096 || only_rows) &&
                    (reinterpret_cast<uintptr_t>(Q) & 15) == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0;
   if (!can) {
     if (launches) *launches = 1;
-    return sv_launch_refine_exact(ctx, Q, R, nq, d, qn, rn, ref_cnt, ref_id, rcap, k, d2_out, idx_out);
+    return sv_launch_refine_exact(ctx, Q, R, nq, d, qn, rn, ref_cnt, ref_id, rcap, k, d2_out, idx_out, only_rows);
   }
   const int nb = (nq + G - 1) / G;
   SV_HIP(ctx->s_grp_cnt.reserve((size_t)nb * 4));
@@ -373,22 +382,21 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
   uint32_t* prow = ctx->s_grp_rows.as<uint32_t>();
   uint64_t* gkeys = ctx->s_grp_keys.as<uint64_t>();
   static_assert(SV_RG_UCAP / 128 <= 32, "a work item holds its tile in 5 bits");
-  const int max_items = nb * (ucap / 128);
+  // (the GEMM's grid: every group could hold ucap / 128 tiles; a caller that knows how few groups are live -- the second tier --
+  //  says so, instead of 16 early-exit workgroups per query row)
+  const int max_items = ((live_groups_hint > 0 && live_groups_hint < nb) ? live_groups_hint : nb) * (ucap / 128);
   SV_HIP(ctx->s_grp_work.reserve((size_t)(max_items + 1) * 4));
   uint32_t* work = ctx->s_grp_work.as<uint32_t>();
   SV_HIP(hipMemsetAsync(work, 0, 4, ctx->stream));
   const size_t ulds = ((size_t)tcap + (size_t)ucap + RG_UT) * 4;
   if (ulds + 1024 > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_union_kernel), ulds));
   hipLaunchKernelGGL(refine_union_kernel, dim3(nb), dim3(RG_UT), ulds, ctx->stream, ref_cnt, ref_id, rcap, nq, G, d,
-                     ctx->opt.refine_group == 2 ? 1 : 0, ucap, tcap, gcnt, gids, prow, work, ctx->s_grp_pos.as<uint16_t>());
+                     (ctx->opt.refine_group == 2 || only_rows) ? 1 : 0, ucap, tcap, gcnt, gids, prow, work, ctx->s_grp_pos.as<uint16_t>(), only_rows);
   SV_HIP(hipGetLastError());
   {
     const int mt = G > 32 ? 2 : 1;
-    const bool deep = d > 4096;
-    const int ks = deep ? RG_KS : RG_KS_SHALLOW;
-    const size_t glds = (size_t)(32 * mt + 128) * (ks + 4) * 4 + 128 * 4;
-    auto gk = deep ? (mt == 2 ? refine_group_gemm_kernel<2, RG_KS> : refine_group_gemm_kernel<1, RG_KS>)
-                   : (mt == 2 ? refine_group_gemm_kernel<2, RG_KS_SHALLOW> : refine_group_gemm_kernel<1, RG_KS_SHALLOW>);
+    const size_t glds = (size_t)(32 * mt + 128) * (RG_KS + 4) * 4 + 128 * 4;
+    auto gk = mt == 2 ? refine_group_gemm_kernel<2, RG_KS> : refine_group_gemm_kernel<1, RG_KS>;
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(gk), glds));
     hipLaunchKernelGGL(gk, dim3(max_items), dim3(256), glds, ctx->stream, Q, R, d, nq, G, qn, rn, gcnt, gids, ucap, gkeys, work);
     SV_HIP(hipGetLastError());
@@ -396,6 +404,7 @@ int sv_launch_refine_grouped(segvlad_ctx* ctx, const float* Q, const float* R, i
   {
     int rpad = 2;
     while (rpad < rcap) rpad <<= 1;
+    if ((size_t)rpad * 8 + 1024 > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_group_select_kernel), (size_t)rpad * 8));
     hipLaunchKernelGGL(refine_group_select_kernel, dim3(nq), dim3(256), (size_t)rpad * 8, ctx->stream, gcnt, gkeys, ref_cnt,
                        ctx->s_grp_pos.as<uint16_t>(), rcap, G, ucap, k, d2_out, idx_out);
     SV_HIP(hipGetLastError());

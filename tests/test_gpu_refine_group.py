@@ -108,7 +108,7 @@ def test_duplicates_and_second_tier_rows_beside_grouped_rows():
     assert st["n_refine2"] > 0, st
 
 
-@pytest.mark.parametrize("hint,d", [(50, 1024), (50, 256), (7, 256), (64, 128), (33, 1024)])
+@pytest.mark.parametrize("hint,d", [(50, 1024), (50, 256), (7, 256), (64, 128), (33, 1024), (50, 160)])
 def test_image_sized_groups_via_the_hint(hint, d):
     """option query_group: a query image's rows (here `hint` noisy copies of one place's rows) form one group -- two 32-row
     accumulator tiles per wave beyond 32 rows -- and the last group of the batch is cut."""
