@@ -102,11 +102,9 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
   // all band entries (13 500 -> 16 384 slots, 105 bitonic stages: ~150 us per group and 0.15-0.19 ms per 200 query images, as
   // much as the GEMM it feeds); the set's contents do not depend on the insertion order, the sort makes their order canonical.
   uint32_t* uniq = buf + tcap;                           // [ucap + RG_UT]: the distinct ids
-  __shared__ uint32_t s_over;
   if (total > 0 && 4 * total <= 3 * tcap) {              // (load factor <= 0.75; beyond: the group stays with the per-row kernels)
     const uint32_t mask = (uint32_t)tcap - 1u;
     for (int j = tid; j < tcap; j += RG_UT) buf[j] = 0xffffffffu;
-    if (tid == 0) s_over = 0u;
     __syncthreads();
     for (int t = w; t < nrows; t += RG_UT / 64) {
       const int c = (int)(off[t + 1] - off[t]);

@@ -54,7 +54,9 @@ def test_bench_step_predictions_equal_oracle_on_20_images():
     assert "error" not in vd and "error" not in c2v, (vd, c2v)
     assert vd["predictions_identical_to_search_200"] is True and c2v["predictions_identical_to_search_200"] is True
     assert "search 50" in vd["workload"] and "search 200" in j["config"]["workload"]
-    assert c2v["stages_ms_per_step"]["knn_select"] < 0.5 * c2["stages_ms_per_step"]["knn_select"]
+    # (round 5: with the bands of an image refined over their union the 200-deep select + refine is 14 ms, no longer 113, and the
+    #  50-deep one 7.5: still the cheaper, no longer by the factor the per-row gathers gave it)
+    assert c2v["stages_ms_per_step"]["knn_select"] < 0.8 * c2["stages_ms_per_step"]["knn_select"]
 
 
 def test_bench_two_ranks_one_gpu_equal_single_rank(tmp_path):

@@ -7,10 +7,12 @@ grep "refine probe" /tmp/pm.log
 f=$(find /tmp/pm -name '*counter_collection.csv' | head -1)
 python - "$f" <<PY
 import csv,sys,collections
+import os
+pats=os.environ.get("PMC_KERNELS","refine").split(",")    # PMC_KERNELS=refine,knn_f16_filter: the deep-row filter launches as well
 acc=collections.defaultdict(float); n=collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k=r["Kernel_Name"]
-    if "refine" not in k: continue
+    if not any(p in k for p in pats): continue
     k=k.split("(")[0][-48:]
     acc[k]+=float(r["Counter_Value"]); n[k]+=1
 for k,v in acc.items():
