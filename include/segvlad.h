@@ -145,7 +145,11 @@ int segvlad_describe(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int
  *                               indices; patch_blocks HOST: their [S_b][S_b] byte matrices, concatenated) are written over the
  *                               device's, then prep -> aggregation (-> projection) run: the result is that of segvlad_images[_pca]
  *                               with the patched adjacency.  Same tokens / inc_bits / seg_offsets / adj buffers as in begin.
- *      A begin must be followed by an end (flags is optional) before any other describe / images call on the context.       */
+ *      A begin must be followed by an end (flags is optional) before any other describe / incidence / adjacency / images /
+ *      cluster_aggregate call on the context: those return SEGVLAD_ERR_STATE while a begin is open (round 6; the rule used to
+ *      be documented only).  segvlad_describe_begin and segvlad_describe return SEGVLAD_ERR_LIMIT -- "this entry point cannot,
+ *      the separate ones can" -- for an empty batch (B == 0 or no segments), for a PCA model without the fp16x3 form
+ *      (option pca_arith=fp32, or K*D not a multiple of 32) and for an image with more segments than the in-LDS Delaunay holds.   */
 int segvlad_describe_begin(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int H, int W, int patch, const float* tokens, int B,
                            int N, const int32_t* seg_offsets, int order, uint64_t* inc_bits_out, double* centroids_out, uint8_t* adj_out,
                            uint8_t* img_flags_out, int pca);

@@ -252,6 +252,7 @@ def l2_matrix(R, Q, rows_block=0):
     for a in range(0, nr, step):
         Rd = R32[a:a + step].astype(np.float64)
         out[:, a:a + step] = (q2 + (Rd * Rd).sum(1)[None, :] - 2.0 * (q @ Rd.T)).astype(np.float32)
+    np.maximum(out, 0.0, out=out, where=out < 0)    # faiss: `if (dis < 0) dis = 0` (see knn_l2)
     return out
 
 
@@ -275,7 +276,9 @@ def topk_from_d2(d2, k):
 
 def knn_l2(R, Q, k, block=2048):
     """Exact squared-L2 top-k, ascending, ties -> lower index.  Inputs are coerced to fp32 (as
-    faiss does), distances evaluated in fp64 and rounded to fp32.  Rows beyond n_r are (inf, -1)."""
+    faiss does), distances evaluated in fp64 and rounded to fp32, negative values set to zero BEFORE the
+    selection (faiss 1.7.3 utils/distances.cpp, exhaustive_L2sqr_blas: `if (dis < 0) dis = 0`; its
+    small-batch path sums squared differences and cannot go negative either).  Rows beyond n_r are (inf, -1)."""
     R32 = np.ascontiguousarray(R, dtype=np.float32)
     Q32 = np.ascontiguousarray(Q, dtype=np.float32)
     nr, nq = R32.shape[0], Q32.shape[0]
@@ -288,6 +291,7 @@ def knn_l2(R, Q, k, block=2048):
         q = Q32[s:s + block].astype(np.float64)
         d2 = (q * q).sum(1)[:, None] + rn[None, :] - 2.0 * (q @ Rd.T)
         d2 = d2.astype(np.float32)
+        np.maximum(d2, 0.0, out=d2, where=d2 < 0)
         order = np.argsort(d2, axis=1, kind="stable")[:, :kk]
         D2[s:s + block, :kk] = np.take_along_axis(d2, order, axis=1)
         I[s:s + block, :kk] = order

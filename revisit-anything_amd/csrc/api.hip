@@ -183,6 +183,13 @@ StageScope::~StageScope() {
   if (!ctx) return SEGVLAD_ERR_ARG; \
   sv_begin(ctx)
 
+// Between segvlad_describe_begin and segvlad_describe_end the context's per-batch scratch (segment / adjacency offsets, the
+// token-major copy, the labels) belongs to THAT batch, and the mask branch is in flight on the side stream: every other entry
+// point that would write them refuses instead of describing a different batch with the open one's offsets.
+#define CHECK_NO_OPEN_DESCRIBE(what)                                                                                        \
+  if (ctx->mask_branch_on_side)                                                                                             \
+  return ctx->fail(SEGVLAD_ERR_STATE, what ": a segvlad_describe_begin is open on this context (call segvlad_describe_end first)")
+
 hipError_t sv_max_dyn_lds(const void* fn, size_t bytes) {
   static std::mutex mu;
   static std::map<std::pair<int, const void*>, size_t> done;   // largest size granted so far
@@ -471,12 +478,14 @@ static int incidence_impl(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm,
 int segvlad_incidence(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
                       uint64_t* inc_bits) {
   CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("incidence");
   return incidence_impl(ctx, masks, S, Hm, Wm, H, W, patch, inc_bits, nullptr, false);
 }
 
 int segvlad_incidence_centroids(segvlad_ctx* ctx, const uint8_t* masks, int S, int Hm, int Wm, int H, int W, int patch,
                                 uint64_t* inc_bits, double* centroids) {
   CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("incidence_centroids");
   return incidence_impl(ctx, masks, S, Hm, Wm, H, W, patch, inc_bits, centroids, true);
 }
 
@@ -541,12 +550,14 @@ static int adjacency_impl(segvlad_ctx* ctx, const double* centroids, const int32
 int segvlad_adjacency(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
                       uint8_t* adj_out, uint32_t* n_empty_out) {
   CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("adjacency");
   return adjacency_impl(ctx, centroids, seg_offsets, B, order, adj_out, n_empty_out, nullptr);
 }
 
 int segvlad_adjacency_flagged(segvlad_ctx* ctx, const double* centroids, const int32_t* seg_offsets, int B, int order,
                               uint8_t* adj_out, uint8_t* img_flags_out) {
   CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("adjacency_flagged");
   if (B > 0 && !img_flags_out) return ctx->fail(SEGVLAD_ERR_ARG, "adjacency_flagged: null img_flags_out");
   return adjacency_impl(ctx, centroids, seg_offsets, B, order, adj_out, nullptr, img_flags_out);
 }
@@ -756,6 +767,7 @@ int segvlad_images(segvlad_ctx* ctx, const float* tokens, int B, int N, const ui
                    const int32_t* seg_offsets, const uint8_t* adj, float* out, uint8_t* labels_out, float* gap_out,
                    float* block_norms_out) {
   CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("images");
   return images_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, out, labels_out, gap_out, block_norms_out, nullptr, 0);
 }
 
@@ -789,6 +801,7 @@ int segvlad_images_pca(segvlad_ctx* ctx, const float* tokens, int B, int N, cons
                        const int32_t* seg_offsets, const uint8_t* adj, float* y, int l2norm, float* desc_out,
                        uint8_t* labels_out, float* gap_out) {
   CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("images_pca");
   return images_pca_impl(ctx, tokens, B, N, inc_bits, seg_offsets, adj, y, l2norm, desc_out, labels_out, gap_out);
 }
 
@@ -812,9 +825,14 @@ static int describe_begin_impl(segvlad_ctx* ctx, const uint8_t* masks, int Hm, i
   if (patch <= 0 || N != (H / patch) * (W / patch))
     return ctx->fail(SEGVLAD_ERR_ARG, "describe: N=%d tokens do not match the %dx%d image at patch %d", N, H, W, patch);
   const int S_tot = B > 0 ? seg_offsets[B] : 0;
-  if (B == 0 || S_tot <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "describe: no images / no segments");
-  if (pca && (ctx->P == 0 || ctx->pca_w_scale <= 0.f || ctx->opt.pca_fp32))
-    return ctx->fail(SEGVLAD_ERR_STATE, "describe: needs segvlad_pca_set and the fp16x3 projection (pca_arith)");
+  // Configurations the split call does not take are reported as SEGVLAD_ERR_LIMIT -- the code of "this entry point cannot, the
+  // separate ones (incidence_centroids -> adjacency -> images[_pca]) can": an empty batch, and a PCA model without the fp16x3
+  // form (option pca_arith=fp32, or K*D not a multiple of 32: images_pca then writes the descriptor and projects it with the
+  // plain GEMM).  ADVICE r05: both used to come back as ERR_ARG / ERR_STATE, which a caller cannot tell from misuse.
+  if (B == 0 || S_tot <= 0) return ctx->fail(SEGVLAD_ERR_LIMIT, "describe: no images / no segments (use the separate entry points)");
+  if (pca && ctx->P == 0) return ctx->fail(SEGVLAD_ERR_STATE, "describe: call segvlad_pca_set first");
+  if (pca && (ctx->pca_w_scale <= 0.f || ctx->opt.pca_fp32))
+    return ctx->fail(SEGVLAD_ERR_LIMIT, "describe: the split call needs the fp16x3 projection (pca_arith; K*D %% 32 == 0): use the separate entry points");
   // pinned landing zone of the flags and the centroids (read by segvlad_describe_flags while the assignment pass runs)
   const size_t need = (size_t)B + (size_t)S_tot * 16 + 64;
   if (need > ctx->h_desc_cap) {
@@ -962,6 +980,7 @@ __global__ void fill_ones_kernel(float* p, int n) {
 int segvlad_cluster_aggregate(segvlad_ctx* ctx, int num_c, const float* res, const uint8_t* labels, int N, int D,
                               const uint64_t* inc_bits, int S, const uint8_t* adj, float* out) {
   CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("cluster_aggregate");
   if (num_c <= 0 || num_c > 256 || N <= 0 || D <= 0 || (D % 4) || S < 0)
     return ctx->fail(SEGVLAD_ERR_ARG, "cluster_aggregate: bad shape num_c=%d N=%d D=%d S=%d", num_c, N, D, S);
   if (S == 0) return SEGVLAD_OK;

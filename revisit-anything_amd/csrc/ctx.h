@@ -27,9 +27,17 @@
   } while (0)
 
 // squared L2 distance from the norms and the dot product; ONE definition so that every path (matrix GEMM,
-// filtered GEMM, exact refinement) rounds identically: fma(-2, dot, ||q||^2 + ||r||^2)
+// filtered GEMM, exact refinement) rounds identically: fma(-2, dot, ||q||^2 + ||r||^2), negative results set to zero --
+// faiss's IndexFlatL2 (1.7.3, utils/distances.cpp, exhaustive_L2sqr_blas: `if (dis < 0) dis = 0`, "negative values can occur
+// for identical vectors due to roundoff errors") does the same BEFORE its heap sees the value, so an exact duplicate is at
+// distance 0 and `2 - d2` (place_rec_main.py:78-81) never exceeds 2 (round 6).  The comparison form keeps a NaN a NaN, as
+// faiss's does.  max(0, .) is monotone and 1-Lipschitz: order statistics and the filters' margins |d2~ - d2| <= eps carry
+// over to the clamped values unchanged.
 #if defined(__HIPCC__)
-__device__ __forceinline__ float sv_d2(float q2, float r2, float dot) { return __fmaf_rn(-2.f, dot, q2 + r2); }
+__device__ __forceinline__ float sv_d2(float q2, float r2, float dot) {
+  const float v = __fmaf_rn(-2.f, dot, q2 + r2);
+  return v < 0.f ? 0.f : v;
+}
 #endif
 
 // Layout of the fp16 operand planes of the split projection GEMM (gemm_f16x3_kernel): [row / 128][k / 32][128 rows][32 k],

@@ -78,12 +78,19 @@ def describe_split(dino_in, masks_in, image_keys: Sequence[str], describe: Calla
 
 
 def run_segloc(dino_r, masks_r, keys_r, dino_q, masks_q, keys_q, gt, pipeline, batch_size: int = 100, n_top: int = 5,
-               k_search: int = 200, k_vote: int = 50):
+               k_search: int = 200, k_vote: int = 50, save_results: Optional[dict] = None):
     """Reference split -> index, query split -> ranked reference images -> recall@1..n_top, on the device pipeline
     (``pipeline``: a ``SegVLADPipeline`` whose engine has the vocabulary and, if used, the PCA model set).
     The chain is ``recall_segloc``'s (place_rec_main.py:44-96): normalised descriptors, exact search ``k_search``,
-    keep ``k_vote``, ``2 - d^2``, similarity-weighted image vote, ``calc_recall``."""
+    keep ``k_vote``, ``2 - d^2``, similarity-weighted image vote, ``calc_recall``.
+
+    ``save_results`` = ``{"workdir", "dataset_name", "experiment_name", "experiment_config", "domain"}`` writes what the
+    reference pickles under its ``--save_results`` switch, under the reference's file names: the reference descriptors
+    ``segFtVLAD1`` (place_rec_main.py:292-305), the query descriptors ``segFtVLAD2`` (``:357-370``) -- torch CPU tensors, the
+    rows as they are handed to ``recall_segloc`` -- and ``{'sims', 'matches'}``, the ``k_search``-deep search output
+    (``:61-75``)."""
     from .pipeline import recall_at
+    from . import store
 
     def describe(tokens, masks, offs):
         import torch
@@ -100,4 +107,9 @@ def run_segloc(dino_r, masks_r, keys_r, dino_q, masks_q, keys_q, gt, pipeline, b
     q_off = np.concatenate([[0], np.cumsum([len(r) for r in seg_range2])]).astype(np.int32)
     pred, _, matches, sims = pipeline.retrieve(d2, q_off, k_search=k_search, k_vote=k_vote, n_top=n_top)
     pred = pred.cpu().numpy() if hasattr(pred, "cpu") else np.asarray(pred)
+    if save_results is not None:
+        full_d2, full_idx = pipeline.last_search
+        store.save_experiment_pickles(save_results["workdir"], save_results["dataset_name"], save_results["experiment_name"],
+                                      save_results["experiment_config"], save_results["domain"], segFtVLAD1=d1, segFtVLAD2=d2,
+                                      sims=full_d2, matches=full_idx)
     return recall_at(pred, gt, n_top), pred, matches, sims

@@ -76,7 +76,10 @@ class SegVLADPipeline:
             try:
                 h = eng.describe_begin(masks, tokens, seg_offsets, self.H, self.W, self.patch, self.order, pca=self.use_pca)
             except SegVLADError as e:
-                if e.code != SEGVLAD_ERR_LIMIT:   # (more segments in an image than the in-LDS Delaunay holds: the paths below)
+                # SEGVLAD_ERR_LIMIT = "the split call cannot, the separate entry points can": more segments in an image than the
+                # in-LDS Delaunay holds, an empty batch, a PCA model without the fp16x3 form (pca_arith=fp32 / K*D % 32 != 0:
+                # images_pca then projects the stored descriptor with the plain GEMM) -> the paths below
+                if e.code != SEGVLAD_ERR_LIMIT:
                     raise
                 h = None
             if h is not None:
@@ -185,6 +188,7 @@ class SegVLADPipeline:
         -- an exact search's first columns do not depend on its depth -- for a quarter of the refinement."""
         self.eng.hint_query_groups(qseg_offsets)
         d2, idx = self.eng.search(qdesc, k_vote if vote_depth_only else k_search)
+        self.last_search = (d2, idx)   # the full-depth lists: what `save_results` pickles (place_rec_main.py:61-75)
         sims, m = self.eng.sims_from_d2(d2, idx, k_vote)
         pred, sc = self.eng.vote(m, sims, qseg_offsets, n_top=n_top, mode=mode, want_scores=want_scores)
         return pred, sc, m, sims

@@ -249,6 +249,39 @@ def save_results(path: str, sims, matches) -> None:
         pickle.dump({"sims": np.asarray(sims), "matches": np.asarray(matches)}, f)
 
 
+def experiment_pickle_paths(workdir: str, dataset_name: str, experiment_name: str, experiment_config: dict, domain) -> dict:
+    """The three result files of a ``--save_results`` run, under the reference's own names
+    (``place_rec_main.py:62-68`` ``{dataset}_matches_sims_domain_{domain}__{suffix}``, ``:292-300`` ``..._segFtVLAD1_...``,
+    ``:357-365`` ``..._segFtVLAD2_...``, all in ``{workdir}/results/global/{experiment_name}/``)."""
+    folder = f"{workdir}/results/global//{experiment_name}"      # (the reference's f"{out_folder}/{experiment_name}" with out_folder ending in "/")
+    suffix = experiment_config["results_pkl_suffix"]
+    return {kind: f"{folder}/{dataset_name}_{kind}_domain_{domain}__{suffix}" for kind in ("segFtVLAD1", "segFtVLAD2", "matches_sims")}
+
+
+def save_experiment_pickles(workdir: str, dataset_name: str, experiment_name: str, experiment_config: dict, domain,
+                            segFtVLAD1=None, segFtVLAD2=None, sims=None, matches=None) -> dict:
+    """What ``place_rec_main.py`` pickles under ``save_results`` -- the reference descriptors (``:292-305``) and the query
+    descriptors (``:357-370``) as the torch CPU tensors the reference dumps, and ``{'sims', 'matches'}`` = the 200-deep
+    ``index.search`` output as NumPy arrays (``:61-75``; 'sims' holds the squared distances, as in the reference).  Only the
+    given items are written; returns the paths."""
+    import torch
+
+    paths = experiment_pickle_paths(workdir, dataset_name, experiment_name, experiment_config, domain)
+    os.makedirs(os.path.dirname(paths["matches_sims"]), exist_ok=True)
+    for kind, t in (("segFtVLAD1", segFtVLAD1), ("segFtVLAD2", segFtVLAD2)):
+        if t is None:
+            continue
+        t = t.detach().cpu() if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(t))
+        with open(paths[kind], "wb") as f:
+            pickle.dump(t, f)
+        print(f"{kind} tensor saved to {paths[kind]}")
+    if sims is not None and matches is not None:
+        to_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)   # noqa: E731
+        save_results(paths["matches_sims"], to_np(sims), to_np(matches))
+        print(f"Results saved to {paths['matches_sims']}")
+    return paths
+
+
 def load_results(path: str) -> Tuple[np.ndarray, np.ndarray]:
     with open(path, "rb") as f:
         d = pickle.load(f)

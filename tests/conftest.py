@@ -19,6 +19,7 @@ os.environ.setdefault("SEGVLAD_GUARD", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_perf: timing / rate assertions on a real MI355X (box dependent; never part of -m gpu)")
 
 
 @pytest.fixture(scope="session")
@@ -36,16 +37,19 @@ def _gpu_available():
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly rather than silently skip: only auto-skip
-    # when the user did NOT ask for gpu tests explicitly.
-    if "gpu" in (config.getoption("-m") or ""):
-        return
+    # `-m gpu` (or `-m gpu_perf`) on a box without a GPU must fail loudly rather than silently skip: only auto-skip the
+    # markers the user did NOT ask for explicitly (`-m "not gpu"` asks for neither).
     if _gpu_available():
         return
+    import re
+
+    expr = config.getoption("-m") or ""
+    asked = {m for m in ("gpu", "gpu_perf") if re.search(r"(?<!not )\b%s\b" % m, expr)}
     skip = pytest.mark.skip(reason="no GPU in this container")
     for it in items:
-        if "gpu" in it.keywords:
-            it.add_marker(skip)
+        for m in ("gpu", "gpu_perf"):
+            if m in it.keywords and m not in asked:
+                it.add_marker(skip)
 
 
 def engine_scope(fixture_name, config):

@@ -21,7 +21,9 @@
 
 #include <atomic>
 
+#ifndef __HIP_PLATFORM_AMD__
 #define __HIP_PLATFORM_AMD__ 1
+#endif
 #include <hip/hip_runtime_api.h>
 
 namespace {

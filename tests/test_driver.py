@@ -65,3 +65,53 @@ def test_mixed_geometry_in_a_batch_is_an_error(tmp_path):
         driver.describe_split(st.FeatureStore(dino.root, "dino"), msk, keys, pooled)
     tokens, m = driver.load_image_inputs(st.FeatureStore(dino.root, "dino"), msk, keys[0])
     assert tokens.shape == (6, 6) and m.shape == (2, 8, 10) and m.dtype == np.uint8
+
+
+def test_run_segloc_save_results_writes_the_reference_pickles(tmp_path):
+    """place_rec_main.py:62-75, 292-305, 357-370: the three `--save_results` files, under the reference's names, with the
+    reference's contents (torch CPU tensors; {'sims': d2 [n_q, k_search], 'matches': ids}).  A NumPy stand-in pipeline."""
+    import pickle
+
+    import torch
+
+    from revisit_anything_amd.place_rec import default_experiment
+
+    dino_r, msk_r, keys_r, _, _ = make_split(tmp_path, [2, 3, 1], seed=3)
+    dino_q, msk_q, keys_q, _, _ = make_split(tmp_path, [2, 1], seed=4)
+
+    class FakeEng:
+        device = "cpu"
+
+    class FakePipe:
+        eng = FakeEng()
+
+        def describe(self, tokens, masks, offs, l2norm=True):
+            return torch.from_numpy(pooled(tokens.numpy(), masks.numpy(), offs).astype(np.float32))
+
+        def index_reset(self):
+            self.rows = None
+
+        def index_add(self, rows, img):
+            self.rows, self.img = np.asarray(rows), np.asarray(img)
+
+        def retrieve(self, q, q_off, k_search, k_vote, n_top):
+            q = np.asarray(q)
+            d2 = ((q[:, None, :] - self.rows[None]) ** 2).sum(-1).astype(np.float32)
+            idx = np.argsort(d2, axis=1, kind="stable")[:, :k_search]
+            d2 = np.take_along_axis(d2, idx, 1)
+            self.last_search = (torch.from_numpy(d2), torch.from_numpy(idx))
+            pred = np.stack([self.img[idx[q_off[i], :n_top]] for i in range(len(q_off) - 1)])
+            return pred, None, idx[:, :k_vote], 2 - d2[:, :k_vote]
+
+    save = {"workdir": str(tmp_path / "w"), "dataset_name": "VPAir", "experiment_name": "e", "domain": "aerial",
+            "experiment_config": default_experiment(order=3, pca=True)}
+    rec, pred, matches, sims = driver.run_segloc(dino_r, msk_r, keys_r, dino_q, msk_q, keys_q, [[0], [1]], FakePipe(), n_top=2,
+                                                 k_search=4, k_vote=3, save_results=save)
+    paths = st.experiment_pickle_paths(save["workdir"], "VPAir", "e", save["experiment_config"], "aerial")
+    assert paths["segFtVLAD1"].endswith("/results/global//e/VPAir_segFtVLAD1_domain_aerial___results_SegLoc_VLAD_PCA_o3.pkl")
+    ft1, ft2 = (pickle.load(open(paths[k], "rb")) for k in ("segFtVLAD1", "segFtVLAD2"))
+    assert isinstance(ft1, torch.Tensor) and tuple(ft1.shape) == (6, 4) and tuple(ft2.shape) == (3, 4)
+    d2, ids = st.load_results(paths["matches_sims"])
+    assert d2.shape == (3, 4) and ids.shape == (3, 4) and np.array_equal(ids[:, :3], matches) and np.allclose(2 - d2[:, :3], sims)
+    # without the switch nothing is written
+    driver.run_segloc(dino_r, msk_r, keys_r, dino_q, msk_q, keys_q, [[0], [1]], FakePipe(), n_top=2, k_search=4, k_vote=3)

@@ -120,3 +120,55 @@ def test_split_describe_with_patched_adjacency_equals_images_pca_on_the_patched_
     eng.describe_cancel(h2)
     assert torch.equal(eng.describe(masks, tok, off, H, W, 14, 3)["out"], eng.seg_vlad_pca(tok, bits, off, adj, l2norm=True)["out"])
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["pca_arith_fp32", "kd_not_a_multiple_of_32"])
+def test_pipeline_describe_falls_back_when_the_split_call_cannot_take_the_projection(case):
+    """segvlad_describe_begin needs the fp16x3 form of the PCA model; with option pca_arith=fp32, or with
+    K*D not a multiple of 32 (no split planes at all), it reports SEGVLAD_ERR_LIMIT and pipeline.describe takes the separate
+    entry points, whose images_pca has the plain-projection form -- as it did before the three-call path existed."""
+    from revisit_anything_amd._lib import SEGVLAD_ERR_LIMIT, SegVLADError
+    from revisit_anything_amd.pipeline import SegVLADPipeline
+
+    if case == "pca_arith_fp32":
+        eng, C = _setup(seed=4)
+        eng.set_option("pca_arith", "fp32")
+    else:
+        eng, C = _setup(K=5, D=36, P=16, seed=5)        # K*D = 180: not a multiple of 32
+    H, W = 112, 140
+    tok, masks, off = _batch(C, 3, [6, 9, 5], H, W, seed=91)
+    with pytest.raises(SegVLADError) as ei:
+        eng.describe_begin(masks, tok, off, H, W, 14, 2, pca=True)
+    assert ei.value.code == SEGVLAD_ERR_LIMIT
+    fused = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True)
+    step = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=True, host_adjacency=True)
+    a = fused.describe(tok, masks, off)
+    b = step.describe(tok, masks, off)
+    assert torch.equal(a, b) and torch.isfinite(a).all() and a.shape == (20, eng.P)
+    eng.close()
+
+
+def test_other_entry_points_refuse_while_a_describe_is_open():
+    """between begin and end the per-batch scratch belongs to the open batch; segvlad_images / _images_pca /
+    _cluster_aggregate / _incidence / _adjacency return SEGVLAD_ERR_STATE instead of describing another batch with its offsets,
+    and the open describe still ends with the right rows."""
+    from revisit_anything_amd._lib import SEGVLAD_ERR_STATE, SegVLADError
+
+    eng, C = _setup(seed=6)
+    H, W = 112, 140
+    tok, masks, off = _batch(C, 3, [7, 5, 9], H, W, seed=13)
+    tok2, masks2, off2 = _batch(C, 2, [4, 6], H, W, seed=14)
+    bits, cent = eng.incidence_centroids(masks, H, W, 14)
+    adj, _ = eng.adjacency_flagged(cent, off, 3, device_flags=True)
+    ref = eng.seg_vlad_pca(tok, bits, off, adj, l2norm=True)["out"]
+    bits2, cent2 = eng.incidence_centroids(masks2, H, W, 14)
+    adj2, _ = eng.adjacency_flagged(cent2, off2, 3, device_flags=True)
+    h = eng.describe_begin(masks, tok, off, H, W, 14, 3, pca=True)
+    for call in (lambda: eng.seg_vlad(tok2, bits2, off2, adj2), lambda: eng.seg_vlad_pca(tok2, bits2, off2, adj2),
+                 lambda: eng.incidence_centroids(masks2, H, W, 14), lambda: eng.adjacency_flagged(cent2, off2, 3, device_flags=True)):
+        with pytest.raises(SegVLADError) as ei:
+            call()
+        assert ei.value.code == SEGVLAD_ERR_STATE
+    assert torch.equal(eng.describe_end(h, None, None, l2norm=True)["out"], ref)
+    assert torch.equal(eng.seg_vlad_pca(tok, bits, off, adj, l2norm=True)["out"], ref)     # and the context is free again
+    eng.close()

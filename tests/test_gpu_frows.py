@@ -290,7 +290,27 @@ def test_driver_run_segloc_over_a_feature_store_equals_oracle(eng, tmp_path):
     gt = [[int(t)] for t in tau]
     eng.set_vocab(C)
     pipe = SegVLADPipeline(eng, H, W, 14, order=2, use_pca=False)
-    rec, pred, matches, sims = driver.run_segloc(dr, mr, kr, dq, mq, kq, gt, pipe, batch_size=5, n_top=3, k_search=20, k_vote=10)
+    from revisit_anything_amd.place_rec import default_experiment
+    save = {"workdir": str(tmp_path / "work"), "dataset_name": "17places", "experiment_name": "exp1_test",
+            "experiment_config": default_experiment(order=2, pca=False), "domain": "indoor"}
+    rec, pred, matches, sims = driver.run_segloc(dr, mr, kr, dq, mq, kq, gt, pipe, batch_size=5, n_top=3, k_search=20, k_vote=10,
+                                                 save_results=save)
+    # the three pickles of the reference's --save_results run, under ITS file names (place_rec_main.py:62-75, 292-305, 357-370)
+    import pickle
+    folder = tmp_path / "work" / "results" / "global" / "exp1_test"
+    names = sorted(f.name for f in folder.iterdir())
+    assert names == [f"17places_{kind}_domain_indoor___results_SegLoc_VLAD_o2.pkl" for kind in ("matches_sims", "segFtVLAD1", "segFtVLAD2")]
+    with open(folder / names[0], "rb") as f:
+        ms = pickle.load(f)
+    with open(folder / names[1], "rb") as f:
+        ft1 = pickle.load(f)
+    with open(folder / names[2], "rb") as f:
+        ft2 = pickle.load(f)
+    import torch
+    assert isinstance(ft1, torch.Tensor) and isinstance(ft2, torch.Tensor) and ft1.device.type == "cpu"
+    assert set(ms) == {"sims", "matches"} and ms["sims"].shape == (ft2.shape[0], 20) and ms["matches"].dtype == np.int64
+    assert np.array_equal(ms["matches"][:, :10], matches.cpu().numpy())                    # the vote read their first 10 columns
+    assert np.array_equal((2 - ms["sims"][:, :10]).astype(np.float32), sims.cpu().numpy())  # 'sims' holds d^2, as in the reference
 
     # oracle: the same chain in fp64 (seg-VLAD per image with order-2 neighbourhoods -> exact kNN -> vote -> recall)
     def odesc(toks, masks):
@@ -303,6 +323,7 @@ def test_driver_run_segloc_over_a_feature_store_equals_oracle(eng, tmp_path):
 
     R, imr = odesc(tr, msr)
     Q, imq = odesc(tq, msq)
+    assert np.abs(ft1.numpy() - R).max() < 2e-6 and np.abs(ft2.numpy() - Q).max() < 2e-6   # the pickled rows ARE the descriptors
     d2, idx = O().knn_l2(R.astype(np.float32), Q.astype(np.float32), 20)
     osims = (2 - d2[:, :10]).astype(np.float32)
     seg_range = [np.where(imq == i)[0] for i in range(n_q)]

@@ -442,6 +442,38 @@ def test_knn_leveled_filter_path_is_exact(eng, d):
     assert np.array_equal(im, idx) and np.array_equal(dm, d2)
 
 
+@pytest.mark.parametrize("n,nq", [(3000, 64), (70001, 300), (70001, 40)])   # matrix path; leveled batch; single-image pass
+def test_knn_exact_duplicates_are_at_distance_zero_like_faiss(eng, n, nq):
+    """faiss's IndexFlatL2 sets a negative ||q||^2 + ||r||^2 - 2 q.r to zero before its heap sees it (utils/distances.cpp,
+    exhaustive_L2sqr_blas), so a query that IS a reference row has d2 = 0 and `2 - d2` (place_rec_main.py:78-81) never exceeds 2
+    (VERDICT r05 missing #5: the unclamped form returned -1e-7).  Unit rows of d = 1024, every query a copy of a reference row,
+    some rows present two or three times: d2 >= 0 everywhere, the copies first and in id order, sims <= 2, bits equal to the
+    oracle's clamp."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(606))
+    d, k = 1024, 20
+    R = rng.standard_normal((n, d)).astype(np.float32)
+    R /= np.linalg.norm(R, axis=1, keepdims=True)
+    src = rng.choice(n - 10, nq, replace=False)
+    R[n - 1] = R[src[0]]
+    R[n - 2] = R[src[0]]
+    R[n - 3] = R[src[1]]
+    Q = R[src].copy()
+    eng.db_reset()
+    eng.db_add(R)
+    d2, idx = eng.search(Q, k)
+    sims, _ = eng.sims_from_d2(d2, idx, 10)
+    d2, idx, sims = d2.cpu().numpy(), idx.cpu().numpy(), sims.cpu().numpy()
+    assert (d2 >= 0).all() and (sims <= 2.0).all()
+    assert np.array_equal(d2[:, 0], np.zeros(nq, np.float32)) and np.array_equal(sims[:, 0], np.full(nq, 2.0, np.float32))
+    assert idx[0, :3].tolist() == sorted([int(src[0]), n - 2, n - 1]) and (d2[0, :3] == 0).all()
+    assert idx[1, :2].tolist() == sorted([int(src[1]), n - 3]) and (d2[1, :2] == 0).all()
+    assert np.array_equal(idx[2:, 0], src[2:])
+    rd2, ridx = O().knn_l2(R, Q, k)
+    assert (rd2 >= 0).all() and np.abs(d2 - rd2).max() < 1e-5
+    eng.db_reset()
+
+
 def test_knn_raw_descriptor_width_refines_without_lds_query_cache(eng):
     """Raw K*D-wide rows (BASELINE configs[1] searches 98 304-d descriptors without PCA): the query row no longer fits
     the refinement kernel's LDS cache.  Filtered search over the whole database == matrix-path search over three

@@ -19,11 +19,17 @@ STUB = os.path.join(STUB_DIR, "librccl_stub.so")
 
 
 def _build_stub():
-    src = os.path.join(STUB_DIR, "rccl_stub.cpp")
-    if os.path.exists(STUB) and os.path.getmtime(STUB) >= os.path.getmtime(src):
-        return
-    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-w", "-I/opt/rocm/include", src, "-o", STUB,
-                    "-L/opt/rocm/lib", "-lamdhip64", "-lrt"], check=True)
+    """Built lazily HERE (and, best effort, by __graft_entry__.build()): the product build never depends on it; a box that cannot
+    build it skips these tests."""
+    sys.path.insert(0, STUB_DIR)
+    try:
+        import build_stub
+
+        build_stub.build()
+    except Exception as e:   # noqa: BLE001
+        pytest.skip(f"the RCCL test stub cannot be built here: {e}")
+    finally:
+        sys.path.remove(STUB_DIR)
 
 
 def _problem():
