@@ -317,6 +317,9 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "pj_nw")) return as_int(&o.pj_nw);
   if (!strcmp(key, "pj_f16")) return as_int(&o.pj_f16);
   if (!strcmp(key, "small_plan")) return as_int(&o.small_plan);
+  if (!strcmp(key, "small_tail")) return as_int(&o.small_tail);
+  if (!strcmp(key, "small_head")) return as_int(&o.small_head);
+  if (!strcmp(key, "debug_small_tail")) return as_int(&o.debug_small_tail);
   if (!strcmp(key, "refine_group")) return as_int(&o.refine_group);
   if (!strcmp(key, "query_group")) return as_int(&o.query_group);
   if (!strcmp(key, "debug_search")) return as_int(&o.debug_search);
@@ -343,6 +346,15 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
 int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n) {
   if (!ctx) return SEGVLAD_ERR_ARG;
   if (!stats_out || n < 0) return ctx->fail(SEGVLAD_ERR_ARG, "search_stats: bad arguments");
+  if (ctx->tail_stats_dev) {   // the last search was a device-driven pass: its tail's counters are still on the device
+    uint32_t h[4] = {0, 0, 0, 0};
+    (void)hipSetDevice(ctx->device);
+    SV_HIP(hipStreamSynchronize(ctx->stream));
+    SV_HIP(hipMemcpy(h, ctx->tail_stats_dev, sizeof(h), hipMemcpyDeviceToHost));
+    ctx->sstats.n_redo = h[0];      // rows redone exactly (brute force on the device)
+    ctx->sstats.n_refine2 = h[1];   // rows refined from their candidate lists (second tier)
+    ctx->tail_stats_dev = nullptr;
+  }
   const SvSearchStats& t = ctx->sstats;
   const int64_t v[12] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo, t.n_refine2,
                          t.grp_groups, t.grp_union_sum};
@@ -1133,6 +1145,9 @@ int segvlad_db_reset(segvlad_ctx* ctx) {
   ctx->db_rn_max = 0.f;
   ctx->db_rn_max_rows = 0;
   ctx->db_heur_off = false;
+  if (ctx->tail_rows_since > 0) (void)hipStreamSynchronize(ctx->stream);   // (the tail's pinned totals have landed)
+  ctx->tail_fail_base = ctx->h_pin ? reinterpret_cast<volatile uint32_t*>(ctx->h_pin)[8] : 0u;
+  ctx->tail_rows_since = 0;
   return SEGVLAD_OK;
 }
 
@@ -1177,6 +1192,9 @@ int segvlad_db_add(segvlad_ctx* ctx, const float* R, int n, int d, const int32_t
   ctx->db_n = n_new;
   ctx->db_d = d;
   ctx->db_heur_off = false;
+  if (ctx->tail_rows_since > 0) (void)hipStreamSynchronize(ctx->stream);   // (the tail's pinned totals have landed)
+  ctx->tail_fail_base = ctx->h_pin ? reinterpret_cast<volatile uint32_t*>(ctx->h_pin)[8] : 0u;
+  ctx->tail_rows_since = 0;
   return sv_finish(ctx);
 }
 
@@ -1286,7 +1304,11 @@ static int heur_rank_small(int target, int ratio, double pfail) {
 // chunk); rovf_rows_in [m]: second-tier flags, zero on entry; n_rovf_seen: the caller's copy of fail_count[1] so far.
 static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, const float* qp, const uint16_t* q16a,
                         const uint16_t* q16b, const float* qn, int m, float* out_d2, int64_t* out_idx, uint32_t* fail_rows,
-                        uint32_t* fail_count, uint32_t* rovf_rows_in, uint32_t* n_fail_host, uint32_t* n_rovf_seen, int phase = 0) {
+                        uint32_t* fail_count, uint32_t* rovf_rows_in, uint32_t* n_fail_host, uint32_t* n_rovf_seen, int phase = 0,
+                        uint32_t* tail_stats = nullptr) {
+  // tail_stats != null (one query image per pass, round 6): NO read-back -- small_tail_kernel is launched behind the refinement,
+  // reads the two counters on the device and finishes flagged rows there (small_pass_kernels.hip); the host learns nothing
+  // about them in this call (*n_fail_host = 0), segvlad_search_stats fetches the kernel's counters on demand
   // phase 0: the whole pass.  1: the exact sample level only; 2: everything behind it -- a batch search enqueues phase 1 (which
   // needs neither the query plane nor the filter's margin) BEFORE it waits for the two scalars that fix them, so that the device
   // has that level to run while the host waits (m > 128 only: the single-image plan's fused level 0 is one chain with its pass)
@@ -1426,7 +1448,13 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
           sc.count();
         }
       }   // (the stage's stop event is recorded before the host waits below)
-      if (last) {
+      if (last && tail_stats) {
+        StageScope sc(ctx, "knn_select");
+        SV_TRY(sv_launch_small_tail(ctx, qp, R, qn, rn, n, d, m, k, fail_rows, fail_count, rovf_rows, ref_lim, ctx->s_cand_cnt.as<uint32_t>(),
+                                    ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP, out_d2, out_idx, tail_stats));
+        sc.count();
+        if (n_fail_host) *n_fail_host = 0;
+      } else if (last) {
         // one read-back per chunk: rows flagged for the redo / matrix-path fallback (handled by the caller) and rows whose
         // refine band outgrew the first-tier list.  The latter are refined here, straight from their candidate lists,
         // which the next chunk would overwrite.
@@ -1455,14 +1483,14 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
           }
           ctx->sstats.n_refine2 += h_cnt[1];
         }
-        if (ctx->opt.search_stats) {
-          hcnt.resize(m);
-          SV_HIP(hipStreamSynchronize(ctx->stream));
-          SV_HIP(hipMemcpy(hcnt.data(), ctx->s_ref_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-          for (uint32_t c : hcnt) {
-            ctx->sstats.refine_sum += c;
-            if ((int64_t)c > ctx->sstats.refine_max) ctx->sstats.refine_max = c;
-          }
+      }
+      if (last && ctx->opt.search_stats) {
+        hcnt.resize(m);
+        SV_HIP(hipStreamSynchronize(ctx->stream));
+        SV_HIP(hipMemcpy(hcnt.data(), ctx->s_ref_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (uint32_t c : hcnt) {
+          ctx->sstats.refine_sum += c;
+          if ((int64_t)c > ctx->sstats.refine_max) ctx->sstats.refine_max = c;
         }
       }
       // thresholds now hold approximate rank-th distances A_r: the exact one is <= A_r + eps, and any row at least that
@@ -1558,6 +1586,15 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   };
   ctx->sstats = SvSearchStats();
   ctx->sstats.n_queries = nq;
+  ctx->tail_stats_dev = nullptr;
+  // device-driven single-image passes never tell the host how many rows they had to redo -- but their running total lands in a
+  // pinned word (small_tail_kernel): looked at here WITHOUT synchronising (it may be a pass or two behind).  More than a quarter
+  // of >= 64 rows redone since the index last changed: the sample misleads on this database, stop guessing (as the read-back path
+  // decides below for its own redos).
+  if (ctx->h_pin && ctx->tail_rows_since >= 64) {
+    const uint32_t redone = reinterpret_cast<volatile uint32_t*>(ctx->h_pin)[8] - ctx->tail_fail_base;
+    if ((int64_t)redone * 4 > ctx->tail_rows_since) ctx->db_heur_off = true;
+  }
 
   // level plan: strides 16^L, ..., 16, 1.  The coarsest sample goes through the exact fp32 matrix path (an order of
   // magnitude dearer per row than the fp16 filter), so take as many levels as keep it selective: a sample of s rows
@@ -1610,7 +1647,9 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // level, which then collects 2900 candidates per query instead of 780, and as 0.2 ms of longer selects.)
   int small_stride = 16;
   while ((n + small_stride - 1) / small_stride > 4096 && small_stride <= 512) small_stride *= 2;
+  bool small_taken = false;
   if (heuristic && nq <= 128 && ctx->opt.small_plan && small_stride <= 512) {
+    small_taken = true;
     plh.levels = 1;
     plh.stride0 = small_stride;
     plh.ratio_last = small_stride;
@@ -1650,7 +1689,8 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   // index used to allocate > 1 GiB of candidate lists (the buffers only ever grow, so a later large batch re-allocates once)
   const size_t mrows = (size_t)std::min(nq, SV_CHUNK);
   // flag block: [nq] row flags, 2 counts (flagged, second-tier), [mrows] second-tier flags of the current chunk -- one fill
-  const size_t ovf_bytes = (((size_t)nq + 2 + mrows) * 4 + 255) & ~(size_t)255;   // (a whole number of 256-byte blocks: one fill kernel)
+  // (+ 4 words behind them: the device-driven tail's counters of this search)
+  const size_t ovf_bytes = (((size_t)nq + 2 + mrows + 4) * 4 + 255) & ~(size_t)255;   // (a whole number of 256-byte blocks: one fill kernel)
   bool ovf_zeroed = false;
   // the per-chunk scratch and the flag block, reserved (and the flags zeroed) once -- by the early exact level of a batch
   // search (below) or in front of the chunk loop
@@ -1714,9 +1754,27 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
       SV_HIP(ctx->s_qscale.reserve(16));
       const bool fuse_qn = !qn_done && (reinterpret_cast<uintptr_t>(dq) & 15) == 0;   // (d % 64 == 0 on this path)
       SV_HIP(ctx->s_ovf.reserve(ovf_bytes));
+      // round 6: the whole head of a single-image pass in ONE launch (small_pass_kernels.hip) -- plane, scale, norms, flags AND the
+      // sample thresholds (from the filter's own fp16 product on the strided sample: the thresholds are guesses the pass verifies,
+      // they need no exact distances) -- instead of query preparation -> exact sample GEMM -> reduce + rank (three dependent launches)
+      const int64_t n0_small = (n + small_stride - 1) / small_stride;
+      const int r0_small = std::min(k, small_stride == SV_RATIO ? heur_rank(k) : heur_rank_small(k, small_stride, plh.pfail));   // (levels_chunk's rank[0])
+      if (small_taken && fuse_qn && ctx->opt.small_head && ctx->opt.debug_search == 0 && n0_small <= 4096 &&
+          sv_small_head_ok(nq, d, (int)n0_small, r0_small)) {
+        ovf_zeroed = true;
+        SV_TRY(reserve_scratch());
+        StageScope sc(ctx, "knn_level0");
+        SV_TRY(sv_launch_small_head(ctx, (const float*)dq, nq, d, ctx->db_f16.as<uint16_t>(), rn, small_stride, (int)n0_small,
+                                    ctx->db_f16_scale, r0_small, ctx->s_qf16.as<uint16_t>(), ctx->s_qscale.as<float>(),
+                                    ctx->s_qnorm.as<float>(), ctx->s_ovf.as<uint32_t>(), (int)(ovf_bytes / 4), ctx->s_dist.as<float>(),
+                                    ctx->s_thr_d2.as<float>(), ctx->s_cand_cnt.as<uint32_t>()));
+        sc.count();
+        level0_done = true;
+      } else {
       SV_TRY(sv_launch_query_f16_small(ctx, (const float*)dq, (int64_t)nq * d, ctx->db_f16_scale, ctx->s_qf16.as<uint16_t>(),
                                        ctx->s_qscale.as<float>(), fuse_qn ? ctx->s_qnorm.as<float>() : nullptr, nq, d,
                                        ctx->s_ovf.as<uint32_t>(), (int)(ovf_bytes / 4)));
+      }
       ovf_zeroed = true;   // (the flag block of this search: no fill launch of its own in front of the pass)
       if (fuse_qn) qn_done = true;
       ctx->f16_scale_dev = ctx->s_qscale.as<float>();
@@ -1795,6 +1853,12 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     return (pl.kind == 1 ? reinterpret_cast<const uint16_t*>(f16.p) : reinterpret_cast<const uint16_t*>(hi.p)) + (size_t)q0 * d;
   };
   uint32_t n_flag = 0;   // running count of the flagged rows, read back by every chunk (levels_chunk synchronises once)
+  // one query image per pass on the single-image plan with the scale on the device: the pass ends in small_tail_kernel instead of
+  // a read-back (option small_tail = 0: the round-5 path, for A/B and for the tests that compare the two)
+  uint32_t* tail_stats = nullptr;
+  if (small_taken && pl.kind == 1 && ctx->f16_scale_dev && ctx->opt.small_tail &&
+      ctx->opt.debug_search == 0 && n <= 0xffffffffLL)
+    tail_stats = rovf_flags + mrows;
   for (int q0 = 0; q0 < nq; q0 += SV_CHUNK) {
     const int m = (nq - q0 < SV_CHUNK) ? (nq - q0) : SV_CHUNK;
     if (q0) SV_HIP(hipMemsetAsync(rovf_flags, 0, (size_t)m * 4, ctx->stream));
@@ -1802,7 +1866,11 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
                         pl.kind == 3 ? nullptr : plane_a(ctx->s_qf16, ctx->s_qh, q0),
                         pl.kind == 2 ? ctx->s_ql.as<uint16_t>() + (size_t)q0 * d : nullptr, qn + q0, m, (float*)dd2 + (size_t)q0 * k,
                         (int64_t*)didx + (size_t)q0 * k, flag_rows + q0, flag_count, rovf_flags, &n_flag, &n_rovf_seen,
-                        (q0 == 0 && level0_done) ? 2 : 0));
+                        (q0 == 0 && level0_done) ? 2 : 0, tail_stats));
+  }
+  if (tail_stats) {
+    ctx->tail_stats_dev = tail_stats;
+    ctx->tail_rows_since += nq;
   }
   if (n_flag && !heuristic) {
     int nf = 0;
@@ -1823,7 +1891,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     SV_HIP(ctx->s_rd_d2.reserve((size_t)nr * k * 4));
     SV_HIP(ctx->s_rd_idx.reserve((size_t)nr * k * 8));
     const size_t rd_m = (size_t)std::min(nr, SV_CHUNK);
-    SV_HIP(ctx->s_rd_flags.reserve(((size_t)nr + 2 + rd_m) * 4));   // (same layout as s_ovf)
+    SV_HIP(ctx->s_rd_flags.reserve(((size_t)nr + 2 + rd_m) * 4));   // (same layout as s_ovf, without the tail's counters)
     SV_HIP(hipMemsetAsync(ctx->s_rd_flags.p, 0, ((size_t)nr + 2 + rd_m) * 4, ctx->stream));
     SV_HIP(hipMemcpyAsync(ctx->s_rd_rows.p, rows.data(), (size_t)nr * 4, hipMemcpyHostToDevice, ctx->stream));
     float* rq = ctx->s_rd_q.as<float>();

@@ -161,6 +161,11 @@ struct SvOptions {
                                // 2 = segvlad_search_sharded fails BEHIND its local search, where it can only abort the communicator
   int debug_search = 0;   // 1: print per-level candidate statistics to stderr (synchronises); 7: token_norms_kernel waits for every
                           //    outstanding memory operation at every step (verification of its counted waits: same bits)
+  int debug_small_tail = 0;   // tests only: bit 0 = every row of a device-driven pass is flagged for the tail's brute force, bit 1 = every
+                              // row's band is sent to its second tier, bit 2 = the hand-over's sticky failure word is raised
+  int small_head = 1;     // single-image passes start with small_head_kernel (plane + scale + norms + flags + sample thresholds in one
+                          // launch); 0 = query preparation -> exact sample level -> reduce + rank (rounds 3-5)
+  int small_tail = 1;     // single-image passes end in small_tail_kernel (no read-back); 0 = the read-back of rounds 3-5
   int small_plan = 1;     // <= 128 queries (one query image per pass): one filter level behind an exact sample of 2048..4096
                           // rows (see segvlad_search); 0 = the deep plan of the batches
   int pj_f16 = 1;         // P-space aggregation: the tile sums on the 16-bit matrix pipe (0: fp32 MFMA, as before round 4)
@@ -257,15 +262,23 @@ struct segvlad_ctx {
   bool f16_bias_ok = false;   // this search's batch filter launches may use the biased-accumulator kernel (segvlad_search)
   const float* f16_scale_dev = nullptr;   // set by segvlad_search for the duration of a single-image search (see above)
   bool db_heur_off = false;   // set when > 25 % of a search's queries needed the rigorous redo (until the index changes)
+  // device-driven single-image passes (small_pass_kernels.hip): the tail kernel's counters of the LAST such search live in device
+  // memory and are fetched by segvlad_search_stats (the search itself never reads them back); its running totals reach the host
+  // through two pinned words that segvlad_search looks at WITHOUT synchronising -- a database on which the low-rank thresholds
+  // keep failing is switched to the rigorous plan one or two calls late instead of never
+  const uint32_t* tail_stats_dev = nullptr;   // [4]: rows redone by brute force, second-tier rows, hand-over failures; null = none pending
+  uint32_t tail_fail_base = 0;                // h_pin[8] when the index last changed
+  int64_t tail_rows_since = 0;                // query rows sent through device-driven passes since then
 
   // Device buffers, as X-macro lists (segvlad_create tags them, segvlad_destroy releases them, guard mode walks them).
   //  persistent: contents outlive a call -- vocab: [K][D] raw centres; vocab_bt: normalised centres in MFMA-B order
   //  [D/2][Kpad/32][64]; pca_scale = 1/sqrt(var) or 1; pca_w1 / pca_w2: fp16 two-term split of comps * pca_w_scale (16-bit MFMA
   //  path); pca_cproj: [P] W mean ("project then aggregate"; rebuilt when stale); db_hi / db_lo / db_f16: 16-bit images of the rows;
-  //  s_ref_keys / s_ref_tick: hand-over words of refine_exact_small_kernel (all ones / all zero between launches)
+  //  s_ref_keys / s_ref_tick: hand-over words of refine_exact_small_kernel (all ones / all zero between launches);
+  //  s_tail_tick: tickets (all zero between launches) + running totals of small_tail_kernel
 #define SV_PERSISTENT_BUFS(X)                                                                                                    \
   X(vocab) X(vocab_bt) X(pca_mean) X(pca_comps) X(pca_scale) X(pca_w1) X(pca_w2) X(pca_cproj) X(db_rows) X(db_norms) X(db_img)    \
-  X(db_hi) X(db_lo) X(db_f16) X(s_ref_keys) X(s_ref_tick)
+  X(db_hi) X(db_lo) X(db_f16) X(s_ref_keys) X(s_ref_tick) X(s_tail_tick)
   //  scratch: grow-only, reused across calls, nothing in them is read after the call that wrote it; s_sh_*: exchange buffers of
   //  the row-sharded index (comm.hip)
 #define SV_SCRATCH_BUFS(X)                                                                                                       \
@@ -274,7 +287,7 @@ struct segvlad_ctx {
   X(s_ref_cnt) X(s_ref_id) X(s_qscale) X(s_qf16) X(s_xh1) X(s_xh2) X(s_desc) X(s_tokorder) X(s_laboff) X(s_rnsorted) X(s_ovf)     \
   X(s_fb_q) X(s_fb_d2) X(s_fb_idx) X(s_fb_rows) X(s_rd_rows) X(s_rd_q) X(s_rd_d2) X(s_rd_idx) X(s_rd_flags) X(s_rd_p1) X(s_rd_p2)  \
   X(s_sel_todo) X(s_vote_keys) X(s_pz) X(s_rowbase) X(s_tilegrp) X(s_bn) X(s_l0part) X(s_ref_lim) X(s_sh_d2) X(s_sh_idx)          \
-  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work) X(s_grp_pos) X(s_tnk_redo)
+  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work) X(s_grp_pos) X(s_tnk_redo) X(s_tail_part)
 #define SV_DECL_BUF(n) DevBuf n;
   SV_PERSISTENT_BUFS(SV_DECL_BUF)
   SV_SCRATCH_BUFS(SV_DECL_BUF)
@@ -418,6 +431,21 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
                            const uint32_t* only_rows = nullptr, uint32_t* fail_rows = nullptr, uint32_t* fail_count = nullptr,
                            const uint32_t** poison_dev = nullptr);
 int sv_refine_small_repair(segvlad_ctx* ctx);
+// small_pass_kernels.hip: the device-driven tail of a single-image pass (<= 128 rows): launched behind the refinement, returns at
+// once when fail_count[0] == fail_count[1] == 0, else finishes the flagged rows on the device (second tier from the candidate
+// lists; exact brute force for rows flagged for a redo) -- the search needs no read-back.  stats: [4] device words of this search.
+int sv_launch_small_tail(segvlad_ctx* ctx, const float* Q, const float* R, const float* qn, const float* rn, int64_t n, int d, int m, int k,
+                         uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, const float* ref_lim, const uint32_t* cand_cnt,
+                         const float* cand_d2, const uint32_t* cand_id, int cap, float* d2_out, int64_t* idx_out, uint32_t* stats);
+int sv_ensure_pinned_words(segvlad_ctx* ctx);
+// the HEAD of such a pass in one launch: the queries' fp16 plane (scales_dev[0] = scale, [1] = 1 / (scale x db_scale)), their squared
+// norms (row_sumsq's bits), the zeroed flag block, and thr_out[q] = the rank-th smallest APPROXIMATE distance (the filter's own fp16
+// product) of query q to the n0 sample rows 0, stride, 2 stride, ... of the fp16 plane Rh; cand_cnt[q] = 0.
+// cand_scratch: m x n0 floats.  sv_small_head_ok: the shapes it takes.
+bool sv_small_head_ok(int m, int d, int n0, int rank);
+int sv_launch_small_head(segvlad_ctx* ctx, const float* X, int m, int d, const uint16_t* Rh, const float* rn, int64_t stride, int n0,
+                         float db_scale, int rank, uint16_t* qplane, float* scales_dev, float* qn_out, uint32_t* zero, int zero_words,
+                         float* cand_scratch, float* thr_out, uint32_t* cand_cnt);   // ctx->h_pin (16 zeroed words) + ctx->ev_scalars
 // refine_group_kernels.hip: the same refinement for a batch, with the bands of 32 consecutive query rows evaluated over the
 // union of their rows where they overlap (option refine_group); *launches = kernels launched
 constexpr int SV_RG_UCAP = 2048;   // longest union a group may hold (longer: its rows keep the per-row kernels)

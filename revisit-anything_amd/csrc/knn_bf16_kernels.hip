@@ -25,18 +25,10 @@
 #include <stdio.h>
 
 #include "ctx.h"
+#include "knn_dev.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ uint32_t f2key_(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f_(uint32_t k) {
-  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-  return __uint_as_float(u);
-}
 
 // ---- fp32 -> (hi, lo) bf16, round-to-nearest-even ---------------------------------------------------
 __device__ __forceinline__ uint16_t bf16_rne(float x) {
@@ -1901,25 +1893,6 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
 }
 
 // ---- candidate handling ----------------------------------------------------------------------------------
-__device__ __forceinline__ void bitonic64(uint64_t* a, int n, int tid) {
-  for (int size = 2; size <= n; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (int t = tid; t < (n >> 1); t += 256) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const uint64_t x = a[lo], y = a[hi];
-        if ((y < x) == up) {
-          a[lo] = y;
-          a[hi] = x;
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
 // wave-aggregated LDS histogram increment (keys cluster on few digits: a plain atomicAdd would serialise)
 __device__ __forceinline__ void hist_add_(uint32_t* hist, bool active, uint32_t bin) {
   uint64_t todo = __ballot(active);
@@ -2051,35 +2024,6 @@ __global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict
       ref_cnt[row] = s_n;
     }
   }
-}
-
-// sum over the 64 lanes, returned wave-uniform: quad swaps, half-row and row mirrors (DPP: no LDS crossbar), then the four
-// row sums through readlane
-__device__ __forceinline__ uint32_t wave_sum_u32_(uint32_t v) {
-  int x = (int)v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);   // row_half_mirror
-  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);   // row_mirror
-  return (uint32_t)(__builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
-                    __builtin_amdgcn_readlane(x, 48));
-}
-
-__device__ __forceinline__ uint32_t wave_min_u32_(uint32_t v) {
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
-  return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
-             min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
-}
-__device__ __forceinline__ uint32_t wave_max_u32_(uint32_t v) {
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));
-  return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
-             max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
 }
 
 // The same ranking for lists of up to 4096 candidates (every list of the low-rank level scheme, and nearly every list of
@@ -3069,15 +3013,21 @@ int sv_maxabs_and_norm_min(segvlad_ctx* ctx, const float* x, int64_t n, const fl
   return SEGVLAD_OK;
 }
 
+int sv_ensure_pinned_words(segvlad_ctx* ctx) {
+  if (!ctx->h_pin) {
+    SV_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), 64, hipHostMallocDefault));
+    for (int j = 0; j < 16; ++j) ctx->h_pin[j] = 0u;
+    SV_HIP(hipEventCreateWithFlags(&ctx->ev_scalars, hipEventDisableTiming));
+  }
+  return SEGVLAD_OK;
+}
+
 // The same two scalars WITHOUT the wait in between: _begin enqueues the reductions and the copy into pinned words of the
 // context and records an event behind them; _end blocks on that event only.  What the caller enqueues between the two runs on
 // the device while the host waits.
 int sv_maxabs_and_norm_min_begin(segvlad_ctx* ctx, const float* x, int64_t n, const float* norms, int64_t n_norms) {
   SV_HIP(ctx->s_minmax.reserve(32));
-  if (!ctx->h_pin) {
-    SV_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), 64, hipHostMallocDefault));
-    SV_HIP(hipEventCreateWithFlags(&ctx->ev_scalars, hipEventDisableTiming));
-  }
+  SV_TRY(sv_ensure_pinned_words(ctx));
   uint32_t* mm = ctx->s_minmax.as<uint32_t>() + 4;   // [4] = max |x| bits (init 0), [5] = min key (init all ones)
   static const uint32_t init[2] = {0u, 0xffffffffu};
   SV_HIP(hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, ctx->stream));

@@ -31,7 +31,14 @@
  *     "pj_nw"         8 | 4   waves per workgroup of the P-space aggregation
  *     "x3_tile", "x3_gm", "agg_kpb", "assign_narrow"   tile / order / geometry of the projection GEMM, the descriptor
  *                     aggregation and the assignment kernel
+ *   single-image passes (small_pass_kernels.hip)
+ *     "small_head"    1 | 0   the pass starts with small_head_kernel: plane, scale, norms, flags and the sample thresholds (from the
+ *                     filter's own fp16 product) in one launch | query preparation -> exact fp32 sample level -> reduce + rank
+ *     "small_tail"    1 | 0   the pass ends in small_tail_kernel, which reads the overflow counters on the DEVICE and finishes
+ *                     flagged rows there (no read-back, no host synchronisation in segvlad_search) | the read-back of rounds 3-5
  *   debugging and the tests' own hooks
+ *     "debug_small_tail"   bit 0: every row of a device-driven pass is flagged for the tail's exact brute force; bit 1: every
+ *                          row is sent through the tail's second tier; bit 2: the checked hand-over's sticky word is raised
  *     "debug_search"       1 = per-level candidate statistics on stderr (synchronises); 7 = the Gram kernel waits for every
  *                          outstanding memory operation at every step (verification of its counted waits)
  *     "debug_fail_search"  segvlad_search fails at once (the sharded entry's error path)

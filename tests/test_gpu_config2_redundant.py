@@ -364,7 +364,9 @@ def test_single_image_pass_overflow_paths_on_a_fresh_context(d):
     d2, idx = eng.search(Q, k)
     st = eng.search_stats()
     assert st["levels"] == 1 and st["filter"] == "f16", st
-    assert st["n_refine2"] >= 1 and st["n_fallback"] == 1, st
+    # (round 6: the pass finishes its flagged rows on the device -- small_tail_kernel -- so the overflowing list is counted as a
+    #  row redone exactly, n_redo, not as a matrix-path fallback of the host's)
+    assert st["n_refine2"] >= 1 and st["n_fallback"] + st["n_redo"] == 1, st
     rd2, ridx = O().topk_from_d2(O().l2_matrix(R.cpu().numpy(), Q.cpu().numpy()), k)
     dd, ii = d2.cpu().numpy(), idx.cpu().numpy()
     assert np.abs(dd - rd2).max() < 1e-5

@@ -44,3 +44,16 @@ for s in ("knn_level0", "knn_gemm", "knn_select"):
 print(f"stages sum {tot * 1e3:.1f} us; wall per search {e0.elapsed_time(e1) / reps * 1e3:.1f} us; streamed 2.05 GB -> "
       f"{2.048e9 / (tot * 1e-3) / 1e12:.2f} TB/s of the stage sum = {2.048e9 / (tot * 1e-3) / 8e12:.3f} of HBM peak")
 print(eng.search_stats())
+# the call as a caller sees it: stage timers off, `reps` calls back to back, ONE synchronisation at the end (bench.py's call_ms_wall)
+import time  # noqa: E402
+
+eng.set_profiling(False)
+for _ in range(5):
+    eng.search(Q, k)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    eng.search(Q, k)
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / reps
+print(f"call_ms_wall {wall * 1e3:.4f} ms -> {2.048e9 / wall / 8e12:.3f} of HBM peak by the wall clock of the call")
