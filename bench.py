@@ -724,15 +724,22 @@ def run(a, top=True):
         pass_ms = g_ms + s_ms
         # headline = the bytes the pass ACTUALLY moves (the fp16 plane once + the refine gathers), over the WHOLE pass
         # (filter + select + exact refinement); the SURVEY's fp32 bytes are kept beside it for comparison only
+        # round 6: `achieved` / `frac` are priced on the CALL'S WALL CLOCK -- the search as a caller sees it, `reps`
+        # calls back to back with one synchronisation at the end (the call no longer synchronises itself: its overflow counters are
+        # read on the device, small_pass_kernels.hip) -- not on the sum of the stage timers, which stays beside it (`frac_by_stage_sum`)
         stream_roof = {"bound": "hbm", "B_q": S, "unit": "GB/s", "peak": PEAK_HBM_GBS,
-                       "achieved": moved / (pass_ms * 1e-3) / 1e9, "frac": moved / (pass_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       "achieved": moved / (call_ms * 1e-3) / 1e9, "frac": moved / (call_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       "frac_by_call_wall": moved / (call_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       "frac_by_stage_sum": moved / (pass_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                        "filter_only_gbs": moved / (g_ms * 1e-3) / 1e9, "filter_only_frac": moved / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                        "survey_fp32_bytes_gbs": alg / (pass_ms * 1e-3) / 1e9,
                        "filter_ms": g_ms, "select_refine_ms": s_ms, "pass_ms": pass_ms, "call_ms_wall": call_ms,
                        "one_image_end_to_end_ms_wall": image_ms,
                        "search_stats": eng.search_stats(),
                        "note": "one 50-segment query image per pass over the whole shard; 'achieved' = bytes actually streamed "
-                               "(2-byte fp16 plane when the filter is f16) / (filter + select + refine time)"}
+                               "(2-byte fp16 plane when the filter is f16) / the wall clock of the call (20 calls back to back, one "
+                               "synchronisation at the end); frac_by_stage_sum = the same bytes / (head + filter + select + refine + tail "
+                               "stage timers, measured in a separate loop with the timers on)"}
 
     res = {
         "metric": "query_images_per_sec", "value": nQ * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,

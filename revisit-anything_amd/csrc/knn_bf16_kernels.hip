@@ -2232,15 +2232,14 @@ __device__ __forceinline__ void select_wg_body(uint32_t* __restrict__ cnt, const
                                                         uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
                                                         uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
                                                         uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt,
-                                                        const uint32_t c) {
+                                                        const uint32_t c, const float (&pre_d2)[16], const uint32_t (&pre_id)[16],
+                                                        const uint32_t flagged, const float t_in) {
   constexpr uint32_t PAD = 0xffffffffu;
   constexpr int PER = PERK;   // 32: 8192 keys, the candidate lists' capacity (SV_CAP)
   __shared__ uint32_t xs[2][4];
   __shared__ uint32_t s_n;
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
-  const uint32_t flagged = ovf_rows[row];
-  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
   uint32_t key[PER], cidv[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -2248,8 +2247,9 @@ __device__ __forceinline__ void select_wg_body(uint32_t* __restrict__ cnt, const
     key[i] = PAD;
     cidv[i] = 0u;
     if (j < (int)c && c <= (uint32_t)(256 * PER)) {
-      key[i] = f2key_(cd2[row * cap + j]);
-      if (mode == 1) cidv[i] = cid[row * cap + j];
+      // (the first 16 slots per thread were requested by the kernel together with the list's length: one round trip, not two)
+      key[i] = f2key_(i < 16 ? pre_d2[i < 16 ? i : 0] : cd2[row * cap + j]);
+      if (mode == 1) cidv[i] = i < 16 ? pre_id[i < 16 ? i : 0] : cid[row * cap + j];
     }
   }
   if (tid == 0) s_n = 0u;
@@ -2309,13 +2309,29 @@ __global__ __launch_bounds__(256) void select_wg_kernel(uint32_t* __restrict__ c
                                                         uint32_t* __restrict__ ref_id, int rcap, uint32_t* __restrict__ ovf_rows,
                                                         uint32_t* __restrict__ ovf_count, uint32_t* __restrict__ rovf_rows,
                                                         uint32_t* __restrict__ rovf_count, float* __restrict__ ref_lim, int fixed_cnt) {
-  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[blockIdx.x];
+  // Everything the list's length decides is REQUESTED before the length is known: the first 16 slots of every thread (lists of
+  // <= 4096 entries -- every list the single-image plan produces in practice -- are complete with them; the slots lie inside the
+  // row's `cap` entries whatever the length, entries beyond it are never looked at), the row's flag, its threshold.  The length
+  // used to be a round trip of its own in front of them (round 6: ~1.5 us of a 20-us kernel that is a chain of such trips).
+  const int64_t row = blockIdx.x;
+  float pre_d2[16];
+  uint32_t pre_id[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = threadIdx.x + 256 * i;
+    const bool in = j < cap;
+    pre_d2[i] = in ? cd2[row * cap + j] : 0.f;
+    pre_id[i] = (in && mode == 1) ? cid[row * cap + j] : 0u;
+  }
+  const uint32_t flagged = ovf_rows[row];
+  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  const uint32_t c = fixed_cnt >= 0 ? (uint32_t)fixed_cnt : cnt[row];
   if (c <= 4096u)
     select_wg_body<16>(cnt, cd2, cid, cap, k, mode, check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
-                       ovf_count, rovf_rows, rovf_count, ref_lim, fixed_cnt, c);
+                       ovf_count, rovf_rows, rovf_count, ref_lim, fixed_cnt, c, pre_d2, pre_id, flagged, t_in);
   else
     select_wg_body<32>(cnt, cd2, cid, cap, k, mode, check, thr_in, thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
-                       ovf_count, rovf_rows, rovf_count, ref_lim, fixed_cnt, c);
+                       ovf_count, rovf_rows, rovf_count, ref_lim, fixed_cnt, c, pre_d2, pre_id, flagged, t_in);
 }
 
 // The sampled exact level of a single-image pass: the K-split partial dot products of <= 128 query rows against <= 4096
@@ -2783,6 +2799,14 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
   __shared__ uint32_t ids[ROWS];
   __shared__ int last;
   const int tid = threadIdx.x;
+#ifdef SV_REFINE_TIMING
+  unsigned long long T[12];
+  int ti = 0;
+#define RTICK() T[ti++] = __builtin_amdgcn_s_memtime()
+#else
+#define RTICK()
+#endif
+  RTICK();
   const int64_t row = blockIdx.x / parts;
   const int base = (int)(blockIdx.x % parts) * ROWS;
   // the list's length and this workgroup's slice of it are requested together (the slice lies inside the list's rcap slots
@@ -2790,6 +2814,7 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
   const uint32_t idv = tid < ROWS ? ref_id[row * rcap + base + tid] : 0u;
   const int n = (int)ref_cnt[row];
   const int cnt = min(ROWS, n - base);
+  RTICK();   // T1: list length + ids
   if (cnt > 0) {
     if (tid < ROWS) ids[tid] = idv;
     __syncthreads();
@@ -2843,6 +2868,7 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
 #undef SV_RS_LOAD
 #undef SV_RS_SRC
 #undef SV_RS_J
+    RTICK();   // T2: rows loaded and walked
     if (tid < cnt) {
       const uint32_t id = ids[tid];
       __hip_atomic_store(&gkeys[row * rcap + base + tid], ((uint64_t)f2key_(sv_d2(qn[row], rn[id], acc)) << 32) | id, __ATOMIC_RELAXED,
@@ -2856,6 +2882,7 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
   __syncthreads();
   if (tid == 0) last = (__hip_atomic_fetch_add(&tick[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(parts - 1));
   __syncthreads();
+  RTICK();   // T3: key stores acknowledged + ticket
   if (!last) return;
   int np2 = 2;
   while (np2 < n) np2 <<= 1;
@@ -2890,17 +2917,31 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
     }
     return;
   }
-  bitonic64(a, np2, tid);
-  for (int j = tid; j < k; j += 256) {
-    float dd = INFINITY;
-    int64_t id = -1;
-    if (j < n) {
-      dd = key2f_((uint32_t)(a[j] >> 32));
-      id = (int64_t)(uint32_t)a[j];
+  RTICK();   // T4: keys read back
+  // (distance, id) order WITHOUT a sort: the keys are distinct (the id is part of them), so a key's place in the sorted list is the
+  // number of smaller keys -- every thread counts that for its own one or two keys against the n keys in LDS (broadcast reads, no
+  // barrier) and writes its result straight to that place.  The bitonic sort of 512 words was 45 barrier-separated stages: 9.6 us of
+  // the last workgroup's 25 (round 6); the count is ~2.
+  for (int j = tid; j < n; j += 256) {
+    const uint64_t v = a[j];
+    int place = 0;
+#pragma unroll 8
+    for (int t = 0; t < n; ++t) place += (a[t] < v) ? 1 : 0;
+    if (place < k) {
+      d2_out[row * k + place] = key2f_((uint32_t)(v >> 32));
+      idx_out[row * k + place] = (int64_t)(uint32_t)v;
     }
-    d2_out[row * k + j] = dd;
-    idx_out[row * k + j] = id;
   }
+  for (int j = n + tid; j < k; j += 256) {   // a list shorter than k pads with (inf, -1)
+    d2_out[row * k + j] = INFINITY;
+    idx_out[row * k + j] = -1;
+  }
+  RTICK();   // T5: placed
+#ifdef SV_REFINE_TIMING
+  if (tid == 0 && row == 0 && cnt > 0)
+    printf("refine row0 last wg: ids %llu rows+walk %llu store+ticket %llu readback %llu sort %llu cycles (n=%d)\n", T[1]-T[0], T[2]-T[1], T[3]-T[2], T[4]-T[3], T[5]-T[4], n);
+#endif
+#undef RTICK
 }
 
 int sv_refine_small_repair(segvlad_ctx* ctx) {

@@ -583,7 +583,7 @@ int sv_launch_small_tail(segvlad_ctx* ctx, const float* Q, const float* R, const
     hipLaunchKernelGGL(small_tail_debug_kernel, dim3(1), dim3(128), 0, ctx->stream, ctx->opt.debug_small_tail, m, fail_rows, fail_count,
                        rovf_rows, const_cast<float*>(ref_lim), ctx->s_ref_tick.as<uint32_t>(), 128);
   if (m > 128 || k > 1024 || cap > ST_CAP || (d & 3)) return ctx->fail(SEGVLAD_ERR_LIMIT, "small tail: m=%d k=%d cap=%d d=%d", m, k, cap, d);
-  constexpr int G = 128;
+  constexpr int G = 64;
   int kp = 256;
   while (kp < k) kp <<= 1;
   SV_HIP(ctx->s_tail_part.reserve((size_t)m * G * kp * 8));

@@ -447,8 +447,8 @@ def test_knn_exact_duplicates_are_at_distance_zero_like_faiss(eng, n, nq):
     """faiss's IndexFlatL2 sets a negative ||q||^2 + ||r||^2 - 2 q.r to zero before its heap sees it (utils/distances.cpp,
     exhaustive_L2sqr_blas), so a query that IS a reference row has d2 = 0 and `2 - d2` (place_rec_main.py:78-81) never exceeds 2
     (VERDICT r05 missing #5: the unclamped form returned -1e-7).  Unit rows of d = 1024, every query a copy of a reference row,
-    some rows present two or three times: d2 >= 0 everywhere, the copies first and in id order, sims <= 2, bits equal to the
-    oracle's clamp."""
+    some rows present two or three times: d2 >= 0 everywhere, the copies first and in id order, sims <= 2, values equal to the
+    oracle's (which clamps like faiss)."""
     import torch
     rng = np.random.Generator(np.random.PCG64(606))
     d, k = 1024, 20
@@ -465,9 +465,11 @@ def test_knn_exact_duplicates_are_at_distance_zero_like_faiss(eng, n, nq):
     sims, _ = eng.sims_from_d2(d2, idx, 10)
     d2, idx, sims = d2.cpu().numpy(), idx.cpu().numpy(), sims.cpu().numpy()
     assert (d2 >= 0).all() and (sims <= 2.0).all()
-    assert np.array_equal(d2[:, 0], np.zeros(nq, np.float32)) and np.array_equal(sims[:, 0], np.full(nq, 2.0, np.float32))
-    assert idx[0, :3].tolist() == sorted([int(src[0]), n - 2, n - 1]) and (d2[0, :3] == 0).all()
-    assert idx[1, :2].tolist() == sorted([int(src[1]), n - 3]) and (d2[1, :2] == 0).all()
+    # (||q||^2 + ||r||^2 - 2 q.r of a row with itself is a few ulp of 2 either side of zero in fp32 -- in faiss too; the negative
+    #  ones are the ones the clamp catches)
+    assert (d2[:, 0] < 5e-6).all() and (d2[:, 0] == 0).any() and (sims[:, 0] > 2.0 - 5e-6).all()
+    assert idx[0, :3].tolist() == sorted([int(src[0]), n - 2, n - 1]) and (d2[0, :3] == d2[0, 0]).all()
+    assert idx[1, :2].tolist() == sorted([int(src[1]), n - 3]) and (d2[1, :2] == d2[1, 0]).all()
     assert np.array_equal(idx[2:, 0], src[2:])
     rd2, ridx = O().knn_l2(R, Q, k)
     assert (rd2 >= 0).all() and np.abs(d2 - rd2).max() < 1e-5
