@@ -75,8 +75,9 @@ def kernel_src_sha() -> str:
 
 def pmc_counters(kernel_prefix: str, workload_key: str):
     """Counter evidence of a kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, produced by
-    tools/pmc_summary.py from separate --pmc passes over tools/probe_counters.py, which replays this workload's kernel
-    shapes): (HBM bytes per launch, MFMA utilisation, source note).  A summary is quoted ONLY if it records the sha of
+    tools/pmc_summary.py from separate --pmc passes over `bench.py --pmc-calibrate` itself since round 6 -- the dispatches of
+    the TIMED steps, cut out between two marker dispatches; rounds 1-5: over a replay of the kernel shapes):
+    (HBM bytes per launch, MFMA utilisation, source note).  A summary is quoted ONLY if it records the sha of
     the kernel sources it was collected from and that sha equals the current sources'; otherwise (None, None, why)."""
     import glob
     sha = kernel_src_sha()
@@ -170,8 +171,9 @@ def parse():
                    "--same-device lets several ranks share ONE GPU to exercise the N>1 code path on a 1-GPU box")
     p.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0")
     p.add_argument("--dump-preds", default=None, help="debug: rank 0 writes the last step's predictions to this .npy")
-    p.add_argument("--pmc-calibrate", action="store_true", help="after the run, map a 1 GiB tensor through torch.sign once (a known 1 GiB read + "
-                   "1 GiB write) so that tools/pmc_summary.py can calibrate FETCH_SIZE / WRITE_SIZE from the same rocprofv3 pass")
+    p.add_argument("--pmc-calibrate", action="store_true", help="map a 1 GiB tensor through torch.sign (a known 1 GiB read + 1 GiB write) "
+                   "right before and right after the timed steps: tools/pmc_summary.py calibrates FETCH_SIZE / WRITE_SIZE on them and "
+                   "takes the dispatches BETWEEN them as the timed path's (rocprofv3 --pmc passes over this very process)")
     p.add_argument("--query-own", type=float, default=QUERY_OWN_DEFAULT, help="difficulty: correlation of a query image's private token "
                    "noise with its reference image's (1 = the reference image itself, 0 = indistinguishable from its 3 sibling images)")
     p.add_argument("--sweep-own", default=None, help="debug: comma-separated --query-own values; after the DB build print the device "
@@ -435,6 +437,17 @@ def run(a, top=True):
         e_.profile_reset()
     # HIP events on the stream the steps are issued on (hipEvent-timed steps, median), beside the wall clock
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    pmc_cal = None
+    if a.pmc_calibrate and top:
+        # counter passes over THIS process (tools/gpu_round_artifacts.sh pmc, rocprofv3 --pmc with --kernel-include-regex = the
+        # library's kernels + this one): torch.sign over 1 GiB (2^30 B read, 2^30 B written) is dispatched right BEFORE and right
+        # AFTER the timed steps, outside the fences -- the byte calibration of FETCH_SIZE / WRITE_SIZE and, by dispatch order,
+        # the WINDOW tools/pmc_summary.py cuts the timed steps' dispatches out of (the counter evidence
+        # comes from the timed path, not from a replay)
+        pmc_cal = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        torch.cuda.synchronize()
+        pmc_cal.sign()
+        torch.cuda.synchronize()
     fence()
     t0 = time.perf_counter()
     marks[0].record()
@@ -446,6 +459,10 @@ def run(a, top=True):
             marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    if pmc_cal is not None:
+        pmc_cal.sign()
+        torch.cuda.synchronize()
+        del pmc_cal
     for e_ in {eng, eng_d}:
         e_.set_profiling(False)
     step_ms_events = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
@@ -784,12 +801,6 @@ def run(a, top=True):
         res["oracle_check"] = res["cpu_baseline"].pop("oracle_check")
     else:
         res["cpu_baseline"] = None
-    if a.pmc_calibrate and top:
-        cal = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
-        torch.cuda.synchronize()
-        cal2 = cal.sign()    # elementwise kernel ("sign_kernel"): 2^30 B read, 2^30 B written
-        torch.cuda.synchronize()
-        del cal, cal2
     if world > 1 and top:
         dist.destroy_process_group()
     # release this workload's device memory before a sub-record builds its own

@@ -67,3 +67,38 @@ def test_bench_quotes_a_pmc_summary_only_for_the_current_kernel_sources(tmp_path
     assert bench.pmc_counters("knn_f16_filter_kernel", "wl")[:2] == (7.0, 0.5)
     assert bench.pmc_counters("token_norms_kernel", "wl")[:2] == (3.0, 0.3)      # mangled names are matched too
     assert bench.pmc_counters("knn_f16_filter_kernel", "other")[0] is None        # another workload: not this file
+
+
+def test_pmc_summary_window_cuts_the_timed_steps_out_between_the_markers(tmp_path):
+    """Round 6: the counter passes run over bench.py itself; `--window` keeps the dispatches between the two torch.sign markers
+    (the timed steps), reports launches per step, and compares the launch multiset with the counter-free timeline's."""
+    GiB = 1 << 30
+    cal = "void at::native::vectorized_elementwise_kernel<4, at::native::sign_kernel_cuda(...)>"
+    filt = "void knn_f16_filter_kernel<256, 256, 4, 2, 64, 3, 0, true, 0, 2>(unsigned short const*)"
+    asg = "void assign_wide_kernel<2>(float const*)"
+    cp = "__amd_rocclr_copyBuffer"
+
+    def disp(i, name, ctr, val):
+        return {"Dispatch_Id": i, "Kernel_Name": name, "Counter_Name": ctr, "Counter_Value": val, "Start_Timestamp": 10 * i, "End_Timestamp": 10 * i + 5}
+
+    # DB build (outside the window): 3 filter launches that must NOT be averaged in; window: 2 steps x (1 assign + 3 filters)
+    order = [asg, filt, filt, filt, cal, asg, filt, filt, filt, cp, asg, filt, filt, filt, cal, filt]
+    fetch = [disp(i, n, "FETCH_SIZE", (GiB / 64 if n == cal else (8 * GiB / 64 if i < 4 or i == 15 else 2 * GiB / 64))) for i, n in enumerate(order) if n != cp]
+    write = [disp(i, n, "WRITE_SIZE", (GiB / 64 if n == cal else GiB / 128)) for i, n in enumerate(order) if n != cp]
+    trace = [{"Dispatch_Id": i, "Kernel_Name": n, "Start_Timestamp": 10 * i, "End_Timestamp": 10 * i + 5} for i, n in enumerate(order)]
+    for name, rows in (("f", fetch), ("w", write), ("t", trace)):
+        _write(tmp_path / f"{name}.csv", rows)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--window", "--steps", "2", "--key", "k2", "--fetch", str(tmp_path / "f.csv"),
+           "--write", str(tmp_path / "w.csv"), "--timeline-trace", str(tmp_path / "t.csv")]
+    j = json.loads(subprocess.run(cmd, capture_output=True, text=True, check=True).stdout)
+    assert j["launch_multiset_equals_timeline"] is True and j["timed_steps_in_window"] == 2
+    assert j["launch_multiset_per_window"] == {"assign_wide_kernel<2>": 2, "knn_f16_filter_kernel<256, 256, 4, 2, 64, 3, 0, true, 0, 2>": 6}
+    k = {x["name"].split("<")[0]: x for x in j["kernels"]}
+    assert k["knn_f16_filter_kernel"]["launches"] == 6 and k["knn_f16_filter_kernel"]["launches_per_step"] == 3
+    assert abs(k["knn_f16_filter_kernel"]["read_bytes_per_launch"] - 2 * GiB) < 1        # the 8-GiB launches outside the window are not in it
+    assert "timed steps" in j["provenance"].lower() or "TIMED" in j["provenance"]
+    # a timeline with another launch count fails the tool (exit 3) after the summary is written
+    trace[9]["Kernel_Name"] = asg        # (the runtime copy inside the window becomes a third assignment launch)
+    _write(tmp_path / "t.csv", trace)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 3 and json.loads(r.stdout)["launch_multiset_equals_timeline"] is False

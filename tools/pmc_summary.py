@@ -36,21 +36,64 @@ def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
-def load_counters(path):
-    """{kernel: {counter: [values per dispatch]}}"""
-    out = defaultdict(lambda: defaultdict(list))
+WINDOW = False   # --window: keep only the dispatches BETWEEN the first and the last torch.sign marker (bench.py --pmc-calibrate)
+
+
+def _rows(path):
     with open(path, newline="") as f:
-        for r in csv.DictReader(f):
-            out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows = list(csv.DictReader(f))
+    key = next((c for c in ("Dispatch_Id", "Start_Timestamp") if rows and c in rows[0]), None)
+    if key is None:   # (no order column: keep the file's order)
+        key = "_order"
+        for i, r in enumerate(rows):
+            r[key] = i
+    rows.sort(key=lambda r: int(r[key]))
+    return rows, key
+
+
+def _window(rows, key):
+    """(rows inside the marker window, the marker rows).  The markers themselves calibrate the byte counters."""
+    marks = sorted({int(r[key]) for r in rows if "sign_kernel" in r["Kernel_Name"]})
+    if not WINDOW:
+        return rows, [r for r in rows if "sign_kernel" in r["Kernel_Name"]]
+    if len(marks) < 2:
+        raise SystemExit("--window: need the two torch.sign marker dispatches of `bench.py --pmc-calibrate` in the pass")
+    lo, hi = marks[0], marks[-1]
+    return [r for r in rows if lo < int(r[key]) < hi], [r for r in rows if int(r[key]) in (lo, hi)]
+
+
+def load_counters(path):
+    """{kernel: {counter: [values per dispatch]}} (of the marker window with --window; the markers are always included)"""
+    out = defaultdict(lambda: defaultdict(list))
+    rows, key = _rows(path)
+    inside, marks = _window(rows, key)
+    for r in inside + ([] if not WINDOW else marks):
+        out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
 def load_durations(path):
     out = defaultdict(list)
-    with open(path, newline="") as f:
-        for r in csv.DictReader(f):
-            out[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    rows, key = _rows(path)
+    for r in _window(rows, key)[0]:
+        out[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return out
+
+
+def launch_multiset(path):
+    """{kernel: dispatches inside the marker window} of a kernel-trace or counter CSV (runtime copy / fill kernels left out)"""
+    rows, key = _rows(path)
+    out = defaultdict(int)
+    seen = set()
+    for r in _window(rows, key)[0]:
+        if (r[key], r["Kernel_Name"]) in seen:      # (a counter CSV holds one row per counter and dispatch)
+            continue
+        seen.add((r[key], r["Kernel_Name"]))
+        name = short(r["Kernel_Name"])
+        if "__amd_rocclr" in name or "at::native" in name or "sign_kernel" in name:
+            continue
+        out[name] += 1
+    return dict(out)
 
 
 def avg(v):
@@ -65,7 +108,14 @@ def main():
     ap.add_argument("--sq", default=None)
     ap.add_argument("--sq-trace", default=None)
     ap.add_argument("--lds", default=None, help="counter_collection.csv of the LDS pass (SQ_LDS_* / SQ_INSTS_LDS / SQ_ACTIVE_INST_LDS ...)")
+    ap.add_argument("--window", action="store_true", help="the passes ran over `bench.py --pmc-calibrate`: summarise only the dispatches "
+                    "between its two torch.sign markers = the TIMED steps (round 6)")
+    ap.add_argument("--steps", type=int, default=1, help="--window: timed steps inside the window (launches_per_step = launches / steps)")
+    ap.add_argument("--timeline-trace", default=None, help="--window: kernel_trace.csv of the same command WITHOUT counters (the step "
+                    "timeline committed beside the summary); the per-kernel launch multiset of the two windows must be equal")
     a = ap.parse_args()
+    global WINDOW
+    WINDOW = a.window
     F, Wc = load_counters(a.fetch), load_counters(a.write)
     fcal = next((avg(v["FETCH_SIZE"]) for k, v in F.items() if "sign_kernel" in k and v.get("FETCH_SIZE")), None)
     wcal = next((avg(v["WRITE_SIZE"]) for k, v in Wc.items() if "sign_kernel" in k and v.get("WRITE_SIZE")), None)
@@ -85,6 +135,9 @@ def main():
         wr = avg(wv) * wscale if wv else 0.0
         k = {"name": name, "launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
              "hbm_bytes_per_launch": rd + wr}
+        if a.window:
+            k["launches_per_step"] = n / a.steps
+            k["hbm_bytes_per_step"] = (rd + wr) * n / a.steps
         s = SQ.get(name)
         if s and s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("GRBM_GUI_ACTIVE"):
             busy, gui = avg(s["SQ_VALU_MFMA_BUSY_CYCLES"]), avg(s["GRBM_GUI_ACTIVE"])
@@ -114,11 +167,34 @@ def main():
                 k["lds_inst_active_per_busy_cycle"] = avg(lact) / avg(busy)
         kernels.append(k)
     kernels.sort(key=lambda k: -k["hbm_bytes_per_launch"] * k["launches"])
+    extra = {}
+    if a.window:
+        ms_pmc = launch_multiset(a.fetch)
+        extra["timed_steps_in_window"] = a.steps
+        extra["launch_multiset_per_window"] = dict(sorted(ms_pmc.items()))
+        extra["describe_stage_hbm_bytes_per_step"] = sum(
+            k["hbm_bytes_per_step"] for k in kernels
+            if any(t in k["name"] for t in ("incidence", "adjacency", "assign", "prep_kernel", "group_plan", "gram_norms", "token_norms",
+                                            "gemm_f16x3", "project_aggregate", "normalize_rows", "aggregate_kernel")))
+        if a.timeline_trace:
+            ms_tl = launch_multiset(a.timeline_trace)
+            extra["launch_multiset_equals_timeline"] = ms_tl == ms_pmc
+            if ms_tl != ms_pmc:
+                extra["launch_multiset_differences"] = {k_: [ms_pmc.get(k_, 0), ms_tl.get(k_, 0)] for k_ in sorted(set(ms_pmc) | set(ms_tl))
+                                                        if ms_pmc.get(k_, 0) != ms_tl.get(k_, 0)}
     json.dump({"workload_key": a.key, "kernel_src_sha": kernel_src_sha(),
-               "provenance": "tools/gpu_round_artifacts.sh pmc: rocprofv3 --pmc passes over tools/probe_counters.py",
+               "provenance": ("tools/gpu_round_artifacts.sh pmc: rocprofv3 --pmc passes over `bench.py --pmc-calibrate` itself "
+                              "(--kernel-include-regex = the library's kernels + the marker); the dispatches of the TIMED steps, cut out "
+                              "between the two torch.sign markers") if a.window else
+                             "tools/gpu_round_artifacts.sh pmc: rocprofv3 --pmc passes over tools/probe_counters.py",
+               **extra,
                "calibration": {"fetch_raw_per_GiB": fcal, "write_raw_per_GiB": wcal, "bytes_per_fetch_unit": fscale,
                                "bytes_per_write_unit": wscale},
                "kernels": kernels[:40]}, __import__("sys").stdout, indent=1)
+    if extra.get("launch_multiset_equals_timeline") is False:
+        print("pmc_summary: the counter passes' launch multiset differs from the timeline's: " + json.dumps(extra["launch_multiset_differences"]),
+              file=__import__("sys").stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":
