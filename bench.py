@@ -195,6 +195,10 @@ def parse():
                    "(tuning A/B: e.g. --set batch_plan=1); recorded in the line")
     p.add_argument("--no-ubench", action="store_true", help="skip the live MFMA ceiling micro-benchmark (tools/ubench/mfma_peak) and the "
                    "same-shape plain-GEMM yardstick (tools/yardstick_gemm.py)")
+    p.add_argument("--dry-run-collectives", action="store_true", help="no benchmark: the multi-GPU exchange checked WITHOUT the other ranks "
+                   "(sharded.dry_run_collectives: operand shapes / dtypes / contiguity of both collectives and the unpack + merge for world "
+                   "sizes 2..8 against a single index, the real collectives + the C-ABI communicator at world size 1 on the nccl backend); "
+                   "prints a JSON report and exits non-zero on a violation")
     p.add_argument("--shard-sim", type=int, default=8, help="N=1 line: emulate ONE rank of a row-sharded run over this many GPUs on the one "
                    "GPU (a 1/W shard of the database, ALL query segments searched k_vote deep, 1/W of the query images described, the "
                    "W-way merge and the vote; no collective) -> the 'shard_sim' sub-record; 0 = skip")
@@ -448,6 +452,8 @@ def run(a, top=True):
         torch.cuda.synchronize()
         pmc_cal.sign()
         torch.cuda.synchronize()
+    if world > 1:
+        index.profile_collectives(True)
     fence()
     t0 = time.perf_counter()
     marks[0].record()
@@ -459,6 +465,9 @@ def run(a, top=True):
             marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    coll_ms = index.collective_ms() if world > 1 else {}
+    if world > 1:
+        index.profile_collectives(False)
     if pmc_cal is not None:
         pmc_cal.sign()
         torch.cuda.synchronize()
@@ -567,6 +576,10 @@ def run(a, top=True):
     if world > 1:   # every rank's stage times travel to rank 0 (the slowest rank sets the step time)
         mine = {k: round(v["ms_per_step"], 4) for k, v in stages.items()}
         mine["n_local_rows"] = int(index.n_local)
+        # (round 6) the collectives as THIS rank's stream saw them (event pairs around each call: a rank that waits for a slower
+        # peer shows it here) and the bytes it sent / received per step: the first real SCALE run is diagnosable from its one line
+        mine["collective_ms_per_step"] = {k: round(v / a.steps, 4) for k, v in coll_ms.items()}
+        mine["collective_bytes_per_step"] = ShardedSegmentIndex.collective_bytes(world, nQ * S, 50, P, [int(qb[r + 1] - qb[r]) * S for r in range(world)])
         try:
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
@@ -835,8 +848,52 @@ def sub_record(a, **over):
     return out
 
 
+def dry_run_collectives_main(a):
+    """bench.py --dry-run-collectives (also: tests/test_gpu_sharded.py): see sharded.dry_run_collectives.  One process; a world-1
+    process group on the requested backend (nccl = RCCL) is created so that the REAL collectives and the C-ABI communicator run."""
+    from revisit_anything_amd.sharded import dry_run_collectives
+
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    created = False
+    if not dist.is_initialized():
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend, rank=0, world_size=1)
+        created = True
+    eng = SegVLADEngine(local)
+    rep = dry_run_collectives(eng, dev, worlds=(2, 3, 4, 5, 6, 7, 8), nq=200, k=50, d=64)
+    # the C-ABI's own communicator at world size 1: communicator id -> init -> sharded search == plain search, row gather == identity
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    R = torch.nn.functional.normalize(torch.randn(5000, 64, device=dev, generator=g), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(100, 64, device=dev, generator=g), dim=1)
+    index = ShardedSegmentIndex(eng, rank=0, world=1, device=dev, native_comm=True)
+    index.build(R, torch.arange(5000, dtype=torch.int32, device=dev) // 50)
+    d2n, idn = index.search(Q, 50)
+    d2p, idp = eng.search(Q, 50)
+    ok_native = bool(torch.equal(torch.as_tensor(d2n), d2p) and torch.equal(torch.as_tensor(idn), idp))
+    rows = eng.allgather_rows(Q.contiguous(), world=1)
+    ok_native = ok_native and bool(torch.equal(rows, Q))
+    rep["native_comm_world_1"] = {"ok": ok_native, "info": eng.comm_info() if hasattr(eng, "comm_info") else None}
+    rep["ok"] = all(v["ok"] for v in rep["worlds"].values()) and ok_native and rep.get("world_1_process_group", {}).get("ok", False)
+    eng.close()
+    if created:
+        dist.destroy_process_group()
+    print(json.dumps({"dry_run_collectives": rep}))
+    if not rep["ok"]:
+        raise SystemExit(4)
+
+
 def main():
     a = parse()
+    if a.dry_run_collectives:
+        dry_run_collectives_main(a)
+        return
     res = run(a, top=True)
     if res is None:
         return

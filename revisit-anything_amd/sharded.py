@@ -50,6 +50,41 @@ class ShardedSegmentIndex:
         self.row_start = np.zeros(self.world + 1, dtype=np.int64)
         self.n_local = 0
         self.img_of_seg_global: Optional[torch.Tensor] = None
+        # profile_collectives(True): every collective on the data path is bracketed by a pair of events on the current stream;
+        # collective_ms() sums them per name (the N > 1 bench line carries them per rank, with the bytes of collective_bytes())
+        self._coll_events = None
+
+    # ---- what travels, and how long it takes --------------------------------------------------------------------------
+    def profile_collectives(self, on: bool = True):
+        self._coll_events = [] if on else None
+
+    def _timed(self, name: str, fn):
+        if self._coll_events is None or self.device.type != "cuda":
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self._coll_events.append((name, e0, e1))
+        return out
+
+    def collective_ms(self) -> dict:
+        """{collective name: summed milliseconds since profile_collectives(True)} (synchronises on the recorded events)."""
+        out: dict = {}
+        for name, e0, e1 in self._coll_events or []:
+            e1.synchronize()
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        if self._coll_events is not None:
+            self._coll_events = []
+        return out
+
+    @staticmethod
+    def collective_bytes(world: int, nq: int, k: int, d: int, rows_per_rank: Sequence[int]) -> dict:
+        """Bytes every rank SENDS / RECEIVES per retrieve(): the all-gather of the query descriptors (fp32 rows; ragged slices are
+        padded to the longest) and the all-gather of the per-shard top-k as packed 12-byte records."""
+        mx = max(int(r) for r in rows_per_rank) if len(rows_per_rank) else 0
+        return {"query_rows_allgather_send": mx * d * 4, "query_rows_allgather_recv": world * mx * d * 4,
+                "topk_records_allgather_send": nq * k * 12, "topk_records_allgather_recv": world * nq * k * 12}
 
     # ---- build --------------------------------------------------------------------------------------
     def build(self, local_rows, local_img_of_seg):
@@ -103,15 +138,15 @@ class ShardedSegmentIndex:
         x = local_rows.contiguous()
         if self.native and min(rows_per_rank) == mx and x.dim() == 2 and x.dtype == torch.float32:
             # (the C-ABI gathers fp32 rows; any other type keeps torch.distributed's collective and its dtype)
-            return self.be.allgather_rows(x, world=self.world)
+            return self._timed("query_rows_allgather", lambda: self.be.allgather_rows(x, world=self.world))
         if min(rows_per_rank) == mx:   # equal slices (the usual case): ONE all_gather_into_tensor, no padding, no trimming
             out = torch.empty((self.world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-            dist.all_gather_into_tensor(out, x, group=self.group)
+            self._timed("query_rows_allgather", lambda: dist.all_gather_into_tensor(out, x, group=self.group))
             return out
         if x.shape[0] < mx:
             x = torch.cat([x, x.new_zeros((mx - x.shape[0],) + tuple(x.shape[1:]))])
         parts = [torch.empty_like(x) for _ in range(self.world)]
-        dist.all_gather(parts, x, group=self.group)
+        self._timed("query_rows_allgather", lambda: dist.all_gather(parts, x, group=self.group))
         return torch.cat([p[:n] for p, n in zip(parts, rows_per_rank)])
 
     # ---- query --------------------------------------------------------------------------------------
@@ -121,7 +156,8 @@ class ShardedSegmentIndex:
         the global top-k is contained in the union of the per-shard top-k lists)."""
         nq = int(Q.shape[0])
         if self.native:   # local search, packed all-gather, merge: one C-ABI call on the context's stream
-            return self.be.search_sharded(Q, k, int(self.row_start[self.rank]))
+            # (its all-gather sits inside the C-ABI call: the event pair brackets local search + exchange + merge)
+            return self._timed("native_search_sharded", lambda: self.be.search_sharded(Q, k, int(self.row_start[self.rank])))
         if self.world == 1 and self.n_local and (k_local is None or k_local <= k):
             # a single index: the engine's result as it is (no id offset, no slice: four small torch kernels and their launch
             # gaps per call otherwise -- 0.1 ms of a 26-ms step)
@@ -146,14 +182,33 @@ class ShardedSegmentIndex:
         {fp32 bits, id low, id high}; returns ([nq, world*k] d2, [nq, world*k] ids), shard-major within a row.
         (Also valid at world size 1, which is how the RCCL path is smoke-tested on a 1-GPU box.)"""
         nq, k = int(d2.shape[0]), int(d2.shape[1])
-        rec = torch.empty((nq, k, 3), dtype=torch.int32, device=self.device)
+        rec = self.pack_topk_records(d2, idx)
+        allrec = torch.empty((self.world * nq, k, 3), dtype=torch.int32, device=self.device)   # rank-major concatenation
+        self._timed("topk_records_allgather", lambda: dist.all_gather_into_tensor(allrec, rec, group=self.group))
+        return self.unpack_topk_records(allrec, self.world)
+
+    @staticmethod
+    def pack_topk_records(d2: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """[nq, k] (fp32 d2, int64 global id) -> [nq, k, 3] int32 records {fp32 bits, id low, id high}, contiguous: what a rank
+        hands to the all-gather."""
+        if d2.dtype != torch.float32 or idx.dtype != torch.int64 or d2.shape != idx.shape or d2.dim() != 2:
+            raise ValueError(f"pack_topk_records: want fp32 / int64 [nq, k] pairs, got {d2.dtype}{tuple(d2.shape)} / {idx.dtype}{tuple(idx.shape)}")
+        nq, k = int(d2.shape[0]), int(d2.shape[1])
+        rec = torch.empty((nq, k, 3), dtype=torch.int32, device=d2.device)
         rec[:, :, 0] = d2.contiguous().view(torch.int32)
         rec[:, :, 1:] = idx.contiguous().view(torch.int32).view(nq, k, 2)
-        allrec = torch.empty((self.world * nq, k, 3), dtype=torch.int32, device=self.device)   # rank-major concatenation
-        dist.all_gather_into_tensor(allrec, rec, group=self.group)
-        allrec = allrec.view(self.world, nq, k, 3).permute(1, 0, 2, 3)                        # [nq, world, k, 3]
-        d2c = allrec[..., 0].contiguous().view(torch.float32).view(nq, self.world * k)
-        idc = allrec[..., 1:].contiguous().view(torch.int64).view(nq, self.world * k)
+        return rec
+
+    @staticmethod
+    def unpack_topk_records(allrec: torch.Tensor, world: int):
+        """The all-gather's output -- the ranks' record blocks concatenated in rank order, [world * nq, k, 3] int32 -- as
+        ([nq, world * k] fp32 d2, [nq, world * k] int64 ids), shard-major within a row (what merge_topk takes)."""
+        if allrec.dtype != torch.int32 or allrec.dim() != 3 or allrec.shape[2] != 3 or allrec.shape[0] % world or not allrec.is_contiguous():
+            raise ValueError(f"unpack_topk_records: want a contiguous int32 [world * nq, k, 3] block, got {allrec.dtype}{tuple(allrec.shape)}")
+        nq, k = int(allrec.shape[0]) // world, int(allrec.shape[1])
+        r = allrec.view(world, nq, k, 3).permute(1, 0, 2, 3)                                    # [nq, world, k, 3]
+        d2c = r[..., 0].contiguous().view(torch.float32).view(nq, world * k)
+        idc = r[..., 1:].contiguous().view(torch.int64).view(nq, world * k)
         return d2c, idc
 
     def retrieve(self, Q, qseg_offsets: Sequence[int], k_search: int = 200, k_vote: int = 50, n_top: int = 5, mode: int = 0,
@@ -176,3 +231,74 @@ class ShardedSegmentIndex:
         pred, sc = self.be.vote(m, sims, np.asarray(qseg_offsets, dtype=np.int32), n_top=n_top, mode=mode,
                                 img_of_seg=self.img_of_seg_global, want_scores=want_scores)
         return pred, sc, m, sims
+
+
+def dry_run_collectives(backend, device, worlds: Sequence[int] = (2, 3, 4, 8), nq: int = 96, k: int = 50, d: int = 64, seed: int = 0) -> dict:
+    """Everything of the multi-GPU exchange that can be checked WITHOUT the other ranks (VERDICT r05 next #5b): the first real
+    N > 1 run must not be the first time these shapes exist.
+
+    For every world size W in `worlds`: a planted index is cut into W image-aligned shards, every shard is searched on `backend`
+    (one after the other, on this one device), each rank's operands of the two collectives are built exactly as the ranks would
+    build them -- `pack_topk_records`, the (padded) query-row slices -- and CHECKED against what `all_gather_into_tensor` demands
+    (dtype, contiguity, output numel == W x input numel); the collective itself is replaced by the concatenation in rank order
+    that it is defined to produce; `unpack_topk_records` + `merge_topk` must then return the single index's (d2, ids) bit for bit.
+    At W = 1 the real collectives run when a process group is initialised (the nccl = RCCL backend on a GPU box).
+    Returns a report; raises AssertionError / ValueError on the first violation."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    n_img, S = 64, 23
+    R = torch.nn.functional.normalize(torch.randn(n_img * S, d, generator=g), dim=1).to(device)
+    Q = torch.nn.functional.normalize(R[torch.randint(0, n_img * S, (nq,), generator=g).to(device)] + 0.05 * torch.randn(nq, d, generator=g).to(device), dim=1)
+    backend.db_reset()
+    backend.db_add(R, None)
+    d2_ref, idx_ref = (torch.as_tensor(t).to(device) for t in backend.search(Q, k))
+    report = {"worlds": {}, "nq": nq, "k": k, "d": d, "rows": n_img * S}
+    for W in worlds:
+        ib = shard_images(n_img, W)
+        recs, row_slices = [], []
+        qb = shard_images(nq, W)                                      # the ranks' slices of the query rows (ragged unless W | nq)
+        rows_per_rank = [int(qb[r + 1] - qb[r]) for r in range(W)]
+        mx = max(rows_per_rank)
+        for r in range(W):
+            lo, hi = int(ib[r]) * S, int(ib[r + 1]) * S
+            backend.db_reset()
+            if hi > lo:
+                backend.db_add(R[lo:hi].contiguous(), None)
+                dd, ii = (torch.as_tensor(t).to(device) for t in backend.search(Q, k))
+                ii = torch.where(ii >= 0, ii + lo, ii)
+            else:
+                dd = torch.full((nq, k), float("inf"), dtype=torch.float32, device=device)
+                ii = torch.full((nq, k), -1, dtype=torch.int64, device=device)
+            rec = ShardedSegmentIndex.pack_topk_records(dd, ii)
+            assert rec.dtype == torch.int32 and rec.is_contiguous() and tuple(rec.shape) == (nq, k, 3), (W, r, rec.shape)
+            recs.append(rec)
+            x = Q[int(qb[r]):int(qb[r + 1])].contiguous()
+            if x.shape[0] < mx:
+                x = torch.cat([x, x.new_zeros((mx - x.shape[0], d))])
+            assert x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape) == (mx, d)
+            row_slices.append(x)
+        allrec = torch.cat(recs)                                      # = all_gather_into_tensor's output: rank-major concatenation
+        assert allrec.numel() == W * recs[0].numel() and allrec.is_contiguous()
+        d2c, idc = ShardedSegmentIndex.unpack_topk_records(allrec, W)
+        assert tuple(d2c.shape) == (nq, W * k) and d2c.dtype == torch.float32 and idc.dtype == torch.int64 and d2c.is_contiguous() and idc.is_contiguous()
+        md, mi = (torch.as_tensor(t).to(device) for t in backend.merge_topk(d2c, idc, W, k))
+        assert torch.equal(mi, idx_ref) and torch.equal(md, d2_ref), f"world {W}: the merged shards differ from the single index"
+        gathered = torch.cat([p[:n] for p, n in zip(row_slices, rows_per_rank)])
+        assert torch.equal(gathered, Q), f"world {W}: the padded row gather does not reproduce the query rows"
+        report["worlds"][str(W)] = {"ok": True, "rows_per_rank": rows_per_rank,
+                                    "bytes": ShardedSegmentIndex.collective_bytes(W, nq, k, d, rows_per_rank)}
+    backend.db_reset()
+    # world 1 through the REAL collectives (whatever backend the process group has: nccl on the GPU box)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() == 1:
+        index = ShardedSegmentIndex(backend, rank=0, world=1, device=device)
+        index.build(R, torch.arange(n_img, dtype=torch.int32).repeat_interleave(S))
+        d2c, idc = index.exchange_topk(d2_ref, idx_ref)
+        assert torch.equal(d2c, d2_ref) and torch.equal(idc, idx_ref)
+        out = torch.empty_like(Q)
+        dist.all_gather_into_tensor(out, Q.contiguous())
+        assert torch.equal(out, Q)
+        t = torch.tensor([1.0], device=device)
+        dist.all_reduce(t)
+        report["world_1_process_group"] = {"backend": dist.get_backend(), "ok": True}
+        backend.db_reset()
+    return report

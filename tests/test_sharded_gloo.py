@@ -217,3 +217,26 @@ def test_single_index_vote_depth_only_equals_search_depth_retrieve():
     d2, ids = idx.search(torch.from_numpy(Q), 20)     # (the pass-through of a single index: the backend's result as it is)
     rd2, rid = OracleBackend.search(idx.be, Q, 20)
     assert torch.equal(d2, rd2) and torch.equal(ids, rid)
+
+
+def test_dry_run_collectives_with_the_oracle_backend():
+    """sharded.dry_run_collectives (VERDICT r05 next #5b): the operands of both collectives, the unpack and the merge for world
+    sizes 2..8 without the other ranks -- here on the CPU with the NumPy checker behind the backend interface; ragged query
+    slices (96 rows over 5 / 7 ranks) included."""
+    from revisit_anything_amd.sharded import ShardedSegmentIndex, dry_run_collectives
+
+    rep = dry_run_collectives(OracleBackend(), torch.device("cpu"), worlds=(2, 3, 4, 5, 7, 8), nq=96, k=20, d=32)
+    assert set(rep["worlds"]) == {"2", "3", "4", "5", "7", "8"} and all(v["ok"] for v in rep["worlds"].values())
+    assert rep["worlds"]["5"]["rows_per_rank"] == [19, 19, 19, 19, 20] and rep["worlds"]["8"]["bytes"]["topk_records_allgather_recv"] == 8 * 96 * 20 * 12
+    # the pure functions refuse what the collective would silently mangle
+    d2 = torch.zeros(4, 3)
+    idx = torch.zeros(4, 3, dtype=torch.int64)
+    with pytest.raises(ValueError):
+        ShardedSegmentIndex.pack_topk_records(d2.double(), idx)
+    rec = ShardedSegmentIndex.pack_topk_records(d2, idx)
+    with pytest.raises(ValueError):
+        ShardedSegmentIndex.unpack_topk_records(torch.cat([rec, rec, rec]), 5)          # 12 rows are not 5 x nq
+    with pytest.raises(ValueError):
+        ShardedSegmentIndex.unpack_topk_records(torch.cat([rec, rec]).to(torch.int64), 2)
+    a, b = ShardedSegmentIndex.unpack_topk_records(torch.cat([rec, rec]), 2)
+    assert tuple(a.shape) == (4, 6) and b.dtype == torch.int64

@@ -33,7 +33,10 @@ def kernel_src_sha():
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+    n = name.replace("void ", "", 1).strip()
+    if n.startswith("(anonymous namespace)::"):   # kernels of an unnamed namespace: keep the identifier, not the empty prefix
+        n = n[len("(anonymous namespace)::"):]
+    return n.split("(")[0].strip()
 
 
 WINDOW = False   # --window: keep only the dispatches BETWEEN the first and the last torch.sign marker (bench.py --pmc-calibrate)
