@@ -158,6 +158,18 @@ int segvlad_describe_end(segvlad_ctx* ctx, const float* tokens, int B, int N, co
                          uint8_t* adj, int n_patch, const int32_t* patch_images, const uint8_t* patch_blocks, float* desc_out, float* y,
                          int l2norm);
 
+/* ---- vocabulary k-means, one Lloyd half-step over a batch of images: the fit that writes c_centers.pt
+ *      (vlad_c_centers_pt_gen.py:86-158 -> utilities.py:749-791 VLAD.fit -> fast_pytorch_kmeans.KMeans(mode='cosine').fit).
+ *      With the CURRENT centres in the context (segvlad_set_vocab): every token is assigned to the centre of largest cosine
+ *      (normalised token against normalised centre, first maximum -- the assignment kernel of segvlad_images), and
+ *        sums [K][D]  fp64 += sum of the NORMALISED tokens assigned to each centre      (DEVICE memory, accumulated into)
+ *        counts [K]   int64 += number of tokens assigned to each centre                 (DEVICE memory, accumulated into)
+ *      so that a caller walks its token set in batches, then sets centre k to sums[k] / counts[k] (centres that lost all their
+ *      tokens keep their value; the means are NOT re-normalised, utilities.py:749-791).  tokens [B][D][N] fp32 as
+ *      segvlad_images takes them; labels_out [B][N] bytes or NULL.  Deterministic (fixed summation order, no atomics on the
+ *      sums).  Round 6: replaces the round-3 recovery of the sums from normalised VLAD descriptors.                              */
+int segvlad_kmeans_step(segvlad_ctx* ctx, const float* tokens, int B, int N, double* sums, int64_t* counts, uint8_t* labels_out);
+
 /* ---- the K-parametric entry: vlad_matmuls_per_cluster(num_c, masks, res, clus_labels, adjMat)
  *      func_vpr.py:1181-1210.  res [N][D] fp32 residuals (token-major, as the reference passes them),
  *      labels [N] u8 (< num_c <= 256), inc_bits [S][ceil(N/64)], adj [S][S] bytes or NULL,

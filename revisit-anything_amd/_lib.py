@@ -43,6 +43,7 @@ SIGNATURES = {
     "segvlad_describe_flags": (C.c_int, [c_ctx_p, C.c_void_p, C.c_void_p]),
     "segvlad_describe_end": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, _f32p, _f32p, C.c_int]),
+    "segvlad_kmeans_step": (C.c_int, [c_ctx_p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "segvlad_cluster_aggregate": (C.c_int, [c_ctx_p, C.c_int, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                              C.c_void_p, _f32p]),
     "segvlad_pca_set": (C.c_int, [c_ctx_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),

@@ -983,6 +983,34 @@ int segvlad_describe(segvlad_ctx* ctx, const uint8_t* masks, int Hm, int Wm, int
   return segvlad_describe_end(ctx, tokens, B, N, inc_bits_out, seg_offsets, adj_out, 0, nullptr, nullptr, desc_out, y, l2norm);
 }
 
+// ---- vocabulary k-means: one Lloyd half-step over a batch of images (utilities.py:749-791, vlad_c_centers_pt_gen.py:86-158) -------
+int segvlad_kmeans_step(segvlad_ctx* ctx, const float* tokens, int B, int N, double* sums, int64_t* counts, uint8_t* labels_out) {
+  CHECK_CTX();
+  CHECK_NO_OPEN_DESCRIBE("kmeans_step");
+  if (ctx->K == 0) return ctx->fail(SEGVLAD_ERR_STATE, "kmeans_step: call segvlad_set_vocab with the current centres first");
+  if (B < 0 || N <= 0) return ctx->fail(SEGVLAD_ERR_ARG, "kmeans_step: B=%d N=%d", B, N);
+  if (B == 0) return SEGVLAD_OK;
+  if (!tokens || !sums || !counts) return ctx->fail(SEGVLAD_ERR_ARG, "kmeans_step: null pointer");
+  const int K = ctx->K, D = ctx->D;
+  void *d_sums, *d_cnt, *d_lab = nullptr;
+  if (!sv_is_device_ptr(sums) || !sv_is_device_ptr(counts))
+    return ctx->fail(SEGVLAD_ERR_ARG, "kmeans_step: sums / counts are accumulated into and must be device memory");
+  d_sums = sums;
+  d_cnt = counts;
+  SV_TRY(assign_phase(ctx, tokens, B, N));   // labels (cosine arg-max against the normalised centres, first maximum), Xt, 1 / ||x||
+  {
+    StageScope sc(ctx, "kmeans");
+    SV_TRY(sv_launch_centroid_sums(ctx, ctx->s_xt.as<float>(), ctx->s_rnorm.as<float>(), ctx->s_labels.as<uint8_t>(), B, N, D, K,
+                                   (double*)d_sums, (int64_t*)d_cnt));
+    sc.count(2);
+  }
+  if (labels_out) {
+    SV_TRY(sv_out(ctx, labels_out, (size_t)B * N, &d_lab));
+    SV_HIP(hipMemcpyAsync(d_lab, ctx->s_labels.p, (size_t)B * N, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return sv_finish(ctx);
+}
+
 // ---- K-parametric aggregation of given residuals + labels (vlad_matmuls_per_cluster) --------------------
 __global__ void fill_ones_kernel(float* p, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;

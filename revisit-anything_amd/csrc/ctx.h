@@ -287,7 +287,7 @@ struct segvlad_ctx {
   X(s_ref_cnt) X(s_ref_id) X(s_qscale) X(s_qf16) X(s_xh1) X(s_xh2) X(s_desc) X(s_tokorder) X(s_laboff) X(s_rnsorted) X(s_ovf)     \
   X(s_fb_q) X(s_fb_d2) X(s_fb_idx) X(s_fb_rows) X(s_rd_rows) X(s_rd_q) X(s_rd_d2) X(s_rd_idx) X(s_rd_flags) X(s_rd_p1) X(s_rd_p2)  \
   X(s_sel_todo) X(s_vote_keys) X(s_pz) X(s_rowbase) X(s_tilegrp) X(s_bn) X(s_l0part) X(s_ref_lim) X(s_sh_d2) X(s_sh_idx)          \
-  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work) X(s_grp_pos) X(s_tnk_redo) X(s_tail_part)
+  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work) X(s_grp_pos) X(s_tnk_redo) X(s_tail_part) X(s_km_part) X(s_km_cnt)
 #define SV_DECL_BUF(n) DevBuf n;
   SV_PERSISTENT_BUFS(SV_DECL_BUF)
   SV_SCRATCH_BUFS(SV_DECL_BUF)
@@ -370,6 +370,10 @@ int sv_launch_aggregate(segvlad_ctx* ctx, const float* xt, const float* rnorm, c
 int sv_launch_token_norms(segvlad_ctx* ctx, const float* xt, const uint64_t* colmask, const float* centres, int K, int D,
                           const int32_t* seg_off_dev, int B, int N, int SC, float* block_norms, float xscale, uint16_t* h1,
                           uint16_t* h2, const int32_t* rowbase, int64_t dummy_row /* a plane row nobody reads */);
+
+// kmeans_kernels.hip: per-cluster sums of the normalised tokens + label counts of a batch, ACCUMULATED into sums / counts
+int sv_launch_centroid_sums(segvlad_ctx* ctx, const float* xt, const float* rnorm, const uint8_t* labels, int B, int N, int D, int K,
+                            double* sums, int64_t* counts);
 
 // gemm_kernels.hip
 int sv_launch_row_sumsq(segvlad_ctx* ctx, const float* X, int64_t n, int d, float* out);

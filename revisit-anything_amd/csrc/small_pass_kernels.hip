@@ -551,7 +551,13 @@ int sv_launch_small_head(segvlad_ctx* ctx, const float* X, int m, int d, const u
   SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(small_head_kernel), lds));
   hipLaunchKernelGGL(small_head_kernel, dim3(nw), dim3(SH_T), lds, ctx->stream, X, m, d, reinterpret_cast<const _Float16*>(Rh), rn, stride, n0,
                      db_scale, rank, reinterpret_cast<_Float16*>(qplane), scales_dev, qn_out, zero, zero_words, cand_scratch,
-                     reinterpret_cast<unsigned long long*>(ctx->s_tail_tick.as<uint32_t>() + 132), thr_out, cand_cnt, getenv("SV_HEAD_TIMING") ? 1 : 0);
+                     reinterpret_cast<unsigned long long*>(ctx->s_tail_tick.as<uint32_t>() + 132), thr_out, cand_cnt,
+#ifdef SV_HEAD_TIMING
+                     1
+#else
+                     0
+#endif
+  );
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }

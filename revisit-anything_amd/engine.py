@@ -432,6 +432,27 @@ class SegVLADEngine:
             res["desc"] = desc
         return res
 
+    def kmeans_step(self, tokens, sums: torch.Tensor, counts: torch.Tensor, want_labels: bool = False):
+        """segvlad_kmeans_step: with the current centres in the context (set_vocab), ACCUMULATES the per-cluster sums of the normalised
+        tokens into ``sums`` [K, D] fp64 and the assignment counts into ``counts`` [K] int64 (device tensors); tokens [B, D, N]."""
+        t = _as(tokens, np.float32, torch.float32)
+        if isinstance(t, torch.Tensor):
+            t = t.contiguous()
+        if t.ndim == 2:
+            t = t[None]
+        B, D, N = t.shape
+        if D != self.D:
+            raise ValueError(f"tokens have D={D}, vocabulary has D={self.D}")
+        if not (isinstance(sums, torch.Tensor) and sums.is_cuda and sums.dtype == torch.float64 and tuple(sums.shape) == (self.K, self.D)
+                and sums.is_contiguous() and isinstance(counts, torch.Tensor) and counts.is_cuda and counts.dtype == torch.int64
+                and tuple(counts.shape) == (self.K,)):
+            raise ValueError("kmeans_step: sums must be a contiguous device fp64 [K, D] tensor, counts a device int64 [K] tensor")
+        lab = self._empty((B, N), torch.uint8) if want_labels else None
+        self._stream()
+        self._check(self.lib.segvlad_kmeans_step(self._h, _ptr(t), B, N, _ptr(sums), _ptr(counts), _ptr(lab)), "kmeans_step")
+        self._keep = [t]
+        return lab
+
     def cluster_aggregate(self, num_c: int, res, labels, inc_bits, adj=None) -> torch.Tensor:
         """vlad_matmuls_per_cluster surface: res [N,D] fp32 residuals, labels [N] (< num_c), inc_bits [S,nw]."""
         r = _as(res, np.float32, torch.float32)

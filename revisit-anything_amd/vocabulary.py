@@ -8,13 +8,17 @@ the raw centre, func_vpr.py:1151), random initial points, ``max_iter=100``, ``to
 fast-pytorch-kmeans 0.2.0.1 is a third-party dependency without source in the reference tree: this restates its
 published algorithm (parity unpinned).
 
-On the device the iteration needs no new kernel.  For one pseudo-segment covering all tokens of an image the VLAD block
-of cluster k is ``V_k = sum_{t in k} (x_t - C_k) = S_k - n_k C_k`` with ``S_k`` the sum of the assigned unit tokens, so
+On the device a half-step is ``segvlad_kmeans_step`` (round 6): the assignment kernel of the VLAD stage + a centroid-update
+kernel of its own (``csrc/kmeans_kernels.hip``: per-cluster sums of the normalised tokens in a fixed order, no atomics on the
+sums, images reduced in fp64).  Rounds 3-5 needed no new kernel: for one pseudo-segment covering all tokens of an image the
+VLAD block of cluster k is ``V_k = sum_{t in k} (x_t - C_k) = S_k - n_k C_k`` with ``S_k`` the sum of the assigned unit tokens, so
 
     mean_k = S_k / n_k = C_k + V_k / n_k                      (new centre = old centre + mean residual)
 
-and ``V_k`` is recovered exactly from the normalised output of ``segvlad_images`` and its block norms
-(``DeviceBackend``).  ``NumpyBackend`` is the plain CPU form; tests/test_vocabulary.py checks the identity."""
+and ``V_k`` is recovered from the normalised output of ``segvlad_images`` and its block norms -- kept as
+``DeviceBackend.step_from_vlad``, a cross-check: exact algebra, but a cluster whose residual sum is tiny against ``n_k C_k``
+(tokens tight around their centre: the converged state) gets its sum back through a cancellation.  ``NumpyBackend`` is the plain
+CPU form; tests/test_vocabulary.py checks the identity."""
 from __future__ import annotations
 
 import random
@@ -90,6 +94,24 @@ class DeviceBackend:
         return torch.nn.functional.normalize(x, dim=1).cpu().numpy()
 
     def step(self, C: np.ndarray):
+        """One half-step through ``segvlad_kmeans_step`` (round 6: the assignment kernel + a centroid-update kernel of its own --
+        per-cluster sums of the normalised tokens in a fixed order, images reduced in fp64; csrc/kmeans_kernels.hip)."""
+        import torch
+
+        K = C.shape[0]
+        self.eng.set_vocab(np.ascontiguousarray(C, dtype=np.float32))
+        sums = torch.zeros(K, self.d, dtype=torch.float64, device=self.eng.device)
+        counts = torch.zeros(K, dtype=torch.int64, device=self.eng.device)
+        labels = []
+        for b0 in range(0, self.B, self.batch):
+            nb = min(self.batch, self.B - b0)
+            labels.append(self.eng.kmeans_step(self.tok[b0:b0 + nb], sums, counts, want_labels=True).reshape(-1).long())
+        return torch.cat(labels).cpu().numpy(), sums.cpu().numpy(), counts.cpu().numpy()
+
+    def step_from_vlad(self, C: np.ndarray):
+        """The round-3 form of the same half-step, kept as a cross-check: the sums recovered from the NORMALISED output of the
+        segment-VLAD kernels (one all-token pseudo-segment per image), S_k = out_k * ||V_k|| * sqrt(#blocks) + n_k C_k.  Exact
+        algebra, but a cluster whose residual sum is tiny against n_k C_k gets its sum back through a cancellation."""
         import torch
 
         K = C.shape[0]

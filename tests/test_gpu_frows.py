@@ -203,6 +203,46 @@ def test_vocabulary_half_step_at_the_reference_shape_against_the_oracle(eng):
     assert np.all(np.linalg.norm(C, axis=1) < 1.0 + 1e-6)
 
 
+def test_kmeans_step_kernel_with_a_converged_and_an_empty_cluster(eng):
+    """segvlad_kmeans_step (round 6, csrc/kmeans_kernels.hip) where the round-3 recovery of the sums from
+    normalised VLAD descriptors is at its weakest: a cluster whose tokens sit ON their centre (||V_k|| << n_k ||C_k||: the
+    converged state), a cluster that gets no token at all, ragged last column chunk (D = 200 is not a multiple of the kernel's
+    chunk), accumulation over two calls, K = 70 > 64 (the narrow assignment kernel).  Against NumPy in fp64: labels and counts bit
+    for bit, sums to 1e-6 RELATIVE per cluster; the old form stays within its 1e-6 per token."""
+    import torch
+
+    from revisit_anything_amd import vocabulary as vq
+
+    K, D, B, N = 70, 200, 5, 333
+    rng = np.random.Generator(np.random.PCG64(77))
+    C = rng.standard_normal((K, D))
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    C *= rng.uniform(0.4, 1.0, (K, 1))                                   # raw centres: means of unit vectors have norm < 1
+    z = rng.integers(0, K - 1, (B, N))                                   # cluster K-1 never drawn ...
+    Cn = C / np.linalg.norm(C, axis=1, keepdims=True)
+    X = Cn[z] + 0.3 * rng.standard_normal((B, N, D)) / np.sqrt(D)
+    tight = z == 3
+    X[tight] = Cn[3] + 1e-5 * rng.standard_normal((int(tight.sum()), D)) / np.sqrt(D)    # ... and cluster 3 sits on its centre
+    X *= rng.uniform(0.5, 3.0, (B, N, 1))                                # un-normalised tokens: the kernel normalises them itself
+    toks = np.ascontiguousarray(X.transpose(0, 2, 1)).astype(np.float32)                 # [B, D, N]
+    db = vq.DeviceBackend(eng, toks, batch=2)
+    nb = vq.NumpyBackend(toks.transpose(0, 2, 1).reshape(B * N, D))
+    ln, sn, cn = nb.step(C.astype(np.float32).astype(np.float64))
+    ld, sd, cd = db.step(C)
+    assert np.array_equal(ld, ln) and np.array_equal(cd, cn) and cd[K - 1] == 0 and cd[3] == int(tight.sum()) > 10
+    for k in range(K):
+        assert np.abs(sd[k] - sn[k]).max() <= 1e-6 * max(np.abs(sn[k]).max(), 1e-30) * max(1, int(cn[k]) ** 0.5), k
+    assert np.all(sd[K - 1] == 0)
+    lv, sv, cv = db.step_from_vlad(C)
+    assert np.array_equal(lv, ln) and np.array_equal(cv, cn) and np.abs(sv - sn).max() < 1e-6 * max(1.0, float(cn.max()))
+    # the entry accumulates: a second pass over the same tokens doubles both outputs
+    sums = torch.from_numpy(sd).to(eng.device)
+    counts = torch.from_numpy(cd).to(eng.device)
+    eng.kmeans_step(torch.from_numpy(toks).to(eng.device), sums, counts)
+    assert np.array_equal(counts.cpu().numpy(), 2 * cn)
+    assert np.abs(sums.cpu().numpy() - 2 * sn).max() < 4e-6 * max(1.0, float(cn.max()) ** 0.5)
+
+
 # ------------------------------------------------------------------------------------------------
 # f1: the experiment loop over stored inputs (place_rec_main.py:244-373)
 # ------------------------------------------------------------------------------------------------
