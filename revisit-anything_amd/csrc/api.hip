@@ -1500,10 +1500,22 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
           SV_TRY(sv_launch_refine2_compact(ctx, rovf_rows, ref_lim, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
                                            ctx->s_cand_id.as<uint32_t>(), m, SV_CAP));
           if (m > 128 && d > 4096) {   // deep rows: a second-tier list as its own union GEMM (parallel over its 128-row tiles)
-            int nl = 0;
-            SV_TRY(sv_launch_refine_grouped(ctx, qp, R, m, d, qn, rn, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP,
-                                            k, out_d2, out_idx, &nl, rovf_rows, (int)h_cnt[1]));
-            sc.count(1 + nl);
+            // In blocks of <= 1024 + 128 query rows: the grouped path's scratch is per ROW of the block it is handed (positions
+            // [rows][8192] u16, keys [rows][2048] u64, ids [rows][2048] u32: 40 KiB per row -- 670 MB for a whole 16 384-row chunk, kept
+            // for the context's life, where a handful of rows are flagged).  Blocks without a flagged row cost four
+            // early-exit launches in a path that is taken once in a blue moon.
+            int nl_sum = 0;
+            for (int r0 = 0; r0 < m;) {
+              int mb = std::min(1024, m - r0);
+              if (m - (r0 + mb) < 129) mb = m - r0;   // (the grouped path wants > 128 rows: the tail joins the last block)
+              int nl = 0;
+              SV_TRY(sv_launch_refine_grouped(ctx, qp + (size_t)r0 * d, R, mb, d, qn + r0, rn, ctx->s_cand_cnt.as<uint32_t>() + r0,
+                                              ctx->s_cand_id.as<uint32_t>() + (size_t)r0 * SV_CAP, SV_CAP, k, out_d2 + (size_t)r0 * k,
+                                              out_idx + (size_t)r0 * k, &nl, rovf_rows + r0, std::min<int>((int)h_cnt[1], mb)));
+              nl_sum += nl;
+              r0 += mb;
+            }
+            sc.count(1 + nl_sum);
           } else {
             SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP,
                                           k, out_d2, out_idx, rovf_rows));

@@ -201,7 +201,21 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
 //  half of the LDS cycles bank conflicts of the transposing 4-byte stores; 128-byte row pieces three tiles ahead: 32-40 ms.)
 typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
 typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
+// The row pieces are requested by inline asm and waited for by a hand-placed s_waitcnt: the compiler takes the destination
+// registers for defined when the asm statement ends, so nothing but today's register allocation keeps it from copying or spilling
+// them between the request and the wait.  That form is therefore tied to the toolchain it was verified on -- ISA
+// inspected, and tests/test_gpu_refine_group.py holds the kernel to the per-row kernels' bits: AMD clang 22 (ROCm 7.2).  Any
+// other compiler gets plain loads, whose waits it places itself (measured slower: it waits for every outstanding load in front
+// of every LDS access behind a conditional load -- but correct by construction).  -DSEGVLAD_RG_PLAIN_LOADS forces that form.
+#if defined(__clang_major__) && __clang_major__ == 22 && !defined(SEGVLAD_RG_PLAIN_LOADS)
+#define RG_ASM_LOADS 1
 #define RG_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define RG_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define RG_ASM_LOADS 0
+#define RG_GLOAD(dst, ptr) (dst) = *reinterpret_cast<const rg_f32x4*>(ptr)
+#define RG_WAIT_LOADS() do { } while (0)
+#endif
 constexpr int RG_KS = 32;
 
 template <int MT, int KS>
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256) void refine_group_gemm_kernel(const float* __r
   const float* b_frag = tile + (32 * MT + 32 * w + i) * LDR + 4 * kk;
   const int nst = d / KS;
   gload(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RG_WAIT_LOADS();
   sstore();
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
@@ -293,7 +307,7 @@ __global__ __launch_bounds__(256) void refine_group_gemm_kernel(const float* __r
     }
     __syncthreads();   // every wave is done with the LDS image
     if (st + 1 < nst) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RG_WAIT_LOADS();
       sstore();
       __syncthreads();
     }
