@@ -2807,8 +2807,12 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
 #define RTICK()
 #endif
   RTICK();
-  const int64_t row = blockIdx.x / parts;
-  const int base = (int)(blockIdx.x % parts) * ROWS;
+  // part-major: the first workgroups of the grid are part 0 of EVERY list, then part 1, ... -- the parts that hold rows (a band of ~270
+  // rows: parts 0-8 of 16) are all resident in the first round of workgroups, the empty ones come last and leave at once.  Row-major
+  // (rounds 3-5) put all 16 parts of lists 0-31 into the 512 resident slots and made lists 32-49 wait for them (round 6: 40 -> 33 us).
+  const int nlists = (int)(gridDim.x / parts);
+  const int64_t row = blockIdx.x % nlists;
+  const int base = (int)(blockIdx.x / nlists) * ROWS;
   // the list's length and this workgroup's slice of it are requested together (the slice lies inside the list's rcap slots
   // whatever the length; entries beyond it are not looked at)
   const uint32_t idv = tid < ROWS ? ref_id[row * rcap + base + tid] : 0u;
