@@ -990,13 +990,18 @@ def shard_sim(a, W):
     kv = 50
 
     eng.hint_query_groups(q_off_all)   # (what ShardedSegmentIndex.retrieve tells the engine: an image's rows as one refinement group)
+    for kv_ in a.set:
+        eng.set_option(*kv_.split("=", 1))
+    # the other ranks' lists: this rank's own, with ids moved into their shards (distinct ids, same merge work).  Three torch
+    # kernels stand for the unpack of the gathered records (sharded.unpack_topk_records: two copies) -- round 5 built the lists with
+    # ten (a `cat` of W shifted copies), 0.2 ms of emulation glue inside the figure
+    id_shift = (torch.arange(W, device=dev, dtype=torch.int64) * (nR_l * S)).repeat_interleave(kv)[None, :]
 
     def rank_step():
         pipe.describe(q_tok, q_msk, q_off_l)                                     # this rank's slice of the query images
         d2, idx = eng.search(qd_all, kv)                                         # all query segments against the shard
-        # the other ranks' lists: this rank's own, with ids moved into their shards (distinct ids, same merge work)
         d2c = d2.repeat(1, W)
-        idc = torch.cat([idx + r * (nR_l * S) for r in range(W)], dim=1)
+        idc = idx.repeat(1, W) + id_shift
         md, mi = eng.merge_topk(d2c, idc, W, kv)
         sims, m = eng.sims_from_d2(md, mi, kv)
         return eng.vote(m, sims, q_off_all, n_top=5, img_of_seg=img_of_seg)

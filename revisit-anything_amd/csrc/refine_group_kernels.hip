@@ -146,13 +146,16 @@ __global__ __launch_bounds__(RG_UT) void refine_union_kernel(const uint32_t* __r
       rg_bitonic<uint32_t, RG_UT>(uniq, np2, tid);
       for (int j = tid; j < U; j += RG_UT) grp_ids[(size_t)b * ucap + j] = uniq[j];
     }
-    // Is the union cheaper?  Measured on MI355X (ns, d = 1024; the first two terms grow with d): the per-row kernels ~0.46 per
-    // (query, row) pair of the bands; the union GEMM ~0.038 per slot of its 64 x 128 tiles, whatever their fill; the per-query
+    // Is the union cheaper?  Measured on MI355X (ns, d = 1024; the first two terms grow with d): the per-row kernels ~0.39 per
+    // (query, row) pair of the bands + 21 per query row; the union GEMM ~0.038 per slot of its 64 x 128 tiles, whatever their fill; the per-query
     // sort of a band's keys ~0.022 per slot of its power-of-two list (~1.5 slots per band entry).  (200-deep bands of an image's 50 segments on a 1 M-row index:
     // 10 900 pairs against 938 union rows -> grouped; the same image 50 deep on a 125 k-row shard: 2 500 pairs -> row by row.)
     const float dd = (float)d * (1.f / 1024.f);
     const float cost_grp = (float)((U + 127) >> 7) * 8192.f * 0.038f * dd + 1.5f * (float)total * 0.022f;
-    const float cost_row = (float)total * 0.46f * dd;
+    // (round 6: the per-row kernels re-fitted on two band depths -- 10 000 rows x 270-row bands 1.26 ms, x 62-row bands (50-deep
+    //  searches of a 125 k-row shard) 0.45 ms: 0.39 ns per pair + 21 ns per query row, not 0.46 ns per pair.  With the old constant
+    //  the shard's groups were split between the two paths and paid both: select + refine 0.68 ms, 0.62 all per row, 0.48 all grouped.)
+    const float cost_row = (float)total * 0.39f * dd + (float)nrows * 21.f;
     grouped = U <= ucap && (force || cost_grp < cost_row);
     if (grouped) {
       // where each band entry sits in the union: the per-query select then sorts a query's OWN band (<= rcap keys), not the union

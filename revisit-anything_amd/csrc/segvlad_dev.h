@@ -32,8 +32,9 @@
  *     "x3_tile", "x3_gm", "agg_kpb", "assign_narrow"   tile / order / geometry of the projection GEMM, the descriptor
  *                     aggregation and the assignment kernel
  *   single-image passes (small_pass_kernels.hip)
- *     "small_head"    1 | 0   the pass starts with small_head_kernel: plane, scale, norms, flags and the sample thresholds (from the
- *                     filter's own fp16 product) in one launch | query preparation -> exact fp32 sample level -> reduce + rank
+ *     "small_head"    1 | 0 | 3   the pass starts with small_head_kernel: plane, scale, norms, flags and the sample thresholds (from the
+ *                     filter's own fp16 product) in one launch | query preparation -> exact fp32 sample level -> reduce + rank |
+ *                     the same kernel with the query block loaded straight in MFMA fragment shape (measured slower: 22.7 vs 21 us)
  *     "small_tail"    1 | 0   the pass ends in small_tail_kernel, which reads the overflow counters on the DEVICE and finishes
  *                     flagged rows there (no read-back, no host synchronisation in segvlad_search) | the read-back of rounds 3-5
  *   debugging and the tests' own hooks

@@ -283,6 +283,12 @@ constexpr int SH_MT = 8;                      // 16-row query tiles (m <= 128)
 constexpr int SH_PER = 2;                     // merge: workgroup minima per lane (<= 128 workgroups: a sample of <= 4096 rows)
 constexpr int SH_PRE = 4;                     // k-steps whose database fragments are requested before anything else
 
+// FR: 0 = the query block staged through LDS (any shape sv_small_head_ok admits); 1, 2, 4, 8 = the number of 16-row query tiles, padded
+// to a power of two, of the FRAGMENT-DIRECT form (round 6, second version): the k-steps are split over the waves (wave v takes k-steps v,
+// v + 8, ...), so the slices of the query block the waves multiply are DISJOINT -- every wave loads its own slice straight in MFMA
+// fragment shape (lane (i, kq): 8 consecutive floats of row 16 t + i), converts it in registers and multiplies; no LDS image of the
+// operand, no index arithmetic per element, no barrier between load and product (needs FR x ceil(d / 256) <= 16 fragments per lane).
+template <int FR>
 __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restrict__ X, int m, int d, const _Float16* __restrict__ Rh,
                                                           const float* __restrict__ rn, int64_t stride, int n0, float db_scale, int rank,
                                                           _Float16* __restrict__ qplane, float* __restrict__ scales,
@@ -321,6 +327,14 @@ __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restric
       bpre[s_][1] = *reinterpret_cast<const sh_f16x8*>(rb + ks * 32);
     }
   }
+  sh_f32x4 acc[SH_MT][2];
+#pragma unroll
+  for (int t = 0; t < SH_MT; ++t) {
+    acc[t][0] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float inv_scale = 1.f;
+  if constexpr (FR == 0) {
   // (1) the whole query block into registers, max |x| on the way
   float4 xv[SH_NX];
   uint32_t mx = 0;
@@ -351,7 +365,7 @@ __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restric
       scale = ldexpf(1.f, 14 - e);
     }
   }
-  const float inv_scale = 1.f / (scale * db_scale);
+  inv_scale = 1.f / (scale * db_scale);
   if (w == 0 && tid == 0) {
     scales[0] = scale;
     scales[1] = inv_scale;
@@ -385,12 +399,6 @@ __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restric
   __syncthreads();
   TICK();
   // (3) this wave's k-steps of the [mpad x 32] product
-  sh_f32x4 acc[SH_MT][2];
-#pragma unroll
-  for (int t = 0; t < SH_MT; ++t) {
-    acc[t][0] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[t][1] = sh_f32x4{0.f, 0.f, 0.f, 0.f};
-  }
   auto kstep = [&](int ks, const sh_f16x8& b0, const sh_f16x8& b1) {
 #pragma unroll
     for (int t = 0; t < SH_MT; ++t)
@@ -407,6 +415,87 @@ __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restric
   }
   for (int ks = wv + SH_W * SH_PRE; ks < nks; ks += SH_W)
     kstep(ks, *reinterpret_cast<const sh_f16x8*>(ra + ks * 32), *reinterpret_cast<const sh_f16x8*>(rb + ks * 32));
+  } else {
+    // ---- fragment-direct: this wave's slice of the query block in MFMA A-fragment shape ----------------------------------------------
+    constexpr int FRC = FR > 0 ? FR : 1, STEPS = 16 / FRC;
+    const int steps_v = wv < nks ? (nks - wv + SH_W - 1) / SH_W : 0;   // k-steps wv, wv + 8, ... of this wave (<= STEPS: the launcher checks)
+    float4 xf[FRC][STEPS][2];
+    uint32_t mx = 0;
+#pragma unroll
+    for (int t = 0; t < FRC; ++t) {
+      const int row = t * 16 + i16;
+      const float* xr = X + (size_t)min(row, m - 1) * d + kq * 8;
+#pragma unroll
+      for (int s_ = 0; s_ < STEPS; ++s_)
+        if (s_ < steps_v) {
+          xf[t][s_][0] = *reinterpret_cast<const float4*>(xr + (wv + SH_W * s_) * 32);
+          xf[t][s_][1] = *reinterpret_cast<const float4*>(xr + (wv + SH_W * s_) * 32 + 4);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < FRC; ++t)
+#pragma unroll
+      for (int s_ = 0; s_ < STEPS; ++s_)
+        if (s_ < steps_v) {
+          if (t * 16 + i16 >= m) xf[t][s_][0] = xf[t][s_][1] = make_float4(0.f, 0.f, 0.f, 0.f);   // pad rows of the last tile
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            mx = max(max(mx, __float_as_uint(xf[t][s_][h].x) & 0x7fffffffu), max(__float_as_uint(xf[t][s_][h].y) & 0x7fffffffu, __float_as_uint(xf[t][s_][h].z) & 0x7fffffffu));
+            mx = max(mx, __float_as_uint(xf[t][s_][h].w) & 0x7fffffffu);
+          }
+        }
+    mx = wave_max_u32_(mx);
+    if (lane == 0) s_wmax[wv] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < SH_W; ++v) mx = max(mx, s_wmax[v]);
+    float scale = 1.f;
+    {
+      const float maxabs = __uint_as_float(mx);
+      if (maxabs > 0.f && isfinite(maxabs)) {
+        int e;
+        frexpf(maxabs, &e);
+        scale = ldexpf(1.f, 14 - e);
+      }
+    }
+    inv_scale = 1.f / (scale * db_scale);
+    if (w == 0 && tid == 0) {
+      scales[0] = scale;
+      scales[1] = inv_scale;
+    }
+    if (w == (1 % NW))
+      for (int j = tid; j < zero_words; j += SH_T) zero[j] = 0u;
+#pragma unroll
+    for (int s_ = 0; s_ < STEPS; ++s_)
+      if (s_ < steps_v) {
+        const int ks = wv + SH_W * s_;
+        sh_f16x8 b0, b1;
+        if (s_ < SH_PRE) {
+          b0 = bpre[s_ < SH_PRE ? s_ : 0][0];
+          b1 = bpre[s_ < SH_PRE ? s_ : 0][1];
+        } else {
+          b0 = *reinterpret_cast<const sh_f16x8*>(ra + ks * 32);
+          b1 = *reinterpret_cast<const sh_f16x8*>(rb + ks * 32);
+        }
+#pragma unroll
+        for (int t = 0; t < FRC; ++t) {
+          sh_f16x8 a;
+          a[0] = (_Float16)(xf[t][s_][0].x * scale);
+          a[1] = (_Float16)(xf[t][s_][0].y * scale);
+          a[2] = (_Float16)(xf[t][s_][0].z * scale);
+          a[3] = (_Float16)(xf[t][s_][0].w * scale);
+          a[4] = (_Float16)(xf[t][s_][1].x * scale);
+          a[5] = (_Float16)(xf[t][s_][1].y * scale);
+          a[6] = (_Float16)(xf[t][s_][1].z * scale);
+          a[7] = (_Float16)(xf[t][s_][1].w * scale);
+          // every workgroup writes its share of the plane the filter will read: fragment (wave, tile, step) by workgroup (...) % NW
+          const int row = t * 16 + i16;
+          if (row < m && ((wv * 16 + t * STEPS + s_) % NW) == w) *reinterpret_cast<sh_f16x8*>(qplane + (size_t)row * d + ks * 32 + kq * 8) = a;
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc[t][1], 0, 0, 0);
+        }
+      }
+  }
   __syncthreads();   // everybody is done with the operand: its LDS becomes the reduction block
   TICK();
   // (4) the waves' partial products -> LDS -> v = ||r||^2 - 2 q.r / (s_q s_db) per (query, column)
@@ -546,10 +635,19 @@ int sv_launch_small_head(segvlad_ctx* ctx, const float* X, int m, int d, const u
   SV_TRY(sv_small_words(ctx));
   const int nw = (n0 + SH_RW - 1) / SH_RW, mpad = (m + 15) & ~15;
   const size_t lds_a = (size_t)mpad * (d + 8) * 2, lds_r = ((size_t)SH_W * SH_MT * 2 * 256 + (size_t)mpad * SH_RW) * 4;
-  const size_t lds = lds_a > lds_r ? lds_a : lds_r;
+  // fragment-direct form when a lane's slice of the query block fits 16 fragments (FR tiles x ceil(d / 256) k-steps per wave)
+  int fr = 1;
+  while (fr * 16 < mpad) fr <<= 1;
+  const int steps = ((d >> 5) + SH_W - 1) / SH_W;
+  // (measured, m = 50, d = 1024, 1 M rows: the fragment-direct form 22.7 us against 20.8-21.4 us for the LDS-staged one -- its loads are
+  //  16 rows x 32 B per quarter wave instead of whole lines, which costs what the LDS stage and its barrier saved: option
+  //  small_head = 3 selects it, the default stays the staged form)
+  const bool frag = fr * steps <= 16 && ctx->opt.small_head == 3;
+  const size_t lds = frag ? lds_r : (lds_a > lds_r ? lds_a : lds_r);
   if (lds > 160 * 1024) return ctx->fail(SEGVLAD_ERR_LIMIT, "small head: %zu bytes of LDS", lds);
-  SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(small_head_kernel), lds));
-  hipLaunchKernelGGL(small_head_kernel, dim3(nw), dim3(SH_T), lds, ctx->stream, X, m, d, reinterpret_cast<const _Float16*>(Rh), rn, stride, n0,
+  auto kern = !frag ? small_head_kernel<0> : fr == 1 ? small_head_kernel<1> : fr == 2 ? small_head_kernel<2> : fr == 4 ? small_head_kernel<4> : small_head_kernel<8>;
+  SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), lds));
+  hipLaunchKernelGGL(kern, dim3(nw), dim3(SH_T), lds, ctx->stream, X, m, d, reinterpret_cast<const _Float16*>(Rh), rn, stride, n0,
                      db_scale, rank, reinterpret_cast<_Float16*>(qplane), scales_dev, qn_out, zero, zero_words, cand_scratch,
                      reinterpret_cast<unsigned long long*>(ctx->s_tail_tick.as<uint32_t>() + 132), thr_out, cand_cnt,
 #ifdef SV_HEAD_TIMING

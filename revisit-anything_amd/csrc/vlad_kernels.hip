@@ -606,7 +606,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restrict__ T, int N, int D, int K,
                                                           const float* __restrict__ bt, float* __restrict__ Xt,
                                                           uint8_t* __restrict__ labels, float* __restrict__ rnorm,
-                                                          float* __restrict__ gap) {
+                                                          float* __restrict__ gap, int B) {
   // LDS tile [d][token], row stride 128 floats, row d ROTATED by rot(d) = 8 (d >> 2) + 32 (d & 1) tokens: the MFMA A
   // operand reads two rows d, d+1 per instruction (their rotations differ by 32 banks: disjoint), the transposed gather
   // that writes Xt reads (4 c4 + e, tok) for 8 values of c4 and 8 consecutive tokens (banks tok + 8 c4: all 64 distinct),
@@ -616,7 +616,16 @@ __global__ __launch_bounds__(256) void assign_wide_kernel(const float* __restric
   auto rot = [](int d) { return 8 * (d >> 2) + 32 * (d & 1); };
   __shared__ __attribute__((aligned(16))) float tile[2 * DC * TS + 128];   // also [128][NT*32+1] scores at the end (NT <= 2)
   __shared__ float ssum[128];
-  const int b = blockIdx.y, t0 = blockIdx.x * 128;
+  // XCD-aware order (round 6): the workgroups are dealt to the eight XCDs round-robin by their linear id, so with (tile, image) read
+  // straight off the grid the 12 token tiles of an image ran on 8 different XCDs -- and a token tile's 512-byte piece of a D-row
+  // shares its first and last 128-byte line with its neighbours (rows of N = 1530 floats are not line aligned): every boundary line
+  // crossed the fabric into two L2s, 2.36 GB fetched for 1.88 GB of tokens (rocprofv3 FETCH_SIZE, profiles/r06_pmc_traffic.json).
+  // Consecutive LOGICAL tiles now share an XCD: logical id = (linear id % 8) * per + linear id / 8.
+  const int gx = (N + 127) / 128;
+  const int per = (int)((gridDim.x + 7) / 8);
+  const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (logical >= gx * B) return;
+  const int b = logical / gx, t0 = (logical - b * gx) * 128;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kk = l >> 5;
   const float* Tb = T + (size_t)b * D * N;
   const int lr = tid >> 5, lq = tid & 31;        // loader: rows lr + 8 j, tokens t0 + 4 lq .. + 3
@@ -705,11 +714,14 @@ int sv_launch_assign(segvlad_ctx* ctx, const float* tokens, int B, int N, float*
   dim3 grid((N + 63) / 64, B), block(256);
   const float* bt = ctx->vocab_bt.as<float>();
   if (NT <= 2 && ctx->D % 32 == 0 && !ctx->opt.assign_narrow) {
-    dim3 gridw((N + 127) / 128, B);
+    // 1-D grid of (tiles x images) rounded up to a multiple of 8 (the kernel maps its linear id to a (tile, image) pair itself:
+    // XCD-aware order)
+    const unsigned tiles_total = (unsigned)((N + 127) / 128) * (unsigned)B;
+    dim3 gridw((tiles_total + 7) / 8 * 8, 1);
     if (NT == 1)
-      hipLaunchKernelGGL(assign_wide_kernel<1>, gridw, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      hipLaunchKernelGGL(assign_wide_kernel<1>, gridw, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap, B);
     else
-      hipLaunchKernelGGL(assign_wide_kernel<2>, gridw, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap);
+      hipLaunchKernelGGL(assign_wide_kernel<2>, gridw, block, 0, ctx->stream, tokens, N, ctx->D, ctx->K, bt, xt, labels, rnorm, gap, B);
     SV_HIP(hipGetLastError());
     return SEGVLAD_OK;
   }
