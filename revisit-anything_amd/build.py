@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsegvlad_hip.so")
 SOURCES = ["api.hip", "vlad_kernels.hip", "gemm_kernels.hip", "select_kernels.hip", "vote_kernels.hip",
-           "knn_bf16_kernels.hip", "gemm_f16x3_kernels.hip", "project_kernels.hip", "comm.hip", "refine_group_kernels.hip", "small_pass_kernels.hip", "kmeans_kernels.hip"]
+           "knn_filter_kernels.hip", "gemm_f16x3_kernels.hip", "project_kernels.hip", "comm.hip", "refine_group_kernels.hip", "small_pass_kernels.hip", "kmeans_kernels.hip"]
 
 
 def _hipcc() -> str:

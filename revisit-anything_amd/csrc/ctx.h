@@ -404,7 +404,7 @@ int sv_launch_l2_filter(segvlad_ctx* ctx, const float* Q, const float* R, int M,
                         const float* rn, int b_stride, const float* thr, int64_t thr_ld, uint32_t* cand_cnt,
                         float* cand_d2, uint32_t* cand_id, int cap);
 
-// knn_bf16_kernels.hip
+// knn_filter_kernels.hip
 int sv_launch_split_bf16(segvlad_ctx* ctx, const float* X, int64_t n_elems, uint16_t* hi, uint16_t* lo);
 int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Ql, const uint16_t* Rh, const uint16_t* Rl,
                           int M, int n_sample, int d, int b_stride, const float* qn, const float* rn, const float* thr,

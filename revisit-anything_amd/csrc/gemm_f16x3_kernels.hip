@@ -12,7 +12,7 @@
 //   split_f16x2_kernel   (X - sub) * scale -> h1, h2 planes in the blocked layout of ctx.h (sv_x3_off); sub = PCA mean on
 //                        the A side, none on the W side
 //   gemm_f16x3_kernel    C = (A1+A2).(B1+B2)^T * col_scale: BM x BN x 32 tiles, global->LDS DMA with source-side
-//                        swizzle (see knn_bf16_kernels.hip), two stages per operand, optional split-K
+//                        swizzle (see knn_filter_kernels.hip), two stages per operand, optional split-K
 #include <stdlib.h>
 
 #include "ctx.h"

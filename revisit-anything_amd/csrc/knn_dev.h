@@ -1,6 +1,6 @@
-// Device helpers shared by the kNN translation units (knn_bf16_kernels.hip, small_pass_kernels.hip): the order-preserving
+// Device helpers shared by the kNN translation units (knn_filter_kernels.hip, small_pass_kernels.hip): the order-preserving
 // float <-> key map, the workgroup bitonic sort of (key << 32 | id) words, DPP wave reductions.  Moved out of
-// knn_bf16_kernels.hip in round 6, unchanged.
+// knn_filter_kernels.hip in round 6, unchanged.
 #pragma once
 #include <stdint.h>
 

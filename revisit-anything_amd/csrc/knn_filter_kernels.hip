@@ -1,4 +1,6 @@
-// Exact kNN, large-database path: bf16x3 MFMA filter + exact fp32 refinement (gfx950).
+// Exact kNN, large-database path: 16-bit MFMA candidate FILTERS + exact fp32 refinement (gfx950).
+// (This file was knn_bf16_kernels.hip until round 6: it started as the bf16x3 filter below; the default filter since round 2 is the
+//  single-product fp16 kernel knn_f16_filter_kernel further down, the bf16x3 form serves d % 64 != 0.)
 //
 // fp32 MFMA runs at 1/16 of the bf16 rate on CDNA4.  Every fp32 value is split into two bf16 pieces
 // x = hi + lo + e, |e| <= 2^-16 |x|, and the filter GEMM accumulates hi.hi + hi.lo + lo.hi on

@@ -10,7 +10,7 @@
  * SEGVLAD_LIB_PATH) holds every measured-and-not-kept variant (DESIGN.md 4 / 7.1 has the measurements), the timing ablations
  * with WRONG results (f16_cfg 10 .. 160, SEGVLAD_ASSIGN_ABL, SEGVLAD_AGG_ABL) and the phase timers.
  *
- *   fp16 candidate filter of the exact kNN (knn_bf16_kernels.hip)                                shipped library accepts
+ *   fp16 candidate filter of the exact kNN (knn_filter_kernels.hip)                                shipped library accepts
  *     "f16_cfg"       tile configuration; -1 = from the shape: 250 batches, 300 deep rows (d >= 4096), 62 / 63 one query
  *                     image per pass                                                             -1, 250, 300, 62, 63
  *     "f16_mf"        MFMA shape of the batch kernels: 0 = 32 x 32 x 16, else 16 x 16 x 32       -1, 1

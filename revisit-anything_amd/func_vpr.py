@@ -256,6 +256,13 @@ def normalizeFeat(rfts):
     return out.astype(a.dtype if a.dtype in (np.float32, np.float64) else np.float64)
 
 
+def _normalizeFeat_device(rfts):
+    """normalizeFeat's rows left ON THE DEVICE (a torch fp32 tensor): for callers inside this package that hand them straight
+    to the index (place_rec.recall_segloc) -- the rows then cross PCIe once, not three times (up, down, up again)."""
+    a = np.array(rfts).reshape([len(rfts), -1])
+    return engine().normalize_rows(np.ascontiguousarray(a, dtype=np.float32))
+
+
 # --------------------------------------------------------------------------------------------------
 # a12  image vote
 # --------------------------------------------------------------------------------------------------

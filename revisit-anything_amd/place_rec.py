@@ -59,8 +59,11 @@ def recall_segloc(workdir, dataset_name, experiment_config, experiment_name, seg
     Q = _to_numpy(segFtVLAD2)
     index = IndexFlatL2(R.shape[1])
     if experiment_config["pca"]:
-        index.add(func_vpr.normalizeFeat(R))
-        sims, matches = index.search(func_vpr.normalizeFeat(Q), 200)
+        # (the reference's normalizeFeat returns host arrays that index.add / search upload again -- place_rec_main.py:53-55; here the
+        #  normalised rows stay on the device between the two steps: one PCIe crossing for a 1 M x 1024 database instead of three.
+        #  Same kernel, same bits as func_vpr.normalizeFeat)
+        index.add(func_vpr._normalizeFeat_device(R))
+        sims, matches = index.search(func_vpr._normalizeFeat_device(Q), 200)
     else:
         index.add(R)
         sims, matches = index.search(Q, 200)

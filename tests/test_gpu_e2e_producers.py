@@ -69,3 +69,73 @@ def test_producers_feed_the_hip_pipeline_and_match_the_oracle():
     d2, idx = O.knn_l2(ref[:n_ref].astype(np.float32), ref[n_ref:].astype(np.float32), min(20, n_ref))
     assert np.array_equal(m_.cpu().numpy()[:, 0], idx[:, 0])
     assert int(pred[0, 0]) == 2            # the perturbed copy of image 2 retrieves image 2
+
+
+def test_full_size_producers_feed_the_hip_pipeline_and_match_the_oracle():
+    """BASELINE configs[2] AT FULL SIZE under `-m gpu` (VERDICT r05 missing #3): DINOv2 ViT-g/14, layer-31 value facet (D = 1536:
+    utilities.py:219-288, place_rec_SAM_DINO.py:104-142) and SAM ViT-H automatic masks at half resolution (place_rec_SAM_DINO.py:51-63)
+    on 640 x 480 images -- the published geometry with RANDOM-INITIALISED weights (the checkpoints are not in this image: what is
+    checked is the plumbing and the HIP path on the producers' real-shaped output, not Recall) -- through the K = 64 describe stage
+    (order 3 neighbourhoods, PCA off) against the oracle on the very same tokens and masks, then index + retrieval of a perturbed copy."""
+    import torch
+
+    from oracle import segvlad_oracle as O
+    from revisit_anything_amd import producers as pr, synth
+    from revisit_anything_amd.engine import SegVLADEngine
+    from revisit_anything_amd.pipeline import SegVLADPipeline
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    dino = pr.DinoV2ValueFacet.from_config("giant", layer=31, device=dev)
+    sam = pr.SamAutoMasks.from_config("huge", device=dev, points_per_side=16, pred_iou_thresh=-1.0, stability_score_thresh=0.0,
+                                      box_nms_thresh=1.01)
+    with torch.no_grad():   # (a random SAM's default initialiser gives ~0 outputs everywhere)
+        for p in sam.model.parameters():
+            if p.ndim >= 2:
+                p.normal_(0.0, 0.02)
+    H, W, K, S = 480, 640, 64, 50
+    D = dino.model.config.hidden_size
+    assert D == 1536
+    cfg = {"rmin": 0, "desired_width": W, "desired_height": H, "resize": True}
+    rng = np.random.Generator(np.random.PCG64(11))
+    imgs = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(2)]
+    imgs.append(np.clip(imgs[1].astype(np.int16) + rng.integers(-6, 7, (H, W, 3)), 0, 255).astype(np.uint8))   # query ~ image 1
+    toks, masks = [], []
+    for im in imgs:
+        tk = pr.image_to_tokens(np.ascontiguousarray(im[:, :, ::-1]), dino, cfg)
+        segs, _ = pr.masks_given_image(sam, im, cfg)
+        assert tuple(tk.shape) == (1, D, 34, 45) and len(segs) >= 4 and segs[0].shape == (H // 2, W // 2)
+        toks.append(tk.reshape(D, -1).float().cpu().numpy())
+        masks.append(np.stack(segs[:S]).astype(np.uint8))
+    C = synth.make_vocab(K, D, seed=1000)
+    eng = SegVLADEngine(0)
+    eng.set_vocab(C)
+    offs = np.concatenate([[0], np.cumsum([m.shape[0] for m in masks])]).astype(np.int32)
+    order = 3
+    ref = []
+    for tk, m in zip(toks, masks):
+        mb = m.astype(bool)
+        try:
+            adj = O.nbr_masks_agg_fast_single([x for x in mb], order)
+        except Exception:        # Qhull refuses degenerate centroid sets (a random network's masks can coincide): the reference fails too
+            order = 0
+            break
+    pipe = SegVLADPipeline(eng, H, W, 14, order=order, use_pca=False)
+    desc = pipe.describe(torch.from_numpy(np.stack(toks)).to(dev), torch.from_numpy(np.concatenate(masks)).to(dev), offs).cpu().numpy()
+    for tk, m in zip(toks, masks):
+        mb = m.astype(bool)
+        adj = O.nbr_masks_agg_fast_single([x for x in mb], order) if order else None
+        ref.append(O.seg_vlad_from_masks(tk, mb, C, H, W, adj))
+    ref = np.concatenate(ref)
+    assert desc.shape == (int(offs[-1]), K * D)
+    cos = (desc * ref).sum(1) / np.maximum(np.linalg.norm(desc, axis=1) * np.linalg.norm(ref, axis=1), 1e-30)
+    assert np.abs(desc - ref).max() < 2e-6 and cos.min() > 1 - 1e-6
+    n_ref = int(offs[2])
+    eng.db_add(desc[:n_ref], np.repeat(np.arange(2, dtype=np.int32), np.diff(offs[:3])))
+    q = desc[n_ref:]
+    kk = min(20, n_ref)
+    pred, _, m_, _ = pipe.retrieve(torch.from_numpy(q).to(dev), np.array([0, len(q)], np.int32), k_search=kk, k_vote=min(10, n_ref), n_top=2)
+    d2, idx = O.knn_l2(ref[:n_ref].astype(np.float32), ref[n_ref:].astype(np.float32), kk)
+    assert np.array_equal(m_.cpu().numpy()[:, 0], idx[:, 0])
+    assert int(pred[0, 0]) == 1            # the perturbed copy of image 1 retrieves image 1
+    eng.close()
