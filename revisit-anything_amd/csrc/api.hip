@@ -319,6 +319,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "small_plan")) return as_int(&o.small_plan);
   if (!strcmp(key, "small_tail")) return as_int(&o.small_tail);
   if (!strcmp(key, "small_head")) return as_int(&o.small_head);
+  if (!strcmp(key, "batch_l0_f16")) return as_int(&o.batch_l0_f16);
   if (!strcmp(key, "debug_small_tail")) return as_int(&o.debug_small_tail);
   if (!strcmp(key, "refine_group")) return as_int(&o.refine_group);
   if (!strcmp(key, "query_group")) return as_int(&o.query_group);
@@ -1383,6 +1384,12 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
           sc.count();
           l0_fused = true;
         }
+      } else if (heuristic && pl.kind == 1 && m > 128 && n0 <= 4096 && q16a && ctx->opt.batch_l0_f16 && !ctx->f16_scale_dev) {
+        // round 6: a guessed threshold needs no exact distances -- the sample through the filter's own fp16 product (~15 us instead
+        // of 115-160 us of poorly filled fp32 MFMA tiles); the thresholds are then approximate-domain values like every later level's
+        SV_TRY(sv_launch_sample_f16_batch(ctx, q16a, ctx->db_f16.as<uint16_t>(), m, (int)n0, d, pl.stride0, pl.inv_scale, qn, rn,
+                                          ctx->s_dist.as<float>(), ld0));
+        sc.count();
       } else {
         SV_TRY(sv_launch_l2_strided(ctx, qp, R, ctx->s_dist.as<float>(), m, (int)n0, d, ld0, qn, rn, (int)pl.stride0, true));
         sc.count();
@@ -1827,7 +1834,11 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
         // the exact sample level of the first chunk goes out BEFORE the host waits for the two scalars: it needs neither the
         // query plane nor the margin they fix, and the device runs it while the host round trip is under way (round 5; the
         // wait used to leave the device idle in front of every batch search)
-        if (heuristic_pre && nq > 128 && ctx->opt.debug_search == 0) {
+        // (not when the sampled level runs on the fp16 product -- batch_l0_f16: that needs the query plane the scalars fix; it is
+        //  ten times cheaper than the exact GEMM it replaces, which is worth more than hiding that GEMM under the host's wait)
+        const int64_t n0_pre = (n + plh_pre.stride0 - 1) / plh_pre.stride0;
+        const bool l0_f16 = ctx->opt.batch_l0_f16 && n0_pre <= 4096;
+        if (heuristic_pre && nq > 128 && ctx->opt.debug_search == 0 && !l0_f16) {
           SV_TRY(reserve_scratch());
           SV_TRY(levels_chunk(ctx, plh_pre, true, (const float*)dq, nullptr, nullptr, qn, std::min(nq, SV_CHUNK), nullptr, nullptr,
                               ctx->s_ovf.as<uint32_t>(), ctx->s_ovf.as<uint32_t>() + nq, nullptr, nullptr, nullptr, 1));

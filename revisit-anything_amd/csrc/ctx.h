@@ -163,6 +163,8 @@ struct SvOptions {
                           //    outstanding memory operation at every step (verification of its counted waits: same bits)
   int debug_small_tail = 0;   // tests only: bit 0 = every row of a device-driven pass is flagged for the tail's brute force, bit 1 = every
                               // row's band is sent to its second tier, bit 2 = the hand-over's sticky failure word is raised
+  int batch_l0_f16 = 1;   // batch searches on the fp16 filter with guessed thresholds: the sampled level from the filter's own fp16 product
+                          // (sample_f16_batch_kernel) instead of the exact fp32 GEMM; 0 = rounds 2-5
   int small_head = 1;     // single-image passes start with small_head_kernel (plane + scale + norms + flags + sample thresholds in one
                           // launch); 0 = query preparation -> exact sample level -> reduce + rank (rounds 3-5)
   int small_tail = 1;     // single-image passes end in small_tail_kernel (no read-back); 0 = the read-back of rounds 3-5
@@ -447,6 +449,9 @@ int sv_ensure_pinned_words(segvlad_ctx* ctx);
 // product) of query q to the n0 sample rows 0, stride, 2 stride, ... of the fp16 plane Rh; cand_cnt[q] = 0.
 // cand_scratch: m x n0 floats.  sv_small_head_ok: the shapes it takes.
 bool sv_small_head_ok(int m, int d, int n0, int rank);
+// a BATCH search's sampled level from the same product: dist[q][j] = d2~(query q, database row j * stride), j < n0 (row stride ld)
+int sv_launch_sample_f16_batch(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int m, int n0, int d, int64_t stride, float inv_scale,
+                               const float* qn, const float* rn, float* dist, int64_t ld);
 int sv_launch_small_head(segvlad_ctx* ctx, const float* X, int m, int d, const uint16_t* Rh, const float* rn, int64_t stride, int n0,
                          float db_scale, int rank, uint16_t* qplane, float* scales_dev, float* qn_out, uint32_t* zero, int zero_words,
                          float* cand_scratch, float* thr_out, uint32_t* cand_cnt);   // ctx->h_pin (16 zeroed words) + ctx->ev_scalars

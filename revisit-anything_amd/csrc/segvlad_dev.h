@@ -31,6 +31,7 @@
  *     "pj_nw"         8 | 4   waves per workgroup of the P-space aggregation
  *     "x3_tile", "x3_gm", "agg_kpb", "assign_narrow"   tile / order / geometry of the projection GEMM, the descriptor
  *                     aggregation and the assignment kernel
+ *     "batch_l0_f16"  1 | 0   batch searches (guessed thresholds): the sampled level from the filter's own fp16 product | the exact fp32 GEMM
  *   single-image passes (small_pass_kernels.hip)
  *     "small_head"    1 | 0 | 3   the pass starts with small_head_kernel: plane, scale, norms, flags and the sample thresholds (from the
  *                     filter's own fp16 product) in one launch | query preparation -> exact fp32 sample level -> reduce + rank |

@@ -660,6 +660,68 @@ int sv_launch_small_head(segvlad_ctx* ctx, const float* X, int m, int d, const u
   return SEGVLAD_OK;
 }
 
+// ---- the sampled level of a BATCH search from the filter's own fp16 product (round 6) --------------------------------------------------
+// A batch search's coarsest level only has to hand a guessed threshold to the first filter level (the guesses are verified at the end,
+// DESIGN.md 4 item 4), so -- like the single-image head above -- it needs no exact distances: dist[q][j] = d2~(q, sample row j) from one
+// fp16 MFMA product of the query plane and the strided rows of the database plane, the rank select that follows is the one the exact
+// level used.  10 000 queries x 244 (1 M rows) / 488 (a 125 k-row shard) sample rows: ~15 us instead of 115 / 162 us of fp32 MFMA
+// (gemm_nt_kernel<1>, poorly filled at that width).  No LDS: a wave owns 16 query rows x 32 sample rows, its fragments come straight
+// from global memory (the query plane is L2 resident, the sample is half a megabyte).
+__global__ __launch_bounds__(256) void sample_f16_batch_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Rh, int m, int n0,
+                                                               int d, int64_t stride, float inv_scale, const float* __restrict__ qn,
+                                                               const float* __restrict__ rn, float* __restrict__ dist, int64_t ld) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i16 = lane & 15, kq = lane >> 4;
+  const int q0 = (int)blockIdx.y * 64 + wv * 16, c0 = (int)blockIdx.x * SH_RW;
+  if (q0 >= m) return;
+  const _Float16* qa = Qh + (size_t)min(q0 + i16, m - 1) * d + kq * 8;
+  const _Float16* ra = Rh + (size_t)((int64_t)min(c0 + i16, n0 - 1) * stride) * d + kq * 8;
+  const _Float16* rb = Rh + (size_t)((int64_t)min(c0 + 16 + i16, n0 - 1) * stride) * d + kq * 8;
+  sh_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int nks = d >> 5;
+  int ks = 0;
+  for (; ks + 4 <= nks; ks += 4) {   // twelve 16-byte loads in flight per lane
+    sh_f16x8 a[4], b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const sh_f16x8*>(qa + (ks + u) * 32);
+      b0[u] = *reinterpret_cast<const sh_f16x8*>(ra + (ks + u) * 32);
+      b1[u] = *reinterpret_cast<const sh_f16x8*>(rb + (ks + u) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b0[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b1[u], acc1, 0, 0, 0);
+    }
+  }
+  for (; ks < nks; ++ks) {
+    const sh_f16x8 a = *reinterpret_cast<const sh_f16x8*>(qa + ks * 32);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, *reinterpret_cast<const sh_f16x8*>(ra + ks * 32), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, *reinterpret_cast<const sh_f16x8*>(rb + ks * 32), acc1, 0, 0, 0);
+  }
+  // lane (i16, kq) holds rows 4 kq + r (queries), column i16 (sample row) of each tile
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = c0 + 16 * t + i16;
+    if (col >= n0) continue;
+    const float r2 = rn[(int64_t)col * stride];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = q0 + 4 * kq + r;
+      if (q < m) dist[(size_t)q * ld + col] = sv_d2(qn[q], r2, (t == 0 ? acc0[r] : acc1[r]) * inv_scale);
+    }
+  }
+}
+
+int sv_launch_sample_f16_batch(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int m, int n0, int d, int64_t stride, float inv_scale,
+                               const float* qn, const float* rn, float* dist, int64_t ld) {
+  if (m <= 0 || n0 <= 0) return SEGVLAD_OK;
+  if (d % 32) return ctx->fail(SEGVLAD_ERR_LIMIT, "sample_f16_batch: d=%d", d);
+  hipLaunchKernelGGL(sample_f16_batch_kernel, dim3((n0 + SH_RW - 1) / SH_RW, (m + 63) / 64), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<const _Float16*>(Qh), reinterpret_cast<const _Float16*>(Rh), m, n0, d, stride, inv_scale, qn, rn, dist, ld);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
 // tests only (option debug_small_tail): force the tail's paths on a pass that needed none of them
 __global__ void small_tail_debug_kernel(int bits, int m, uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, float* ref_lim,
                                         uint32_t* tick, int tick_poison) {
