@@ -404,6 +404,9 @@ def test_vote_handles_oversized_query_images(eng):
     (40000, 64, 1, 10, "gauss"), (70001, 128, 37, 200, "unit"), (300000, 256, 128, 50, "unit"),
     (100000, 1024, 50, 200, "clustered"), (65537, 2048, 9, 100, "unit"), (50000, 512, 64, 1, "scaled"),
     (120000, 1024, 50, 200, "duplicates"),
+    # round 6 (the device-driven pass: small_head_kernel / small_tail_kernel): BASELINE configs[4]'s PCA-512 rows at a shard's size and
+    # the shards' 50-deep search; 128 and 65 query rows (the 128 x 128 filter tiles; five 16-row query tiles in the head)
+    (250000, 512, 50, 50, "unit"), (130000, 512, 128, 200, "unit"), (90000, 1024, 65, 100, "clustered"),
 ])
 def test_knn_single_image_plan_sweep_equals_deep_plan(case):
     """The single-image plan (<= 128 query rows: one filter level, workgroup selects, shared refinement lists, device-side
