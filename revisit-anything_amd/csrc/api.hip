@@ -11,6 +11,7 @@
 #include <initializer_list>
 
 #include "ctx.h"
+#include "small_pass_dev.h"
 
 int segvlad_ctx::fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -1367,6 +1368,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     ref_lim = ctx->s_ref_lim.as<float>();
   }
   const uint32_t* poison_dev = nullptr;   // see sv_launch_refine_exact
+  bool tail_fused = false;                // the refinement kernel finished the flagged rows itself (no small_tail_kernel)
   const int r0 = rank[0];
   bool l0_fused = false;
   if (phase != 2) {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
@@ -1478,12 +1480,29 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
             ctx->sstats.grp_union_sum += us;
           }
         } else if (last) {
+          // a device-driven pass whose head was small_head_kernel (it repairs a poisoned hand-over buffer): the refinement finishes the
+          // flagged rows itself -- no small_tail_kernel behind it (a kernel boundary of 4-5 us, whatever the kernel does)
+          SvSmallFinish fz;
+          if (tail_stats && ctx->small_head_ran && ctx->opt.small_tail != 2) {
+            fz.on = 1;
+            fz.rovf_rows = rovf_rows;
+            fz.ref_lim = ref_lim;
+            fz.cand_cnt = ctx->s_cand_cnt.as<uint32_t>();
+            fz.cand_d2 = ctx->s_cand_d2.as<float>();
+            fz.cand_id = ctx->s_cand_id.as<uint32_t>();
+            fz.cap = SV_CAP;
+            fz.n_db = n;
+            fz.stats = tail_stats;
+            SV_TRY(sv_launch_small_tail_debug(ctx, m, fail_rows, fail_count, rovf_rows, ref_lim));
+          }
           SV_TRY(sv_launch_refine_exact(ctx, qp, R, m, d, qn, rn, ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP,
-                                        k, out_d2, out_idx, nullptr, fail_rows, fail_count, &poison_dev));
+                                        k, out_d2, out_idx, nullptr, fail_rows, fail_count, &poison_dev, &fz, &tail_fused));
           sc.count();
         }
       }   // (the stage's stop event is recorded before the host waits below)
-      if (last && tail_stats) {
+      if (last && tail_stats && tail_fused) {
+        if (n_fail_host) *n_fail_host = 0;   // (the refinement kernel has finished its flagged rows itself)
+      } else if (last && tail_stats) {
         StageScope sc(ctx, "knn_select");
         SV_TRY(sv_launch_small_tail(ctx, qp, R, qn, rn, n, d, m, k, fail_rows, fail_count, rovf_rows, ref_lim, ctx->s_cand_cnt.as<uint32_t>(),
                                     ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), SV_CAP, out_d2, out_idx, tail_stats));
@@ -1634,6 +1653,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
   ctx->sstats = SvSearchStats();
   ctx->sstats.n_queries = nq;
   ctx->tail_stats_dev = nullptr;
+  ctx->small_head_ran = false;
   // device-driven single-image passes never tell the host how many rows they had to redo -- but their running total lands in a
   // pinned word (small_tail_kernel): looked at here WITHOUT synchronising (it may be a pass or two behind).  More than a quarter
   // of >= 64 rows redone since the index last changed: the sample misleads on this database, stop guessing (as the read-back path

@@ -263,6 +263,7 @@ struct segvlad_ctx {
   int64_t db_rn_max_rows = 0;
   bool f16_bias_ok = false;   // this search's batch filter launches may use the biased-accumulator kernel (segvlad_search)
   const float* f16_scale_dev = nullptr;   // set by segvlad_search for the duration of a single-image search (see above)
+  bool small_head_ran = false;   // this search's pass started with small_head_kernel (which also repairs a poisoned hand-over buffer)
   bool db_heur_off = false;   // set when > 25 % of a search's queries needed the rigorous redo (until the index changes)
   // device-driven single-image passes (small_pass_kernels.hip): the tail kernel's counters of the LAST such search live in device
   // memory and are fetched by segvlad_search_stats (the search itself never reads them back); its running totals reach the host
@@ -432,10 +433,16 @@ int sv_launch_refine2_compact(segvlad_ctx* ctx, const uint32_t* rovf_rows, const
 // memory and CHECKS the hand-over (refine_exact_small_kernel): a query whose keys did not all arrive is flagged there like
 // a failed threshold check, and *poison_dev (set to a device word when that kernel ran, else to null) is non-zero afterwards;
 // the caller then calls sv_refine_small_repair before the buffers' next use.
+// fz / fused_done (round 6): when the shared-list kernel of a single-image pass runs, it finishes the rows the select flagged itself
+// (small_pass_dev.h: SvSmallFinish) and *fused_done is set: the caller then launches no small_tail_kernel behind it.
+struct SvSmallFinish;
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
                            const uint32_t* only_rows = nullptr, uint32_t* fail_rows = nullptr, uint32_t* fail_count = nullptr,
-                           const uint32_t** poison_dev = nullptr);
+                           const uint32_t** poison_dev = nullptr, const SvSmallFinish* fz = nullptr, bool* fused_done = nullptr);
+int sv_small_words(segvlad_ctx* ctx);   // ctx->s_tail_tick: [129] tail tickets, [2] totals, pad, the head's 64-bit arrival counter
+// tests only (option debug_small_tail): force the flags of a pass that needed none
+int sv_launch_small_tail_debug(segvlad_ctx* ctx, int m, uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, float* ref_lim);
 int sv_refine_small_repair(segvlad_ctx* ctx);
 // small_pass_kernels.hip: the device-driven tail of a single-image pass (<= 128 rows): launched behind the refinement, returns at
 // once when fail_count[0] == fail_count[1] == 0, else finishes the flagged rows on the device (second tier from the candidate

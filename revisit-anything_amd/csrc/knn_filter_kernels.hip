@@ -28,6 +28,7 @@
 
 #include "ctx.h"
 #include "knn_dev.h"
+#include "small_pass_dev.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -2793,7 +2794,8 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
                                                                  const uint32_t* __restrict__ ref_id, int rcap, int rpad, int k,
                                                                  float* __restrict__ d2_out, int64_t* __restrict__ idx_out, int parts,
                                                                  uint64_t* __restrict__ gkeys, uint32_t* __restrict__ tick,
-                                                                 uint32_t* __restrict__ fail_rows, uint32_t* __restrict__ fail_count) {
+                                                                 uint32_t* __restrict__ fail_rows, uint32_t* __restrict__ fail_count,
+                                                                 SvSmallFinish fz) {
   constexpr int ROWS = 32, KC = 512, LDR = KC + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);                  // [ROWS][LDR]
@@ -2818,7 +2820,56 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
   // the list's length and this workgroup's slice of it are requested together (the slice lies inside the list's rcap slots
   // whatever the length; entries beyond it are not looked at)
   const uint32_t idv = tid < ROWS ? ref_id[row * rcap + base + tid] : 0u;
+  // fz.on (round 6, second step: the pass WITHOUT small_tail_kernel -- every kernel boundary of this chain costs 4-5 us, whatever the
+  // kernel does): the rows the select flagged are finished HERE, by the row's own `parts` workgroups -- a band that outgrew the
+  // first tier: every part evaluates its slice of the candidate list, the last one sorts; a row flagged for the redo: exact brute
+  // force, every part a slice of the index, the last one merges (small_pass_dev.h; the same chain, sv_d2, (distance, id) order).
+  // The two flags are requested with the list's length: no extra round trip on the common path.
+  const uint32_t f_fail = fz.on ? fail_rows[row] : 0u, f_rovf = fz.on ? fz.rovf_rows[row] : 0u;
   const int n = (int)ref_cnt[row];
+  if (f_fail | f_rovf) {   // (workgroup-uniform)
+    const int p = (int)(blockIdx.x / nlists);
+    uint64_t* a2 = reinterpret_cast<uint64_t*>(smem);                 // <= 8192 words of sort scratch
+    float* qs2 = reinterpret_cast<float*>(smem + 65536);              // 1024 floats
+    uint64_t* best2 = a2 + 2048;                                      // (brute force: the sort scratch is 2048 words)
+    uint64_t* slot = fz.part2 + (size_t)row * fz.row_words;           // this row's words of the exchange buffer
+    if (f_fail) sp_brute_slice(Q, R, qn, rn, fz.n_db, d, k, fz.kp, row, p, parts, slot, a2, best2, qs2, tid);
+    else sp_tier2_slice(Q, R, qn, rn, d, row, p, parts, min(fz.cand_cnt[row], (uint32_t)fz.cap), fz.ref_lim[row], fz.cand_d2, fz.cand_id, fz.cap, slot,
+                        qs2, tid);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = (__hip_atomic_fetch_add(&tick[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(parts - 1));
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (f_fail) {
+      sp_brute_merge(slot, k, fz.kp, parts, a2, best2, tid);
+      for (int j = tid; j < k; j += 256) {
+        const uint64_t v = best2[j];
+        d2_out[row * k + j] = v != ~0ull ? key2f_((uint32_t)(v >> 32)) : INFINITY;
+        idx_out[row * k + j] = v != ~0ull ? (int64_t)(uint32_t)v : -1;
+      }
+    } else {
+      const int c = (int)min(fz.cand_cnt[row], (uint32_t)fz.cap);
+      int np2 = 2;
+      while (np2 < c) np2 <<= 1;
+      for (int j = tid; j < np2; j += 256)
+        a2[j] = j < c ? __hip_atomic_load(&slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+      bitonic64(a2, np2, tid);
+      for (int j = tid; j < k; j += 256) {
+        const uint64_t v = j < np2 ? a2[j] : ~0ull;
+        d2_out[row * k + j] = v != ~0ull ? key2f_((uint32_t)(v >> 32)) : INFINITY;
+        idx_out[row * k + j] = v != ~0ull ? (int64_t)(uint32_t)v : -1;
+      }
+    }
+    if (tid == 0) {
+      __hip_atomic_store(&tick[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(&fz.stats[f_fail ? 0 : 1], 1u);
+      const uint32_t tot = atomicAdd(&fz.totals[f_fail ? 0 : 1], 1u) + 1u;
+      if (fz.host_totals) fz.host_totals[f_fail ? 0 : 1] = tot;   // (the pinned mirror: the latest writer's total)
+    }
+    return;
+  }
   const int cnt = min(ROWS, n - base);
   RTICK();   // T1: list length + ids
   if (cnt > 0) {
@@ -2916,12 +2967,32 @@ __global__ __launch_bounds__(256) void refine_exact_small_kernel(const float* __
     a[j] = v;
   }
   if (tid == 0) __hip_atomic_store(&tick[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (__syncthreads_or(holes)) {   // (never observed; the row's output is left to the redo)
-    if (tid == 0) {
-      __hip_atomic_store(&tick[SV_TICK_POISON], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (fail_rows && atomicExch(&fail_rows[row], 1u) == 0u) atomicAdd(fail_count, 1u);
+  if (fz.on && (fz.debug & 8) && row == 1) holes = 1;   // (tests: the path below has never been taken by the hardware)
+  if (__syncthreads_or(holes)) {   // (never observed)
+    if (tid == 0) __hip_atomic_store(&tick[SV_TICK_POISON], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!fz.on) {   // the row's output is left to the redo (the caller's read-back, or small_tail_kernel)
+      if (tid == 0 && fail_rows && atomicExch(&fail_rows[row], 1u) == 0u) atomicAdd(fail_count, 1u);
+      return;
     }
-    return;
+    // fused finish: nobody comes after this kernel -- this workgroup re-evaluates the row's whole band itself (<= rcap rows, a thread
+    // per row: the same chain); the sticky word makes the NEXT pass's head refill the hand-over buffers (a key that lands late must
+    // not pass for a key of that pass)
+    float* qs2 = reinterpret_cast<float*>(smem);   // (the row tile is free: every part has drawn its ticket)
+    for (int j0 = 0; j0 < n; j0 += 256) {
+      const int j = j0 + tid;
+      const uint32_t id = ref_id[row * rcap + min(j, n - 1)];
+      float acc2[1] = {0.f};
+      for (int c0 = 0; c0 < d; c0 += ST_KC) {
+        const int kc = min(ST_KC, d - c0);
+        __syncthreads();
+        for (int t = tid; t < kc; t += 256) qs2[t] = Q[row * d + c0 + t];
+        __syncthreads();
+        chain_step<1>(R + (size_t)id * d + c0, kc, qs2, acc2);
+      }
+      if (j < n) a[j] = ((uint64_t)f2key_(sv_d2(qn[row], rn[id], acc2[0])) << 32) | id;
+    }
+    __syncthreads();
+    if (tid == 0) atomicAdd(&fz.stats[2], 1u);
   }
   RTICK();   // T4: keys read back
   // (distance, id) order WITHOUT a sort: the keys are distinct (the id is part of them), so a key's place in the sorted list is the
@@ -2959,8 +3030,10 @@ int sv_refine_small_repair(segvlad_ctx* ctx) {
 
 int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int nq, int d, const float* qn, const float* rn,
                            const uint32_t* ref_cnt, const uint32_t* ref_id, int rcap, int k, float* d2_out, int64_t* idx_out,
-                           const uint32_t* only_rows, uint32_t* fail_rows, uint32_t* fail_count, const uint32_t** poison_dev) {
+                           const uint32_t* only_rows, uint32_t* fail_rows, uint32_t* fail_count, const uint32_t** poison_dev,
+                           const SvSmallFinish* fz, bool* fused_done) {
   if (poison_dev) *poison_dev = nullptr;
+  if (fused_done) *fused_done = false;
   if (nq <= 0) return SEGVLAD_OK;
   int rpad = 2;
   while (rpad < rcap) rpad <<= 1;
@@ -2975,8 +3048,24 @@ int sv_launch_refine_exact(segvlad_ctx* ctx, const float* Q, const float* R, int
     if (ctx->s_ref_keys.cap != keys_cap) SV_HIP(hipMemsetAsync(ctx->s_ref_keys.p, 0xff, ctx->s_ref_keys.cap, ctx->stream));
     lds = (size_t)(32 * 516 + 1024) * 4 + (size_t)rpad * 8;
     if (lds > 64 * 1024) SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(refine_exact_small_kernel), lds));
+    SvSmallFinish f;   // (off)
+    if (fz && fz->on && fail_rows && fused_done && k <= 1024) {
+      // the flagged rows' exchange words: a row's `parts` lists of kp keys (brute force) or its `cap` candidate keys (second tier)
+      f = *fz;
+      f.kp = 256;
+      while (f.kp < k) f.kp <<= 1;
+      f.row_words = std::max<int64_t>((int64_t)parts * f.kp, f.cap);
+      SV_HIP(ctx->s_tail_part.reserve((size_t)nq * f.row_words * 8));
+      SV_TRY(sv_small_words(ctx));
+      SV_TRY(sv_ensure_pinned_words(ctx));
+      f.part2 = ctx->s_tail_part.as<uint64_t>();
+      f.totals = ctx->s_tail_tick.as<uint32_t>() + 129;
+      f.host_totals = ctx->h_pin + 8;
+      f.debug = ctx->opt.debug_small_tail;
+      *fused_done = true;
+    }
     hipLaunchKernelGGL(refine_exact_small_kernel, dim3(nq * parts), dim3(256), lds, ctx->stream, Q, R, d, qn, rn, ref_cnt, ref_id, rcap,
-                       rpad, k, d2_out, idx_out, parts, ctx->s_ref_keys.as<uint64_t>(), ctx->s_ref_tick.as<uint32_t>(), fail_rows, fail_count);
+                       rpad, k, d2_out, idx_out, parts, ctx->s_ref_keys.as<uint64_t>(), ctx->s_ref_tick.as<uint32_t>(), fail_rows, fail_count, f);
     SV_HIP(hipGetLastError());
     if (poison_dev) *poison_dev = ctx->s_ref_tick.as<uint32_t>() + SV_TICK_POISON;
     return SEGVLAD_OK;

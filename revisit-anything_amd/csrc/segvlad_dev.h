@@ -36,11 +36,13 @@
  *     "small_head"    1 | 0 | 3   the pass starts with small_head_kernel: plane, scale, norms, flags and the sample thresholds (from the
  *                     filter's own fp16 product) in one launch | query preparation -> exact fp32 sample level -> reduce + rank |
  *                     the same kernel with the query block loaded straight in MFMA fragment shape (measured slower: 22.7 vs 21 us)
- *     "small_tail"    1 | 0   the pass ends in small_tail_kernel, which reads the overflow counters on the DEVICE and finishes
- *                     flagged rows there (no read-back, no host synchronisation in segvlad_search) | the read-back of rounds 3-5
+ *     "small_tail"    1 | 2 | 0   no read-back, no host synchronisation in segvlad_search: flagged rows are finished on the DEVICE -- by the
+ *                     refinement kernel's own workgroups where the shared-list refinement runs behind small_head_kernel (no extra launch),
+ *                     else by small_tail_kernel, launched behind every pass | always small_tail_kernel | the read-back of rounds 3-5
  *   debugging and the tests' own hooks
- *     "debug_small_tail"   bit 0: every row of a device-driven pass is flagged for the tail's exact brute force; bit 1: every
- *                          row is sent through the tail's second tier; bit 2: the checked hand-over's sticky word is raised
+ *     "debug_small_tail"   bit 0: every row of a device-driven pass is flagged for the exact brute force; bit 1: every row is sent through
+ *                          the second tier; bit 2: the checked hand-over's sticky word is raised; bit 3: query row 1's hand-over is treated
+ *                          as failed (the fused finish recomputes the band); bits 8..: grid of small_tail_kernel (A/B)
  *     "debug_search"       1 = per-level candidate statistics on stderr (synchronises); 7 = the Gram kernel waits for every
  *                          outstanding memory operation at every step (verification of its counted waits)
  *     "debug_fail_search"  segvlad_search fails at once (the sharded entry's error path)

@@ -43,65 +43,8 @@
 
 #include "ctx.h"
 #include "knn_dev.h"
+#include "small_pass_dev.h"
 
-namespace {
-
-constexpr int ST_QB = 4;        // flagged rows evaluated per sweep over a workgroup's slice of the index
-constexpr int ST_KC = 1024;     // floats of a query row staged in LDS per step
-constexpr int ST_CAP = 8192;    // longest candidate list (SV_CAP)
-
-// exact chains of ONE index row against nb <= ST_QB staged query chunks (qs[b][0..kc)): acc[b] = fma(q[j], r[j], acc[b]) in j order
-template <int NB>
-__device__ __forceinline__ void chain_step(const float* __restrict__ rrow, int kc, const float* __restrict__ qs, float (&acc)[NB]) {
-  const float4* rp = reinterpret_cast<const float4*>(rrow);
-  const int n4 = kc >> 2;
-  int t = 0;
-  for (; t + 16 <= n4; t += 16) {
-    float4 buf[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) buf[u] = rp[t + u];
-    __builtin_amdgcn_sched_barrier(0);   // all sixteen loads are issued before the first fma
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float4 qv = *reinterpret_cast<const float4*>(qs + b * ST_KC + (t + u) * 4);
-        acc[b] = fmaf(qv.x, buf[u].x, acc[b]);
-        acc[b] = fmaf(qv.y, buf[u].y, acc[b]);
-        acc[b] = fmaf(qv.z, buf[u].z, acc[b]);
-        acc[b] = fmaf(qv.w, buf[u].w, acc[b]);
-      }
-    }
-  }
-  for (; t < n4; ++t) {
-    const float4 rv = rp[t];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const float4 qv = *reinterpret_cast<const float4*>(qs + b * ST_KC + t * 4);
-      acc[b] = fmaf(qv.x, rv.x, acc[b]);
-      acc[b] = fmaf(qv.y, rv.y, acc[b]);
-      acc[b] = fmaf(qv.z, rv.z, acc[b]);
-      acc[b] = fmaf(qv.w, rv.w, acc[b]);
-    }
-  }
-}
-
-// best[0..kp) (ascending, padded with all ones) <- the kp smallest of best U {mine of the 256 threads}; a: >= kp + 256 words of
-// scratch, sort length ns = the power of two holding kp + 256.  Skipped (workgroup-uniformly) when nobody brings a key below
-// best[k - 1].
-__device__ __forceinline__ void merge_best(uint64_t* __restrict__ best, int kp, int k, uint64_t mine, uint64_t* __restrict__ a, int ns,
-                                           int tid) {
-  const bool better = mine < best[k - 1];
-  if (!__syncthreads_or(better ? 1 : 0)) return;
-  for (int j = tid; j < kp; j += 256) a[j] = best[j];
-  a[kp + tid] = better ? mine : ~0ull;
-  for (int j = kp + 256 + tid; j < ns; j += 256) a[j] = ~0ull;
-  bitonic64(a, ns, tid);
-  for (int j = tid; j < kp; j += 256) best[j] = a[j];
-  __syncthreads();
-}
-
-}  // namespace
 
 __global__ __launch_bounds__(256) void small_tail_kernel(const float* __restrict__ Q, const float* __restrict__ R,
                                                          const float* __restrict__ qn, const float* __restrict__ rn, int64_t n, int d,
@@ -294,7 +237,9 @@ __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restric
                                                           _Float16* __restrict__ qplane, float* __restrict__ scales,
                                                           float* __restrict__ qn_out, uint32_t* __restrict__ zero, int zero_words,
                                                           float* __restrict__ cand, unsigned long long* __restrict__ ticket,
-                                                          float* __restrict__ thr_out, uint32_t* __restrict__ cnt, int dbg) {
+                                                          float* __restrict__ thr_out, uint32_t* __restrict__ cnt, int dbg,
+                                                          uint32_t* __restrict__ rtick, int rtick_poison, uint64_t* __restrict__ gkeys,
+                                                          int64_t gkeys_words) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // phase timing (development: -DSV_HEAD_TIMING and SV_HEAD_TIMING=1 in the environment print every workgroup's phase cycles)
 #ifdef SV_HEAD_TIMING
@@ -309,6 +254,12 @@ __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restric
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i16 = lane & 15, kq = lane >> 4;
   const int w = blockIdx.x, NW = gridDim.x;
+  // a hand-over of the previous pass's refinement failed its check (never observed): its buffers back to all ones before THIS pass's
+  // refinement uses them -- every workgroup reads the sticky word before the grid barrier, workgroup 0 clears it behind the barrier
+  const bool repair = rtick && __hip_atomic_load(&rtick[rtick_poison], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  if (repair)
+    for (int64_t j = (int64_t)w * SH_T + tid; j < gkeys_words; j += (int64_t)NW * SH_T)
+      __hip_atomic_store(&gkeys[j], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int mpad = (m + 15) & ~15, MT = mpad >> 4;
   const int lda = d + 8;                                   // halves per LDS row of the query operand (+16 B: the 16 rows of a fragment read hit 16 bank groups)
   _Float16* As = reinterpret_cast<_Float16*>(smem);        // [mpad][lda]
@@ -573,6 +524,7 @@ __global__ __launch_bounds__(SH_T) void small_head_kernel(const float* __restric
   }
   __syncthreads();
   const bool arrived = s_last != 0;
+  if (repair && w == 0 && tid == 0) __hip_atomic_store(&rtick[rtick_poison], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   TICK();
   constexpr uint32_t PAD = 0xffffffffu;
   if (wv == 0)
@@ -621,7 +573,7 @@ bool sv_small_head_ok(int m, int d, int n0, int rank) {
          nw <= 64 * SH_PER && nw >= 4 * rank;
 }
 
-static int sv_small_words(segvlad_ctx* ctx) {   // [129] tail tickets, [2] tail totals, 1 pad, [2] the head's 64-bit arrival counter
+int sv_small_words(segvlad_ctx* ctx) {   // [129] tail tickets, [2] tail totals, 1 pad, [2] the head's 64-bit arrival counter
   const size_t tcap = ctx->s_tail_tick.cap;
   SV_HIP(ctx->s_tail_tick.reserve((size_t)(129 + 2 + 1 + 2) * 4));
   if (ctx->s_tail_tick.cap != tcap) SV_HIP(hipMemsetAsync(ctx->s_tail_tick.p, 0, ctx->s_tail_tick.cap, ctx->stream));
@@ -651,11 +603,12 @@ int sv_launch_small_head(segvlad_ctx* ctx, const float* X, int m, int d, const u
                      db_scale, rank, reinterpret_cast<_Float16*>(qplane), scales_dev, qn_out, zero, zero_words, cand_scratch,
                      reinterpret_cast<unsigned long long*>(ctx->s_tail_tick.as<uint32_t>() + 132), thr_out, cand_cnt,
 #ifdef SV_HEAD_TIMING
-                     1
+                     1,
 #else
-                     0
+                     0,
 #endif
-  );
+                     ctx->s_ref_tick.as<uint32_t>(), 128, ctx->s_ref_keys.as<uint64_t>(), (int64_t)(ctx->s_ref_keys.cap / 8));
+  ctx->small_head_ran = true;
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
@@ -739,17 +692,23 @@ __global__ void small_tail_debug_kernel(int bits, int m, uint32_t* fail_rows, ui
   }
 }
 
+int sv_launch_small_tail_debug(segvlad_ctx* ctx, int m, uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, float* ref_lim) {
+  if ((ctx->opt.debug_small_tail & 7) == 0) return SEGVLAD_OK;
+  hipLaunchKernelGGL(small_tail_debug_kernel, dim3(1), dim3(128), 0, ctx->stream, ctx->opt.debug_small_tail & 7, m, fail_rows, fail_count, rovf_rows,
+                     ref_lim, ctx->s_ref_tick.as<uint32_t>(), 128);
+  SV_HIP(hipGetLastError());
+  return SEGVLAD_OK;
+}
+
 // part: [m][G][kp] words, tickets: [129] words (all zero between launches), stats: [4] words of THIS search (zeroed by the pass's
 // first kernel), totals: [2] words accumulated over the context's life, host_totals: their pinned mirror (or null)
 int sv_launch_small_tail(segvlad_ctx* ctx, const float* Q, const float* R, const float* qn, const float* rn, int64_t n, int d, int m, int k,
                          uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, const float* ref_lim, const uint32_t* cand_cnt,
                          const float* cand_d2, const uint32_t* cand_id, int cap, float* d2_out, int64_t* idx_out, uint32_t* stats) {
   if (m <= 0) return SEGVLAD_OK;
-  if (ctx->opt.debug_small_tail)
-    hipLaunchKernelGGL(small_tail_debug_kernel, dim3(1), dim3(128), 0, ctx->stream, ctx->opt.debug_small_tail, m, fail_rows, fail_count,
-                       rovf_rows, const_cast<float*>(ref_lim), ctx->s_ref_tick.as<uint32_t>(), 128);
+  SV_TRY(sv_launch_small_tail_debug(ctx, m, fail_rows, fail_count, rovf_rows, const_cast<float*>(ref_lim)));
   if (m > 128 || k > 1024 || cap > ST_CAP || (d & 3)) return ctx->fail(SEGVLAD_ERR_LIMIT, "small tail: m=%d k=%d cap=%d d=%d", m, k, cap, d);
-  constexpr int G = 64;
+  const int G = (ctx->opt.debug_small_tail >> 8) > 0 ? (ctx->opt.debug_small_tail >> 8) : 64;   // (development: bits 8.. = grid size A/B)
   int kp = 256;
   while (kp < k) kp <<= 1;
   SV_HIP(ctx->s_tail_part.reserve((size_t)m * G * kp * 8));

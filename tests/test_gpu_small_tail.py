@@ -31,20 +31,25 @@ def _problem(eng, n, d, nq, seed, noise=0.05):
     return R, Q
 
 
-@pytest.mark.parametrize("n,d,nq,k", [(100_000, 256, 40, 50), (70_000, 1024, 50, 200), (50_000, 64, 1, 20), (60_000, 128, 128, 300)])
-def test_every_path_of_the_tail_equals_the_read_back_path(n, d, nq, k):
+@pytest.mark.parametrize("form", [1, 2])          # 1: flagged rows finished by the refinement kernel itself where it can; 2: always small_tail_kernel
+@pytest.mark.parametrize("n,d,nq,k", [(100_000, 256, 40, 50), (70_000, 1024, 50, 200), (50_000, 64, 1, 20), (60_000, 128, 128, 300),
+                                      (90_000, 1024, 128, 1000)])
+def test_every_path_of_the_tail_equals_the_read_back_path(n, d, nq, k, form):
     eng = _engine()
     R, Q = _problem(eng, n, d, nq, seed=n + d)
     eng.set_option("small_tail", 0)
     ref = eng.search(Q, k)
     st0 = eng.search_stats()
     assert st0["levels"] == 1 and st0["filter"] == "f16" and st0["n_redo"] == 0 and st0["n_fallback"] == 0, st0
-    eng.set_option("small_tail", 1)
+    eng.set_option("small_tail", form)
     got = eng.search(Q, k)
     st = eng.search_stats()
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-    assert st["n_redo"] == 0 and st["n_refine2"] == 0, st
-    for bits, key in ((1, "n_redo"), (2, "n_refine2"), (4, "n_redo"), (3, "n_redo")):
+    # (k = 1000: every band outgrows the 512-entry first tier -- all rows take the second tier on both paths)
+    assert st["n_redo"] == 0 and st["n_refine2"] == st0["n_refine2"] == (nq if k > 512 else 0), (st, st0)
+    # bit 3 (value 8): the fused form's own answer to a failed hand-over -- the last workgroup re-evaluates the row's band itself (query
+    # row 1; never taken by the hardware so far) -- changes no bit and leaves the sticky word for the next pass's head to repair
+    for bits, key in ((1, "n_redo"), (2, "n_refine2"), (4, "n_redo"), (3, "n_redo"), (8, "n_redo")):
         eng.db_reset()                 # (a fresh index: rows redone in the previous round must not switch the guessed thresholds off)
         eng.db_add(R)
         eng.set_option("debug_small_tail", bits)
@@ -54,14 +59,16 @@ def test_every_path_of_the_tail_equals_the_read_back_path(n, d, nq, k):
         assert torch.equal(got[1], ref[1]), (bits, (got[1] != ref[1]).sum().item())
         assert torch.equal(got[0], ref[0]), bits
         # (bit 2 raises the word of refine_exact_small_kernel's hand-over, which only rows of d % 1024 == 0 go through)
-        assert st[key] == ((1 if d % 1024 == 0 else 0) if bits == 4 else nq), (bits, st)
+        if k <= 512:
+            assert st[key] == ((1 if d % 1024 == 0 else 0) if bits == 4 else 0 if bits == 8 else nq), (bits, st)
         again = eng.search(Q, k)       # tickets back at zero, hand-over buffers repaired: the next pass is clean
         assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
         assert eng.search_stats()["n_redo"] == 0
     eng.close()
 
 
-def test_real_overflows_are_finished_on_the_device():
+@pytest.mark.parametrize("d", [256, 1024])     # (d % 1024 == 0: the shared-list refinement, whose fused form finishes the flagged rows itself)
+def test_real_overflows_are_finished_on_the_device(d):
     """Query 7's 600 duplicates outgrow the first-tier refine list (-> second tier), query 23's 9000 overflow the candidate list
     (-> exact brute force); everything equals the read-back path and the oracle's clamp-aware top k."""
     from oracle import segvlad_oracle as O
@@ -70,7 +77,7 @@ def test_real_overflows_are_finished_on_the_device():
     dev = eng.device
     g = torch.Generator(device=dev)
     g.manual_seed(13)
-    n, nq, k, d = 120_000, 40, 50, 256
+    n, nq, k = 120_000, 40, 50
     R = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=1)
     star = torch.nn.functional.normalize(torch.randn(2, d, device=dev, generator=g), dim=1)
     dup_a = torch.arange(0, 600, device=dev) * 191 + 17
@@ -87,11 +94,12 @@ def test_real_overflows_are_finished_on_the_device():
     ref = eng.search(Q, k)
     st0 = eng.search_stats()
     assert st0["n_refine2"] >= 1 and st0["n_fallback"] + st0["n_redo"] >= 1, st0
-    eng.set_option("small_tail", 1)
-    got = eng.search(Q, k)
-    st = eng.search_stats()
-    assert st["n_refine2"] >= 1 and st["n_redo"] >= 1 and st["n_fallback"] == 0, st
-    assert torch.equal(got[1], ref[1]) and torch.equal(got[0], ref[0])
+    for form in (1, 2):
+        eng.set_option("small_tail", form)
+        got = eng.search(Q, k)
+        st = eng.search_stats()
+        assert st["n_refine2"] >= 1 and st["n_redo"] >= 1 and st["n_fallback"] == 0, (form, st)
+        assert torch.equal(got[1], ref[1]) and torch.equal(got[0], ref[0]), form
     ii = got[1].cpu().numpy()
     assert np.array_equal(ii[7], np.sort(dup_a.cpu().numpy())[:k]) and np.array_equal(ii[23], np.sort(dup_b.cpu().numpy())[:k])
     rd2, ridx = O.topk_from_d2(O.l2_matrix(R.cpu().numpy(), Q.cpu().numpy()), k)
