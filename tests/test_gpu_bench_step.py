@@ -73,6 +73,27 @@ def test_bench_two_ranks_one_gpu_equal_single_rank(tmp_path):
     assert j1["recall_at_1"] == j2["recall_at_1"]
 
 
+def test_bench_four_ranks_one_gpu_ragged_slices_equal_single_rank(tmp_path):
+    """The same at N = 4 with RAGGED slices (42 query images: 10 / 10 / 11 / 11 per rank; 3001 reference images: shards of 750 / 750 /
+    750 / 751 images) -- the padded row gather and its trimming, shard bounds that are not multiples of anything -- and the round-6
+    records of the N > 1 line: per rank the collectives' milliseconds and bytes (tools/n8_same_device.sh runs N = 8 the same way)."""
+    p1, p4 = str(tmp_path / "p1.npy"), str(tmp_path / "p4.npy")
+    common = ["--steps", "1", "--warmup", "1", "--db-images", "3001", "--query-images", "42", "--no-cpu-baseline", "--no-ubench",
+              "--no-sub-records", "--shard-sim", "0"]
+    j1 = _run([sys.executable, "bench.py", *common, "--dump-preds", p1], 900)
+    port = 31500 + (os.getpid() % 2000)
+    j4 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "4", "--same-device", "--dist-backend", "gloo", *common,
+               "--dump-preds", p4], 1200)
+    assert j4["n_gpus"] == 4 and np.array_equal(np.load(p1), np.load(p4)) and j1["recall_at_1"] == j4["recall_at_1"]
+    ranks = j4["per_rank_stages_ms"]
+    assert len(ranks) == 4 and sorted(r["n_local_rows"] for r in ranks) == [37500, 37500, 37500, 37550]
+    for r in ranks:
+        assert set(r["collective_ms_per_step"]) == {"query_rows_allgather", "topk_records_allgather"}
+        assert r["collective_bytes_per_step"]["topk_records_allgather_send"] == 42 * 50 * 50 * 12
+        assert r["collective_bytes_per_step"]["query_rows_allgather_recv"] == 4 * 11 * 50 * 1024 * 4     # padded to the longest slice
+
+
 def test_bench_config2_raw_descriptors_end_to_end_equals_oracle():
     """BASELINE configs[1] literally (place_rec_main.py:49-60 with pca off): 1000 reference images x 50 segments of raw
     K*D = 98 304-d descriptors, 200 query images, search 200 / vote 50 -- one image's 50 query segments re-computed by the
