@@ -282,7 +282,7 @@ int segvlad_stage_ms(segvlad_ctx* ctx, const char* stage, float* ms_out, int* la
  *      an earlier, larger one already covers cannot fail.)  Results are unchanged; calls synchronise the device. */
 int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
 
-/* ---- statistics of the last segvlad_search on this context (HOST array, up to 12 values):
+/* ---- statistics of the last segvlad_search on this context (HOST array, up to 13 values):
  *      [0] filter levels run after the sampled exact level (0 = distance-matrix path)
  *      [1] filter arithmetic used (0 none, 1 f16, 2 bf16x3, 3 fp32)
  *      [2] query rows whose candidate list overflowed and that were redone, as one dense batch, on the
@@ -295,7 +295,9 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value);
  *      [9] query rows whose refine band held more rows than the first-tier list (512) and that were refined
  *          from their whole candidate list instead (second tier; temporally redundant databases)
  *      [10] groups of 32 consecutive query rows whose refine bands overlapped enough to be evaluated as one exact fp32 GEMM over
- *           the union of their rows, and [11] the sum of those unions' lengths            (option search_stats = 1)            */
+ *           the union of their rows, and [11] the sum of those unions' lengths            (option search_stats = 1)
+ *      [12] database rows the last filter level did not evaluate again: the rows of the stride-16 level, whose survivors stayed in
+ *           the candidate lists (0: every level started from empty lists)                                                         */
 int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n);
 
 /* ---- row-sharded index over the GPUs of a node: one process (and one context) per GPU.

@@ -321,6 +321,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "small_tail")) return as_int(&o.small_tail);
   if (!strcmp(key, "small_head")) return as_int(&o.small_head);
   if (!strcmp(key, "batch_l0_f16")) return as_int(&o.batch_l0_f16);
+  if (!strcmp(key, "level_carry")) return as_int(&o.level_carry);
   if (!strcmp(key, "debug_small_tail")) return as_int(&o.debug_small_tail);
   if (!strcmp(key, "refine_group")) return as_int(&o.refine_group);
   if (!strcmp(key, "query_group")) return as_int(&o.query_group);
@@ -358,9 +359,9 @@ int segvlad_search_stats(segvlad_ctx* ctx, int64_t* stats_out, int n) {
     ctx->tail_stats_dev = nullptr;
   }
   const SvSearchStats& t = ctx->sstats;
-  const int64_t v[12] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo, t.n_refine2,
-                         t.grp_groups, t.grp_union_sum};
-  for (int j = 0; j < n && j < 12; ++j) stats_out[j] = v[j];
+  const int64_t v[13] = {t.levels, t.filter, t.n_fallback, t.cand_max, t.cand_sum, t.refine_max, t.refine_sum, t.n_queries, t.n_redo, t.n_refine2,
+                         t.grp_groups, t.grp_union_sum, t.carry_rows};
+  for (int j = 0; j < n && j < 13; ++j) stats_out[j] = v[j];
   return SEGVLAD_OK;
 }
 
@@ -1420,10 +1421,17 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   float eps_mult = heuristic ? 2.f : 1.f;
   int64_t stride = pl.stride0;
   std::vector<uint32_t> hcnt;
+  // carry (round 6b): the stride-16 level's filter has already evaluated 1/16 of the rows with the arithmetic of the last level; its
+  // survivors under the NEXT threshold stay in the lists (select mode 2) and the last level runs over the other 15/16 only.  Guessed
+  // thresholds only (every level collects under thr + 2 eps there, so the kept set is exactly what the last level would append).
+  const int64_t n_comp = n - (n + SV_RATIO - 1) / SV_RATIO;   // rows that are not multiples of 16
+  const bool carry = heuristic && pl.kind == 1 && levels >= 2 && pl.ratio_last == SV_RATIO && m > 128 && n_comp < 0x7fffffffLL &&
+                     sv_f16_filter_skip_ok(ctx, m, n_comp, d);
+  if (carry) ctx->sstats.carry_rows = n - n_comp;
   for (int lv = 1; lv <= levels; ++lv) {
     stride /= (lv == levels) ? pl.ratio_last : SV_RATIO;
-    const int64_t ns = (n + stride - 1) / stride;
     const bool last = (lv == levels);
+    const int64_t ns = (last && carry) ? n_comp : (n + stride - 1) / stride;
     // the candidate counters start every level at zero: the mode-0 selects of the approximate-domain filters leave them so;
     // only the first filter level behind a select_topk level 0, and the fp32 filter's select, need the memset
     if (pl.kind == 3 || (lv == 1 && !l0_small)) SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
@@ -1433,7 +1441,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
         if (pl.kind == 1)
           SV_TRY(sv_launch_f16_filter(ctx, q16a, ctx->db_f16.as<uint16_t>(), m, (int)ns, d, (int)stride, pl.inv_scale, qn, rn, thr_ptr,
                                       thr_ld, eps_mult, pl.c_eps, pl.rn_max, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
-                                      ctx->s_cand_id.as<uint32_t>(), SV_CAP));
+                                      ctx->s_cand_id.as<uint32_t>(), SV_CAP, (last && carry) ? SV_RATIO : 0));
         else
           SV_TRY(sv_launch_bf16_filter(ctx, q16a, q16b, ctx->db_hi.as<uint16_t>(), ctx->db_lo.as<uint16_t>(), m, (int)ns, d, (int)stride,
                                        qn, rn, thr_ptr, thr_ld, eps_mult, pl.c_eps, pl.rn_max, ctx->s_cand_cnt.as<uint32_t>(),
@@ -1462,7 +1470,8 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
       {
         StageScope sc(ctx, "knn_select");
         SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
-                                       SV_CAP, rank[lv], last ? 1 : 0, heuristic ? 1 : 0, thr_ptr, thr_ld, qn, pl.c_eps, pl.rn_max, thr,
+                                       SV_CAP, rank[lv], last ? 1 : ((carry && lv + 1 == levels) ? 2 : 0), heuristic ? 1 : 0, thr_ptr, thr_ld, qn,
+                                       pl.c_eps, pl.rn_max, thr,
                                        ctx->s_ref_cnt.as<uint32_t>(), ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count,
                                        rovf_rows, rovf_count, ref_lim));
         sc.count();

@@ -165,6 +165,9 @@ struct SvOptions {
                               // row's band is sent to its second tier, bit 2 = the hand-over's sticky failure word is raised
   int batch_l0_f16 = 1;   // batch searches on the fp16 filter with guessed thresholds: the sampled level from the filter's own fp16 product
                           // (sample_f16_batch_kernel) instead of the exact fp32 GEMM; 0 = rounds 2-5
+  int level_carry = 1;    // batch searches, guessed thresholds, fp16 filter: the last level runs over the rows the stride-16 level has not
+                          // seen and that level's survivors stay in the candidate lists (1/16 of the full-level GEMM saved); 0 = every
+                          // level starts from empty lists and the last one covers every row (rounds 2-6a)
   int small_head = 1;     // single-image passes start with small_head_kernel (plane + scale + norms + flags + sample thresholds in one
                           // launch); 0 = query preparation -> exact sample level -> reduce + rank (rounds 3-5)
   int small_tail = 1;     // single-image passes end in small_tail_kernel (no read-back); 0 = the read-back of rounds 3-5
@@ -219,6 +222,7 @@ struct SvSearchStats {
   int64_t n_refine2 = 0;        // query rows whose refine band exceeded the first-tier list (SV_RCAP) and took the second tier
   int64_t grp_groups = 0;       // groups of 32 query rows whose bands were refined over the union of their rows (search_stats only)
   int64_t grp_union_sum = 0;    // sum of those unions' lengths (search_stats only)
+  int64_t carry_rows = 0;       // database rows the last filter level did not compute again (taken over from the stride-16 level: level_carry)
 };
 
 struct segvlad_ctx {
@@ -418,7 +422,10 @@ int sv_launch_bf16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* 
 // collected under).  Flagged rows (also: list overflow) are marked in fail_rows and counted once in *fail_count.
 // mode 0 also ZEROES cand_cnt[row] (the next level's filter appends from zero).  fixed_cnt >= 0: every row is a list of that
 // length (the sampled level's distance block) and cand_cnt is not read.
-int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
+// mode 2 (batches, the level before the last one when that runs over the complement of this level's sample -- option level_carry):
+// thr_out = min(A, thr_in) and the entries with d2~ <= thr_out + 2 eps STAY in the list, compacted to its front, cand_cnt[row] =
+// their number: the last level appends behind them instead of computing the sample's rows a second time.
+int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int nq,
                             int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
                             float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
                             uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows = nullptr, uint32_t* rovf_count = nullptr,
@@ -498,7 +505,9 @@ int sv_launch_query_f16_small(segvlad_ctx* ctx, const float* X, int64_t n_elems,
 int sv_launch_to_f16_devscale(segvlad_ctx* ctx, const float* X, int64_t n_elems, const float* scales_dev, uint16_t* out);
 int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,
-                         float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap);
+                         float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap, int skip = 0);
+// skip = 16: the operand rows are the database rows that are NOT multiples of 16, in order (n_sample of them; b_stride = 1)
+bool sv_f16_filter_skip_ok(const segvlad_ctx* ctx, int M, int64_t n_rows, int d);
 
 // select_kernels.hip
 // top-k of per-query candidate lists (LDS sort on (distance, id)); a list longer than cap flags its query row in

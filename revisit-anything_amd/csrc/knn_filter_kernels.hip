@@ -538,7 +538,7 @@ typedef int sv_rsrc_t;
 //      of this kernel's byte : flop ratio; the deep-row kernel 126.4 -> 125.2 ms; the ping-pong batch kernel 18.19 -> 18.70 ms
 //      (slower: its default stays global_load_lds).
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0, int SKIP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total, int walk,
@@ -572,6 +572,14 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS DMA bases live in M0
   const int wm = w / WN, wn = w % WN;
   const int64_t ldb = (int64_t)d * b_stride;
+  // SKIP > 0 ("the complement of a sample"): operand row j is database row j + j / (SKIP - 1) + 1 -- the rows that are NOT multiples
+  // of SKIP, in order.  The level before the last one has already filtered the multiples of SKIP (its stride-SKIP sample) with the same
+  // arithmetic; its survivors stay in the candidate lists (select mode 0 with carry) and the last level does not compute them again.
+  auto grow = [&](int64_t j) -> int64_t {
+    if constexpr (SKIP > 0) return j + (int64_t)((uint32_t)j / (uint32_t)(SKIP - 1)) + 1;
+    else return j * b_stride;
+  };
+  const int64_t ldr = (int64_t)d;   // fp16 elements per database row: operand row j starts at Rh + grow(j) * ldr
   const int ntiles = d / HBK;
   const int tiles_n = (N + BN - 1) / BN;
   auto swz = [](int r, int c) { return CH == 8 ? (c ^ ((r >> 1) & 7)) : (c ^ ((r >> 2) & 3)); };
@@ -664,6 +672,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   auto voff_b = [&](int64_t n0_, int j) -> unsigned {
     const int row = (w * JB + j) * RP + lrow_p;
     const int rr = (n0_ + row < N) ? row : (int)((int64_t)N - 1 - n0_);
+    if constexpr (SKIP > 0) return (unsigned)(grow(n0_ + rr) - grow(n0_)) * (unsigned)(d * 2) + 16u * (unsigned)swz(row, lch);
     return (unsigned)rr * (unsigned)(ldb * 2) + 16u * (unsigned)swz(row, lch);
   };
   auto rsrc_of = [](const uint16_t* base) -> sv_rsrc_t { return SV_BUF_RSRC(base); };
@@ -671,7 +680,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const int64_t m0_ = (int64_t)tm_ * BM, n0_ = (int64_t)tn_ * BN;
     const int k0_ = kofs(rev_, 0), k1_ = kofs(rev_, 1);
     if constexpr (BUF) {
-      const sv_rsrc_t ra = rsrc_of(Qh + m0_ * d), rb_ = rsrc_of(Rh + n0_ * ldb);
+      const sv_rsrc_t ra = rsrc_of(Qh + m0_ * d), rb_ = rsrc_of(Rh + grow(n0_) * ldr);
 #pragma unroll
       for (int j = 0; j < JA; ++j)
         SV_BUF_LOAD_LDS(ra, (lptr_t)(lds + a_off(0) + (w * JA + j) * 1024), voff_a(m0_, j), 2 * k0_, AUXA);
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     for (int j = 0; j < JB; ++j) {
       const int row = (w * JB + j) * RP + lrow_p;
       const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch) + k0_), (lptr_t)(lds + b_off(0) + (w * JB + j) * 1024), 16,
+      __builtin_amdgcn_global_load_lds((gptr_t)(Rh + grow(rb) * ldr + 8 * swz(row, lch) + k0_), (lptr_t)(lds + b_off(0) + (w * JB + j) * 1024), 16,
                                        0, AUXB);
     }
     if (NB == 3 && ntiles > 1) {
@@ -706,7 +715,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       for (int j = 0; j < JB; ++j) {
         const int row = (w * JB + j) * RP + lrow_p;
         const int64_t rb = (n0_ + row < N) ? (n0_ + row) : (int64_t)(N - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(Rh + rb * ldb + 8 * swz(row, lch) + k1_),
+        __builtin_amdgcn_global_load_lds((gptr_t)(Rh + grow(rb) * ldr + 8 * swz(row, lch) + k1_),
                                          (lptr_t)(lds + b_off(1) + (w * JB + j) * 1024), 16, 0, AUXB);
       }
     }
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
     for (int nt = 0; nt < NCN; ++nt) {
       const int64_t colj = (int64_t)tn_ * BN + wn * (32 * TN) + nt * CW + (threadIdx.x & (CW - 1));
-      cnn[nt] = (colj < N) ? rn[colj * b_stride] : INFINITY;  // +inf: columns beyond N never pass
+      cnn[nt] = (colj < N) ? rn[grow(colj)] : INFINITY;  // +inf: columns beyond N never pass
     }
   };
   if (BIAS) load_cn(tn);
@@ -805,7 +814,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
       const int64_t colj = n0 + wn * (32 * TN) + nt * 32 + i;
-      cn[nt] = (colj < N) ? rn[colj * b_stride] : INFINITY;  // +inf: columns beyond N never pass
+      cn[nt] = (colj < N) ? rn[grow(colj)] : INFINITY;  // +inf: columns beyond N never pass
     }
   }
 
@@ -813,7 +822,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   const uint16_t* srcA[BUF ? 1 : JA];
   const uint16_t* srcB[BUF ? 1 : JB];
   unsigned voA[BUF ? JA : 1], voB[BUF ? JB : 1];
-  const sv_rsrc_t rsA = rsrc_of(Qh + m0 * d), rsB = rsrc_of(Rh + n0 * ldb);
+  const sv_rsrc_t rsA = rsrc_of(Qh + m0 * d), rsB = rsrc_of(Rh + grow(n0) * ldr);
   if constexpr (BUF) {
 #pragma unroll
     for (int j = 0; j < JA; ++j) voA[j] = voff_a(m0, j);
@@ -830,7 +839,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     for (int j = 0; j < JB; ++j) {
       const int row = (w * JB + j) * RP + lrow_p;
       const int64_t rb = (n0 + row < N) ? (n0 + row) : (int64_t)(N - 1);
-      srcB[j] = Rh + rb * ldb + 8 * swz(row, lch);
+      srcB[j] = Rh + grow(rb) * ldr + 8 * swz(row, lch);
     }
   }
   constexpr int BAHEAD = NB - 1;  // how many k-tiles ahead the B DMA runs (A always runs one ahead)
@@ -1431,7 +1440,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
             if (slot < (uint32_t)cap) {
               const int64_t row = rowbase + (int64_t)lrow;
               cand_d2[row * cap + slot] = __uint_as_float(rec.x);
-              cand_id[row * cap + slot] = (uint32_t)((n0 + (int64_t)(rec.y & 0xffu)) * b_stride);
+              cand_id[row * cap + slot] = (uint32_t)grow(n0 + (int64_t)(rec.y & 0xffu));
             }
           }
         }
@@ -1639,7 +1648,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
       if (slot < (uint32_t)cap) {
         const int64_t row = m0 + lrow;
         cand_d2[row * cap + slot] = __uint_as_float(rec.x);
-        cand_id[row * cap + slot] = (uint32_t)((n0 + (int64_t)(rec.y & 0xffffu)) * b_stride);
+        cand_id[row * cap + slot] = (uint32_t)grow(n0 + (int64_t)(rec.y & 0xffffu));
       }
     }
   }
@@ -1662,7 +1671,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
               if (slot < (uint32_t)cap) {
                 const int64_t row = m0 + lrow;
                 cand_d2[row * cap + slot] = v;
-                cand_id[row * cap + slot] = (uint32_t)((n0 + wn * (32 * TN) + nt * 32 + i) * b_stride);
+                cand_id[row * cap + slot] = (uint32_t)grow(n0 + wn * (32 * TN) + nt * 32 + i);
               }
             }
           }
@@ -1681,7 +1690,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 }
 
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0, int SKIP = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1722,7 +1731,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF, BUF, DSPLIT>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF, BUF, DSPLIT, SKIP>;
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
@@ -1732,11 +1741,33 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   return SEGVLAD_OK;
 }
 
+// Can the LAST level of a batch search run over the complement of the stride-16 sample (skip = 16)?  Only the two default batch
+// kernels have that form; the answer mirrors sv_launch_f16_filter's choice for (M, n_rows, d) under the context's options.
+bool sv_f16_filter_skip_ok(const segvlad_ctx* ctx, int M, int64_t n_rows, int d) {
+  const SvOptions& o = ctx->opt;
+  if (!o.level_carry || M <= 128 || n_rows <= 0 || !ctx->f16_bias_ok || o.f16_mf == 0 || o.f16_epi == 0) return false;
+  if (sv_f16_kblock(o, d)) return o.f16_deep_cfg < 0 || o.f16_deep_cfg == 4;
+  if (o.f16_cfg >= 0 && o.f16_cfg != 250) return false;
+  if (o.f16_pp == 0 || o.f16_dsplit != 0 || o.f16_buf == 1) return false;   // (the A/B variants of the batch kernel)
+  return (int64_t)((M + 255) / 256) * ((n_rows + 255) / 256) >= 1024;
+}
+
 int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                          float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld, float eps_mult,
-                         float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap) {
+                         float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int cap, int skip) {
   if (M <= 0 || n_sample <= 0) return SEGVLAD_OK;
 #define SV_F16_ARGS ctx, Qh, Rh, M, n_sample, d, b_stride, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap
+  if (skip) {
+    // operand row j = database row j + j / 15 + 1 (n_sample = the number of rows that are not multiples of 16): see the kernel's SKIP
+    if (skip != 16 || b_stride != 1 || !sv_f16_filter_skip_ok(ctx, M, n_sample, d))
+      return ctx->fail(SEGVLAD_ERR_STATE, "f16 filter: no complement-of-sample form for this configuration");
+    if (sv_f16_kblock(ctx->opt, d)) {
+      if (ctx->opt.f16_buf != 0 && (int64_t)256 * d * 2 * 2 + 4096 < (int64_t)0xffffffffLL)
+        return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1, true, 0, 16>(SV_F16_ARGS);
+      return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1, false, 0, 16>(SV_F16_ARGS);
+    }
+    return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 0, 16>(SV_F16_ARGS);
+  }
   // tile configuration: option "f16_cfg" (default chosen from measurements)
   // r02 measurements (10 000 x 1 M x 1024, random unit vectors, filter launches only): 0 -> 22.5 ms, 50 (ping-pong) -> 21.7,
   // 200 (persistent) -> 21.7, 250 (persistent + ping-pong) -> 21.5; HBK = 32 variants (4, 1) 24.1 / 25.3
@@ -1912,8 +1943,8 @@ __device__ __forceinline__ void hist_add_(uint32_t* hist, bool active, uint32_t 
 // yields A_k, the k-th smallest approximate distance (+inf if fewer than k candidates).
 //   mode 0: thr_out[q] = A_k
 //   mode 1: refine list = ids with d2~ <= A_k + 2 eps(q) (unordered; at most rcap, more -> the row is flagged in ovf_rows)
-__global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
-                                                            const uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
+__global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict__ cnt, float* __restrict__ cd2,
+                                                            uint32_t* __restrict__ cid, int cap, int k, int mode, int check,
                                                             const float* __restrict__ thr_in, int64_t thr_in_ld,
                                                             const float* __restrict__ qn, float c_eps, float rn_max,
                                                             float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
@@ -1934,12 +1965,12 @@ __global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict
   __shared__ uint32_t s_c;
   if (tid == 0) {
     s_c = cnt[row];
-    if (mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero (no memset launch between the levels)
+    if (mode != 1) cnt[row] = 0u;   // the next level's filter appends from zero (no memset launch between the levels); mode 2: below
   }
   __syncthreads();
   const uint32_t c = s_c;
   // the threshold this list was collected under (read before thr_out -- possibly the same word -- is overwritten)
-  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  const float t_in = ((check && mode == 1) || mode == 2) ? thr_in[row * thr_in_ld] : 0.f;
   auto flag_row = [&]() {
     // this query is redone later (rigorous thresholds / exact matrix path): a threshold of -inf keeps its candidate
     // list empty at the finer levels, an empty refine list makes the refinement a no-op
@@ -1994,6 +2025,29 @@ __global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict
     if (tid == 0) thr_out[row] = ak;
     return;
   }
+  if (mode == 2) {   // carry (see select_small_body): in place, 256 entries at a time -- a chunk's survivors land below its own start + 256
+    const float t2 = fminf(ak, t_in);
+    const float lim2 = t2 + 2.f * c_eps * sqrtf(qn[row] * rn_max);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < (int)c; j0 += 256) {
+      const int j = j0 + tid;
+      const float v = (j < (int)c) ? key2f_(keys[j]) : INFINITY;
+      const uint32_t id = (j < (int)c) ? cid[row * cap + j] : 0u;
+      __syncthreads();   // the chunk is in registers
+      if (j < (int)c && v <= lim2) {
+        const uint32_t pos = atomicAdd(&s_n, 1u);
+        cd2[row * cap + pos] = v;
+        cid[row * cap + pos] = id;
+      }
+      __syncthreads();   // (the next chunk's reads start at j0 + 256 >= every position written so far)
+    }
+    if (tid == 0) {
+      thr_out[row] = t2;
+      cnt[row] = s_n;
+    }
+    return;
+  }
   // heuristic thresholds: the list holds every row with d2~ <= t_in + 2 eps; the refine set {d2~ <= A_k + 2 eps} is
   // contained in it iff A_k <= t_in
   if (check && !(ak <= t_in)) {
@@ -2037,7 +2091,7 @@ __global__ __launch_bounds__(256) void select_approx_kernel(uint32_t* __restrict
 // select_small_body: the ranking itself for lists of at most 64 * PER keys (PER register slots per lane, loops fully
 // unrolled: a run-time bound on the slot loops cost a scalar branch per slot and bit -- 40 us per launch).
 template <int PER>
-__device__ __forceinline__ void select_small_body(const float* __restrict__ cd2, const uint32_t* __restrict__ cid, int64_t row, int l,
+__device__ __forceinline__ void select_small_body(uint32_t* __restrict__ cnt, float* __restrict__ cd2, uint32_t* __restrict__ cid, int64_t row, int l,
                                                   uint32_t c, int cap, int k, int mode, int check, float t_in,
                                                   const float* __restrict__ qn, float c_eps, float rn_max,
                                                   float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
@@ -2062,7 +2116,7 @@ __device__ __forceinline__ void select_small_body(const float* __restrict__ cd2,
       key[i] = f2key_(cd2[row * cap + j]);
       // mode 1: the ids travel with the keys (fetched behind a ballot branch, slot by slot, each was a round trip of its own:
       // 12 of the 19 us of a pass's last select)
-      if (mode == 1) cidv[i] = cid[row * cap + j];
+      if (mode != 0) cidv[i] = cid[row * cap + j];
     }
   }
   float ak = INFINITY;
@@ -2116,6 +2170,34 @@ __device__ __forceinline__ void select_small_body(const float* __restrict__ cd2,
   }
   if (mode == 0) {
     if (l == 0) thr_out[row] = ak;
+    return;
+  }
+  if (mode == 2) {
+    // carry: the next level runs over the rows this level has NOT seen (the complement of its sample), under the threshold
+    // t2 = min(A_k, t_in).  This list holds every sampled row with d2~ <= t_in + 2 eps, hence every one with d2~ <= t2 + 2 eps --
+    // exactly the rows the next level's filter would append for the sample: they are compacted to the front and the counter is
+    // left at their number.  (A threshold below A_k is as good a guess as A_k: the last level's check is against the value stored.)
+    const float t2 = fminf(ak, t_in);
+    const float lim2 = t2 + 2.f * c_eps * sqrtf(qn[row] * rn_max);
+    uint32_t kept = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const float v = key2f_(key[i]);
+      const bool hit = key[i] != PAD && v <= lim2;
+      const uint64_t mk = __builtin_amdgcn_ballot_w64(hit);
+      if (mk != 0ull) {
+        const uint32_t pos = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        if (hit) {   // (every key of the list is in registers: writing in place races with nothing)
+          cd2[row * cap + pos] = v;
+          cid[row * cap + pos] = cidv[i];
+        }
+        kept += (uint32_t)__popcll(mk);
+      }
+    }
+    if (l == 0) {
+      thr_out[row] = t2;
+      cnt[row] = kept;
+    }
     return;
   }
   if (check && !(ak <= t_in)) {
@@ -2400,8 +2482,8 @@ int sv_launch_l0_reduce_rank(segvlad_ctx* ctx, const float* parts, int splits, i
   return SEGVLAD_OK;
 }
 
-__global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict__ cnt, const float* __restrict__ cd2,
-                                                           const uint32_t* __restrict__ cid, int nq, int cap, int k, int mode, int check,
+__global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict__ cnt, float* __restrict__ cd2,
+                                                           uint32_t* __restrict__ cid, int nq, int cap, int k, int mode, int check,
                                                            const float* __restrict__ thr_in, int64_t thr_in_ld,
                                                            const float* __restrict__ qn, float c_eps, float rn_max,
                                                            float* __restrict__ thr_out, uint32_t* __restrict__ ref_cnt,
@@ -2420,9 +2502,9 @@ __global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict_
   }
   if (l == 0) {
     if (todo) todo[row] = 0u;
-    if (mode == 0) cnt[row] = 0u;   // the next level's filter appends from zero (no memset launch between the levels)
+    if (mode != 1) cnt[row] = 0u;   // the next level's filter appends from zero (no memset launch between the levels); mode 2: see the body
   }
-  const float t_in = (check && mode == 1) ? thr_in[row * thr_in_ld] : 0.f;
+  const float t_in = ((check && mode == 1) || mode == 2) ? thr_in[row * thr_in_ld] : 0.f;
   auto flag_row = [&]() {
     if (l == 0) {
       if (atomicExch(&ovf_rows[row], 1u) == 0u) atomicAdd(ovf_count, 1u);
@@ -2437,25 +2519,26 @@ __global__ __launch_bounds__(256) void select_small_kernel(uint32_t* __restrict_
     return;
   }
   if (c <= 256u)
-    select_small_body<4>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+    select_small_body<4>(cnt, cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
                          ovf_count, rovf_rows, rovf_count, ref_lim);
   else if (c <= 1024u)
-    select_small_body<16>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+    select_small_body<16>(cnt, cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
                           ovf_count, rovf_rows, rovf_count, ref_lim);
   else if (c <= 2048u)
-    select_small_body<32>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+    select_small_body<32>(cnt, cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
                           ovf_count, rovf_rows, rovf_count, ref_lim);
   else
-    select_small_body<64>(cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
+    select_small_body<64>(cnt, cd2, cid, row, l, c, cap, k, mode, check, t_in, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, ovf_rows,
                           ovf_count, rovf_rows, rovf_count, ref_lim);
 }
 
-int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, const float* cand_d2, const uint32_t* cand_id, int nq,
+int sv_launch_select_approx(segvlad_ctx* ctx, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id, int nq,
                             int cap, int rank, int mode, int check, const float* thr_in, int64_t thr_in_ld, const float* qn,
                             float c_eps, float rn_max, float* thr_out, uint32_t* ref_cnt, uint32_t* ref_id, int rcap,
                             uint32_t* fail_rows, uint32_t* fail_count, uint32_t* rovf_rows, uint32_t* rovf_count, float* ref_lim,
                             int fixed_cnt) {
   if (nq <= 0) return SEGVLAD_OK;
+  if (mode == 2 && nq <= 128) return ctx->fail(SEGVLAD_ERR_STATE, "select: the carrying form exists for batches only");
   if (nq <= 128) {   // one query image per pass: a workgroup per list
     hipLaunchKernelGGL(select_wg_kernel, dim3(nq), dim3(256), 0, ctx->stream, cand_cnt, cand_d2, cand_id, cap, rank, mode, check, thr_in,
                        thr_in_ld, qn, c_eps, rn_max, thr_out, ref_cnt, ref_id, rcap, fail_rows, fail_count, rovf_rows, rovf_count,

@@ -31,6 +31,8 @@
  *     "pj_nw"         8 | 4   waves per workgroup of the P-space aggregation
  *     "x3_tile", "x3_gm", "agg_kpb", "assign_narrow"   tile / order / geometry of the projection GEMM, the descriptor
  *                     aggregation and the assignment kernel
+ *     "level_carry"   1 | 0   batch searches (guessed thresholds): the last filter level skips the rows of the stride-16 level, whose
+ *                             survivors stay in the candidate lists | every level from empty lists over all of its rows
  *     "batch_l0_f16"  1 | 0   batch searches (guessed thresholds): the sampled level from the filter's own fp16 product | the exact fp32 GEMM
  *   single-image passes (small_pass_kernels.hip)
  *     "small_head"    1 | 0 | 3   the pass starts with small_head_kernel: plane, scale, norms, flags and the sample thresholds (from the

@@ -108,10 +108,10 @@ class SegVLADEngine:
 
     def search_stats(self) -> dict:
         """Statistics of the last search(): levels, filter arithmetic, rows redone on the exact path, list occupancies."""
-        v = (C.c_int64 * 12)()
-        self._check(self.lib.segvlad_search_stats(self._h, v, 12), "search_stats")
+        v = (C.c_int64 * 13)()
+        self._check(self.lib.segvlad_search_stats(self._h, v, 13), "search_stats")
         names = ("levels", "filter", "n_fallback", "cand_max", "cand_sum", "refine_max", "refine_sum", "n_queries", "n_redo",
-                 "n_refine2", "grp_groups", "grp_union_sum")
+                 "n_refine2", "grp_groups", "grp_union_sum", "carry_rows")
         d = dict(zip(names, [int(x) for x in v]))
         d["filter"] = {0: "none", 1: "f16", 2: "bf16x3", 3: "fp32"}[d["filter"]]
         return d
