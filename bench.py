@@ -628,7 +628,17 @@ def run(a, top=True):
         else:
             ach, peak, unit_note = f32_equiv, PEAK_F32_MFMA_TFLOPS, "fp32 MFMA"
         traffic, mfma_util, traffic_src = pmc_counters(kern.split(" ")[0], wl_key)
+        executed = None
+        if key == "knn_gemm" and sstats.get("levels", 0) >= 1:
+            # rows the filter launches of one step actually multiplied: the levels' strided samples + the last level (all rows, or --
+            # level_carry -- the rows the stride-16 level has not seen); `achieved` stays ALGORITHMIC (every pair counted once)
+            lv = int(sstats["levels"])
+            rows_exec = sum(-(-n_local_rows // 16 ** j) for j in range(lv)) - int(sstats.get("carry_rows", 0))
+            executed = {"filter_rows_per_step": rows_exec, "vs_algorithmic": rows_exec / max(n_local_rows, 1),
+                        "carry_rows": int(sstats.get("carry_rows", 0)),
+                        "executed_tflops": 2.0 * nQ * S * rows_exec * d_knn * eng_filter_products() / (stages[key]["ms_per_step"] * 1e-3) / 1e12}
         roof = {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "executed": executed,
                 "traffic": traffic, "mfma_util": mfma_util, "traffic_source": traffic_src, "avg_launch_ms": avg_ms,
                 "launches_per_step": launches, "dominant_stage": dom,
                 "arithmetic": unit_note, "fp32_equivalent_tflops": f32_equiv,

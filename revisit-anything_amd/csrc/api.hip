@@ -322,6 +322,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "small_head")) return as_int(&o.small_head);
   if (!strcmp(key, "batch_l0_f16")) return as_int(&o.batch_l0_f16);
   if (!strcmp(key, "level_carry")) return as_int(&o.level_carry);
+  if (!strcmp(key, "f16_persist_wgs")) return as_int(&o.f16_persist_wgs);
   if (!strcmp(key, "debug_small_tail")) return as_int(&o.debug_small_tail);
   if (!strcmp(key, "refine_group")) return as_int(&o.refine_group);
   if (!strcmp(key, "query_group")) return as_int(&o.query_group);
@@ -1371,7 +1372,7 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
   const uint32_t* poison_dev = nullptr;   // see sv_launch_refine_exact
   bool tail_fused = false;                // the refinement kernel finished the flagged rows itself (no small_tail_kernel)
   const int r0 = rank[0];
-  bool l0_fused = false;
+  bool l0_fused = false, l0_lists = false;
   if (phase != 2) {  // level 0: exact (fp32) top-r0 of the coarsest sample -> thr[q][r0-1]
     {
       StageScope sc(ctx, "knn_level0");   // its own stage: "knn_gemm" then times the filter kernel's launches only
@@ -1387,6 +1388,19 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
           sc.count();
           l0_fused = true;
         }
+      } else if (heuristic && pl.kind == 1 && m > 128 && n0 <= 4096 && q16a && ctx->opt.batch_l0_f16 && !ctx->f16_scale_dev &&
+                 sv_f16_kblock(ctx->opt, d) && ctx->opt.batch_l0_f16 != 2) {
+        // deep rows (raw K*D descriptors): the sample through the FILTER KERNEL under thresholds of +inf -- every sampled row lands in
+        // the candidate lists (n0 <= 4096 entries per query), the mode-0 select below ranks them like any level's.  The no-LDS sample
+        // kernel re-reads the query plane (2 GB at 10 000 x 98 304: not L2 resident) once per 32 sample rows: 8.5 ms for 196 rows,
+        // against ~0.6 ms at the filter's rate.
+        SV_HIP(hipMemsetD32Async((hipDeviceptr_t)thr, 0x7f800000, (size_t)m, ctx->stream));
+        SV_HIP(hipMemsetAsync(ctx->s_cand_cnt.p, 0, (size_t)m * 4, ctx->stream));
+        SV_TRY(sv_launch_f16_filter(ctx, q16a, ctx->db_f16.as<uint16_t>(), m, (int)n0, d, (int)pl.stride0, pl.inv_scale, qn, rn, thr, 1, 2.f,
+                                    pl.c_eps, pl.rn_max, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(),
+                                    ctx->s_cand_id.as<uint32_t>(), SV_CAP));
+        sc.count();
+        l0_lists = true;
       } else if (heuristic && pl.kind == 1 && m > 128 && n0 <= 4096 && q16a && ctx->opt.batch_l0_f16 && !ctx->f16_scale_dev) {
         // round 6: a guessed threshold needs no exact distances -- the sample through the filter's own fp16 product (~15 us instead
         // of 115-160 us of poorly filled fp32 MFMA tiles); the thresholds are then approximate-domain values like every later level's
@@ -1401,6 +1415,10 @@ static int levels_chunk(segvlad_ctx* ctx, const SearchPlan& pl, bool heuristic, 
     StageScope sc(ctx, "knn_select");
     if (l0_fused) {
       // (thr[q] is in place)
+    } else if (l0_lists) {
+      SV_TRY(sv_launch_select_approx(ctx, ctx->s_cand_cnt.as<uint32_t>(), ctx->s_cand_d2.as<float>(), ctx->s_cand_id.as<uint32_t>(), m,
+                                     SV_CAP, r0, 0, 1, nullptr, 0, qn, pl.c_eps, pl.rn_max, thr, ctx->s_ref_cnt.as<uint32_t>(),
+                                     ctx->s_ref_id.as<uint32_t>(), SV_RCAP, fail_rows, fail_count));
     } else if (n0 <= 4096 && pl.kind != 3) {
       // a short sample row: only its r0-th smallest distance is needed -- the wave-per-query register select of the
       // candidate lists (mode 0: thr[q] = rank-th smallest), the distance block standing in for a list of n0 entries

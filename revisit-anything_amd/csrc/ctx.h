@@ -137,6 +137,8 @@ struct SvOptions {
   int f16_walk = -1;      // tile walk of the persistent fp16 filter: bit 0 = an XCD keeps its block of query tiles while it steps
                           // through the database blocks, bit 1 = odd steps run their k-tiles backwards (-1 = default = 3, see
                           // launch_f16_filter); never changes a result
+  int f16_persist_wgs = 32;   // resident workgroups per XCD of the persistent batch filter (1 .. 32): fewer leave CUs free for the whole
+                          // launch to kernels of OTHER streams (the next batch's describe stage, bench.py --pipeline); never changes a result
   int f16_mf = -1;        // MFMA shape of the persistent biased fp16 filter: 0 = 32 x 32 x 16, otherwise 16 x 16 x 32 (needs f16_epi != 0)
   int f16_deep_cfg = -1;  // deep rows (blocked accumulation): -1 / 4 = 8 waves of 64 x 64 on 256 x 128 tiles, 16 x 16 x 32 MFMA, plain loop;
                           // 0 = 4 waves of 64 x 64 on 128 x 128 tiles, 32 x 32 x 16 MFMA (rounds 2-3); 1, 2, 3: measured variants
@@ -164,6 +166,7 @@ struct SvOptions {
   int debug_small_tail = 0;   // tests only: bit 0 = every row of a device-driven pass is flagged for the tail's brute force, bit 1 = every
                               // row's band is sent to its second tier, bit 2 = the hand-over's sticky failure word is raised
   int batch_l0_f16 = 1;   // batch searches on the fp16 filter with guessed thresholds: the sampled level from the filter's own fp16 product
+                          // (deep rows: through the filter kernel itself under +inf thresholds; 2 = the sample kernel there too, A/B)
                           // (sample_f16_batch_kernel) instead of the exact fp32 GEMM; 0 = rounds 2-5
   int level_carry = 1;    // batch searches, guessed thresholds, fp16 filter: the last level runs over the rows the stride-16 level has not
                           // seen and that level's survivors stay in the candidate lists (1/16 of the full-level GEMM saved); 0 = every

@@ -645,8 +645,11 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   };
   int tm, tn;
   int seq = (int)(blockIdx.x >> 3);
+  // PERSIST: resident workgroups per XCD = the stride of a workgroup through its XCD's sequence (bits 8.. of `walk`; 32 = one per
+  // CU.  Fewer leave CUs to kernels of other streams -- the describe stage of the next batch -- for the whole launch: option f16_persist_wgs)
+  const int pstep = (walk >> 8) > 0 ? (walk >> 8) : 32;
   if (PERSIST) {
-    while (seq < seq_total && !tile_of(seq, tm, tn)) seq += 32;
+    while (seq < seq_total && !tile_of(seq, tm, tn)) seq += pstep;
     if (seq >= seq_total) return;
   } else if (gm > 0) {
     if (!tile_of(seq, tm, tn)) return;
@@ -1282,8 +1285,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     if (t == 12345.678f) cand_cnt[0] = 1;
     if (!PERSIST) return;
     // persistent ablations: on to the workgroup's next tile (its head requested here, waited for at once)
-    int tm_n = 0, tn_n = 0, sq_n = seq + 32;
-    while (sq_n < seq_total && !tile_of(sq_n, tm_n, tn_n)) sq_n += 32;
+    int tm_n = 0, tn_n = 0, sq_n = seq + pstep;
+    while (sq_n < seq_total && !tile_of(sq_n, tm_n, tn_n)) sq_n += pstep;
     if (sq_n >= seq_total) return;
     if (BIAS) load_cn(tn_n);
     if (ABL != 3) issue_head(tm_n, tn_n, rev_of(sq_n));
@@ -1313,8 +1316,8 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   // PERSIST: the next tile of this workgroup; its head is requested now and lands under the epilogue
   int tm_next = 0, tn_next = 0, seq_next = seq_total;
   if (PERSIST) {
-    seq_next = seq + 32;
-    while (seq_next < seq_total && !tile_of(seq_next, tm_next, tn_next)) seq_next += 32;
+    seq_next = seq + pstep;
+    while (seq_next < seq_total && !tile_of(seq_next, tm_next, tn_next)) seq_next += pstep;
     if (seq_next < seq_total) {
       if (BIAS) load_cn(tn_next);
       issue_head(tm_next, tn_next, rev_of(seq_next));
@@ -1708,7 +1711,9 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   // default 3: measured on 10 000 x 1 M x 1024 (rocprofv3 FETCH_SIZE, calibrated; tools/pmc_walk.sh): L2 fills of the full-level
   // launch 42.7 GB (walk 0) / 45.1 GB (2: serpentine alone) / 26.3 GB (3), at the same speed (18.39 / 18.34 ms per search's filter
   // launches, interleaved A/B)
-  const int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 7) : 3) : 0;
+  int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 7) : 3) : 0;
+  const int pwgs = (ctx->opt.f16_persist_wgs >= 1 && ctx->opt.f16_persist_wgs <= 32) ? ctx->opt.f16_persist_wgs : 32;
+  if (PERSIST) walk |= pwgs << 8;
   if (gm > 0) {
     gm = gm >= 32 ? 32 : gm >= 16 ? 16 : gm >= 8 ? 8 : gm >= 4 ? 4 : gm >= 2 ? 2 : 1;
     while (gm > 1 && gm / 2 >= tiles_m) gm >>= 1;
@@ -1721,7 +1726,7 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     tiles = (st + 7) / 8 * 8 * 32;
     if (tiles / 8 > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
     seq_total = (int)(tiles / 8);
-    if (PERSIST) tiles = 256;   // 8 XCDs x 32 resident workgroups, each walks its XCD's sequence
+    if (PERSIST) tiles = 8 * pwgs;   // 8 XCDs x 32 (option f16_persist_wgs) resident workgroups, each walks its XCD's sequence
   }
   if (tiles > 0x7fffffffLL) return ctx->fail(SEGVLAD_ERR_LIMIT, "f16 filter: too many tiles");
   size_t lds = 2 * (size_t)BM * HBK * 2 + (size_t)NB * BN * HBK * 2;  // two A stages + NB B stages

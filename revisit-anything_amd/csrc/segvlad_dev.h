@@ -31,9 +31,11 @@
  *     "pj_nw"         8 | 4   waves per workgroup of the P-space aggregation
  *     "x3_tile", "x3_gm", "agg_kpb", "assign_narrow"   tile / order / geometry of the projection GEMM, the descriptor
  *                     aggregation and the assignment kernel
+ *     "f16_persist_wgs" 1..32 resident workgroups per XCD of the persistent batch filter (32 = every CU; fewer leave CUs to other streams)
  *     "level_carry"   1 | 0   batch searches (guessed thresholds): the last filter level skips the rows of the stride-16 level, whose
  *                             survivors stay in the candidate lists | every level from empty lists over all of its rows
  *     "batch_l0_f16"  1 | 0   batch searches (guessed thresholds): the sampled level from the filter's own fp16 product | the exact fp32 GEMM
+ *                             (2: deep rows through sample_f16_batch_kernel instead of the filter kernel under +inf thresholds, A/B)
  *   single-image passes (small_pass_kernels.hip)
  *     "small_head"    1 | 0 | 3   the pass starts with small_head_kernel: plane, scale, norms, flags and the sample thresholds (from the
  *                     filter's own fp16 product) in one launch | query preparation -> exact fp32 sample level -> reduce + rank |
