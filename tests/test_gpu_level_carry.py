@@ -128,3 +128,42 @@ def test_complement_level_two_chunks_and_a_rigorous_redo(eng):
         eng.set_option("level_carry", 1)
     print("clumps of 40:", st)
     assert torch.equal(idc, idp) and torch.equal(d2c, d2p) and torch.equal(idc, idf) and torch.equal(d2c, d2f)
+
+
+def test_complement_level_with_carried_lists_beyond_the_wave_select(eng):
+    """5000 sampled rows (multiples of 16) and 1000 rows of the complement are near-copies of one vector: the stride-16 level's lists of
+    the queries near it hold > 4096 entries -- the workgroup form of the carrying select (select_approx_kernel, mode 2: in-place
+    compaction in chunks) -- the last level appends the complement's copies behind them, the band outgrows the first refinement tier
+    (second tier from the candidate list).  Same (d2, ids) as the plain levels and as the fp32 filter."""
+    import torch
+
+    d, n, k = 256, 300000, 50
+    R, g = _rows(n, d, 9300)
+    dev = R.device
+    v0 = torch.nn.functional.normalize(torch.randn(1, d, device=dev, generator=g), dim=1)
+    on = 16 * torch.randperm(n // 16, device=dev, generator=g)[:5000]
+    off = 16 * torch.randperm(n // 16, device=dev, generator=g)[:1000] + 3
+    R[on] = torch.nn.functional.normalize(v0 + (1e-3 / d ** 0.5) * torch.randn(5000, d, device=dev, generator=g), dim=1)
+    R[off] = torch.nn.functional.normalize(v0 + (1e-3 / d ** 0.5) * torch.randn(1000, d, device=dev, generator=g), dim=1)
+    Q, _, _ = _queries(R, g, 300, 1.0)
+    Q[:12] = torch.nn.functional.normalize(v0 + (1e-3 / d ** 0.5) * torch.randn(12, d, device=dev, generator=g), dim=1)
+    Q = Q.contiguous()
+    eng.db_reset()
+    eng.db_add(R)
+    try:
+        eng.set_option("search_stats", 1)
+        d2c, idc = eng.search(Q, k)
+        stc = eng.search_stats()
+        eng.set_option("level_carry", 0)
+        d2p, idp = eng.search(Q, k)
+        eng.set_option("knn_filter", "fp32")
+        d2f, idf = eng.search(Q, k)
+    finally:
+        eng.set_option("knn_filter", "auto")
+        eng.set_option("level_carry", 1)
+        eng.set_option("search_stats", 0)
+    print("long carried lists:", stc)
+    assert stc["carry_rows"] == (n + 15) // 16 and 5900 <= stc["cand_max"] <= 8192 and stc["n_fallback"] == 0 and stc["n_refine2"] >= 12, stc
+    assert torch.equal(idc, idp) and torch.equal(d2c, d2p) and torch.equal(idc, idf) and torch.equal(d2c, d2f)
+    near = set(on.tolist()) | set(off.tolist())
+    assert all(int(i) in near for i in idc[:12].reshape(-1).tolist())
