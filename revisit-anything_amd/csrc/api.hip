@@ -302,7 +302,7 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "f16_walk")) return as_int(&o.f16_walk);
   if (!strcmp(key, "f16_epi")) return as_dev(&o.f16_epi, {-1, 1});
   if (!strcmp(key, "f16_mf")) return as_dev(&o.f16_mf, {-1, 1});
-  if (!strcmp(key, "f16_deep_cfg")) return as_dev(&o.f16_deep_cfg, {-1, 4});
+  if (!strcmp(key, "f16_deep_cfg")) return as_dev(&o.f16_deep_cfg, {-1, 4, 5});
   if (!strcmp(key, "f16_pp")) return as_dev(&o.f16_pp, {-1, 2});
   if (!strcmp(key, "f16_small_mf")) return as_dev(&o.f16_small_mf, {0});
   if (!strcmp(key, "f16_buf")) return as_dev(&o.f16_buf, {-1, 0});
@@ -1916,7 +1916,7 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
         }
       }
     }
-    pl.c_eps = sv_f16_c_eps(d, sv_f16_kblock(ctx->opt, d), bias_mult);
+    pl.c_eps = sv_f16_c_eps(d, sv_f16_eps_kblock(ctx->opt, d), bias_mult);
   } else if (bf16_path) {
     // lazily extend the bf16 planes to the rows added since the last search
     if (ctx->db_split_rows < n) {

@@ -140,7 +140,8 @@ struct SvOptions {
   int f16_persist_wgs = 32;   // resident workgroups per XCD of the persistent batch filter (1 .. 32): fewer leave CUs free for the whole
                           // launch to kernels of OTHER streams (the next batch's describe stage, bench.py --pipeline); never changes a result
   int f16_mf = -1;        // MFMA shape of the persistent biased fp16 filter: 0 = 32 x 32 x 16, otherwise 16 x 16 x 32 (needs f16_epi != 0)
-  int f16_deep_cfg = -1;  // deep rows (blocked accumulation): -1 / 4 = 8 waves of 64 x 64 on 256 x 128 tiles, 16 x 16 x 32 MFMA, plain loop;
+  int f16_deep_cfg = -1;  // deep rows (blocked accumulation): -1 / 5 = the persistent 256 x 256 ping-pong kernel with blocks flushed to a global
+                          // scratch where the launch fills it (>= 1024 tiles), 4 elsewhere; 4 = 8 waves of 64 x 64 on 256 x 128 tiles, 16 x 16 x 32 MFMA, plain loop;
                           // 0 = 4 waves of 64 x 64 on 128 x 128 tiles, 32 x 32 x 16 MFMA (rounds 2-3); 1, 2, 3: measured variants
                           // (sv_launch_f16_filter)
   int f16_buf = -1;       // operand DMA as buffer_load ... lds: -1 = the deep-row kernel only (measured faster there, slower in the
@@ -194,6 +195,15 @@ constexpr int SV_F16_KBLOCK = 1024;
 inline int sv_f16_kblock(const SvOptions& o, int d) {
   if (o.f16_cfg == 300) return SV_F16_KBLOCK;
   return (o.f16_cfg < 0 && d >= 4096) ? SV_F16_KBLOCK : 0;
+}
+// Deep rows, default geometry (f16_deep_cfg -1 / 5): launches that fill the persistent 256 x 256 kernel run it with blocks of
+// SV_F16_KFLUSH k-tiles of 64 flushed into a global scratch (knn_f16_filter_kernel, KFL) -- the block length the error constant
+// of a search has to cover (the smaller levels run the register-blocked kernel, whose bound is smaller).
+constexpr int SV_F16_KFLUSH = 64;
+inline int sv_f16_eps_kblock(const SvOptions& o, int d) {
+  const int kb = sv_f16_kblock(o, d);
+  if (!kb) return 0;
+  return (o.f16_deep_cfg < 0 || o.f16_deep_cfg == 5) ? SV_F16_KFLUSH * 64 : kb;
 }
 // |d2~ - d2| <= sv_f16_c_eps * ||q|| * ||r|| for the single-product fp16 filter (25 % slack included):
 //   2^-10        both operands rounded to fp16 (relative 2^-11 each; products of two fp16 are exact in fp32),
@@ -297,7 +307,7 @@ struct segvlad_ctx {
   X(s_ref_cnt) X(s_ref_id) X(s_qscale) X(s_qf16) X(s_xh1) X(s_xh2) X(s_desc) X(s_tokorder) X(s_laboff) X(s_rnsorted) X(s_ovf)     \
   X(s_fb_q) X(s_fb_d2) X(s_fb_idx) X(s_fb_rows) X(s_rd_rows) X(s_rd_q) X(s_rd_d2) X(s_rd_idx) X(s_rd_flags) X(s_rd_p1) X(s_rd_p2)  \
   X(s_sel_todo) X(s_vote_keys) X(s_pz) X(s_rowbase) X(s_tilegrp) X(s_bn) X(s_l0part) X(s_ref_lim) X(s_sh_d2) X(s_sh_idx)          \
-  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work) X(s_grp_pos) X(s_tnk_redo) X(s_tail_part) X(s_km_part) X(s_km_cnt)
+  X(s_sh_rec) X(s_sh_all) X(s_sh_d2c) X(s_sh_idc) X(s_grp_cnt) X(s_grp_ids) X(s_grp_rows) X(s_grp_keys) X(s_grp_work) X(s_grp_pos) X(s_tnk_redo) X(s_tail_part) X(s_km_part) X(s_km_cnt) X(s_kflush)
 #define SV_DECL_BUF(n) DevBuf n;
   SV_PERSISTENT_BUFS(SV_DECL_BUF)
   SV_SCRATCH_BUFS(SV_DECL_BUF)

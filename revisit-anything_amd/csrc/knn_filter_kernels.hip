@@ -499,6 +499,16 @@ __device__ __forceinline__ float acc_elem(const f32x16& v, int r) {
   return v[r];
 }
 
+// fire-and-forget fp32 add at L2 (`global_atomic_add_f32` without return: no register, no wait)
+__device__ __forceinline__ void sv_atomic_add_noret(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
+#else
+  (void)p;
+  (void)v;
+#endif
+}
+
 // POL: cache policy of the operand DMA (never changes a result): bit 0 = database rows (B) non-temporal, bit 1 = queries (A)
 // PP : 0 = every wave runs the k-tile as one segment (one barrier per k-tile); PP > 0 = "ping-pong": the k-tile is cut
 //      into PP phases of [load segment: LDS fragment reads + DMA issue][barrier][MFMA segment][barrier], and the second
@@ -531,6 +541,13 @@ typedef int sv_rsrc_t;
 #define SV_BUF_LOAD_LDS(rs, ldsptr, voff, soff, aux) ((void)(rs), (void)(ldsptr), (void)(voff), (void)(soff))
 #endif
 
+// KFL : > 0 = blocked accumulation WITHOUT a second register set (deep rows on the 256 x 256 ping-pong kernel, whose 128 accumulators
+//      per lane leave no room for one): every KFL k-tiles a wave ADDS its accumulators into its own slice of a global scratch
+//      (kscr: [workgroup][wave][128][64 lanes] fp32, all zero between tiles) with non-returning `global_atomic_add_f32` -- fire and
+//      forget: no temporary registers, no wait, the fp32 additions happen in L2, one address is only ever touched by one lane, in
+//      program order -- and clears them; behind the last k-tile the rest is added too, the totals are read back INTO the accumulator
+//      registers (system-coherent loads: the lines of the previous tile may sit in this CU's vector cache) and the slice is zeroed
+//      for the next tile.  Error: sv_f16_c_eps with kb = KFL x HBK (the L2's additions are the "block sums" of that bound).
 // BUF : the operand DMA as `buffer_load_dwordx4 ... lds` -- an SGPR resource per operand and tile, ONE never-rewritten 32-bit
 //      VGPR offset per piece, the k-offset in an SGPR -- instead of `global_load_lds_dwordx4` on a 64-bit per-lane pointer that
 //      every piece re-forms in the same VGPR pair (a write-after-read stall behind the previous piece's address read).  Needs
@@ -538,13 +555,14 @@ typedef int sv_rsrc_t;
 //      of this kernel's byte : flop ratio; the deep-row kernel 126.4 -> 125.2 ms; the ping-pong batch kernel 18.19 -> 18.70 ms
 //      (slower: its default stays global_load_lds).
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0, int SKIP = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0, int SKIP = 0, int KFL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
     const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Rh, int M, int N, int d, int b_stride, int tiles_m, int gm,
     int seq_total, int walk,
     float inv_scale, const float* __restrict__ qn, const float* __restrict__ rn, const float* __restrict__ thr,
     int64_t thr_ld, float eps_mult, float c_eps, float rn_max, uint32_t* __restrict__ cand_cnt,
-    float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap, const float* __restrict__ inv_scale_dev) {
+    float* __restrict__ cand_d2, uint32_t* __restrict__ cand_id, int cap, const float* __restrict__ inv_scale_dev,
+    float* __restrict__ kscr) {
   // single-image searches leave the query scale on the device (no host round trip in front of the pass): [0] = scale,
   // [1] = 1 / (query scale x database scale)
   if (inv_scale_dev) inv_scale = inv_scale_dev[1];
@@ -571,6 +589,13 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS DMA bases live in M0
   const int wm = w / WN, wn = w % WN;
+  // KFL: this wave's slice of the flush scratch, as a scalar (wave-uniform) base address -- formed where it is used (a few SALU
+  // instructions every 64 k-tiles) rather than kept live through the main loop
+  auto kscr_base = [&]() -> float* {
+    const unsigned long long ka = (unsigned long long)(size_t)(kscr + ((size_t)blockIdx.x * NW + (size_t)w) * (128 * 64));
+    return reinterpret_cast<float*>((size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ka >> 32)) << 32) |
+                                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ka)));
+  };
   const int64_t ldb = (int64_t)d * b_stride;
   // SKIP > 0 ("the complement of a sample"): operand row j is database row j + j / (SKIP - 1) + 1 -- the rows that are NOT multiples
   // of SKIP, in order.  The level before the last one has already filtered the multiples of SKIP (its stride-SKIP sample) with the same
@@ -904,7 +929,11 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         apf[t] = *reinterpret_cast<const f16x8*>(lds + b_off(ib) + rb * RB + swz(rb, l >> 4) * 16);
       }
     }
-    for (int kt = 0; kt < ntiles; ++kt) {
+    // (KFL: the k-tiles run in blocks of KFL; the flush sits BETWEEN two runs of the inner loop, not behind a branch inside it -- with
+    //  the branch inside, the 128 accumulators met a zeroed copy of themselves at the loop's back edge and 40 registers spilled)
+    int kt = 0;
+    for (int kstop = (KFL > 0 && KFL < ntiles) ? KFL : ntiles;;) {
+    for (; kt < kstop; ++kt) {
       const int ibn = (ib + BAHEAD >= NB) ? ib + BAHEAD - NB : ib + BAHEAD;
       const unsigned char* SA = lds + a_off(ia);
       const unsigned char* SB = lds + b_off(ib);
@@ -1058,7 +1087,44 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
         }
       }
     }
+    if (KFL == 0 || kt >= ntiles) break;
+    if constexpr (KFL > 0) {   // close a k-block into the wave's global scratch slice (see KFL)
+      static_assert(KFL == 0 || (MF == 1 && PP > 0 && KBT == 0 && PERSIST && TN16 == 8), "flushed blocks: the persistent 16 x 16 x 32 ping-pong kernel");
+      float* const kscr_w = kscr_base() + l;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN16; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sv_atomic_add_noret(kscr_w + 64 * ((mt * TN16 + nt) * 4 + r), acc16[mt][nt][r]);
+            acc16[mt][nt][r] = 0.f;
+          }
+    }
+    kstop = (kt + (KFL > 0 ? KFL : 1) < ntiles) ? kt + (KFL > 0 ? KFL : 1) : ntiles;
+    }
     if (!lag) __builtin_amdgcn_s_barrier();  // the leading half waits for the lagging half's last MFMA segment
+    if constexpr (KFL > 0) {
+      if (ntiles > KFL) {   // the last block joins the flushed ones; totals back into the accumulators; the slice is left zero
+        float* const kscr_w = kscr_base() + l;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN16; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv_atomic_add_noret(kscr_w + 64 * ((mt * TN16 + nt) * 4 + r), acc16[mt][nt][r]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN16; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)   // (agent-scope load: from L2, not from a line the previous tile left in this CU's vector cache)
+              acc16[mt][nt][r] = __hip_atomic_load(kscr_w + 64 * ((mt * TN16 + nt) * 4 + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 16 * TN16; ++j) __hip_atomic_store(kscr_w + 64 * j, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   } else if constexpr (PP < 0) {
     // One wave per SIMD (4 waves of 128 x 128: 0.5 LDS fragment reads per MFMA instead of 0.75): nothing else hides a
     // wave's LDS latency, so the loop is software-pipelined -- the fragments of k-step s+1 are read (into the other half
@@ -1693,7 +1759,7 @@ __global__ __launch_bounds__(64 * WM * WN) void knn_f16_filter_kernel(
 }
 
 template <int BM, int BN, int WM, int WN, int HBK, int NB, int ABL = 0, bool PERSIST = false, int POL = 0, int PP = 0, int KBT = 0,
-          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0, int SKIP = 0>
+          bool BIAS = false, int EPI = 0, int MF = 0, bool BUF = false, int DSPLIT = 0, int SKIP = 0, int KFL = 0>
 static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* Rh, int M, int n_sample, int d, int b_stride,
                              float inv_scale, const float* qn, const float* rn, const float* thr, int64_t thr_ld,
                              float eps_mult, float c_eps, float rn_max, uint32_t* cand_cnt, float* cand_d2, uint32_t* cand_id,
@@ -1736,22 +1802,36 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
     const size_t elds = (size_t)BM * 24 + (size_t)BN * 4 + (size_t)WM * WN * (LCAPl + 1) * 8;
     if (lds < elds) lds = elds;
   }
-  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF, BUF, DSPLIT, SKIP>;
+  auto kern = knn_f16_filter_kernel<BM, BN, WM, WN, HBK, NB, ABL, PERSIST, POL, PP, KBT, BIAS, EPI, MF, BUF, DSPLIT, SKIP, KFL>;
+  float* kscr = nullptr;
+  if (KFL > 0) {   // one slice of 128 x 64 fp32 per resident wave, all zero between tiles (the kernel leaves it so); zeroed here as well
+    const size_t bytes = (size_t)tiles * (WM * WN) * 128 * 64 * 4;
+    SV_HIP(ctx->s_kflush.reserve(bytes));
+    SV_HIP(hipMemsetAsync(ctx->s_kflush.p, 0, bytes, ctx->stream));
+    kscr = ctx->s_kflush.as<float>();
+  }
   if (lds > 64 * 1024)
     SV_HIP(sv_max_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * WM * WN), lds, ctx->stream, Qh, Rh, M, n_sample, d, b_stride, tiles_m,
                      gm, seq_total, walk, inv_scale, qn, rn, thr, thr_ld, eps_mult, c_eps, rn_max, cand_cnt, cand_d2, cand_id, cap,
-                     ctx->f16_scale_dev);
+                     ctx->f16_scale_dev, kscr);
   SV_HIP(hipGetLastError());
   return SEGVLAD_OK;
 }
 
 // Can the LAST level of a batch search run over the complement of the stride-16 sample (skip = 16)?  Only the two default batch
 // kernels have that form; the answer mirrors sv_launch_f16_filter's choice for (M, n_rows, d) under the context's options.
+// deep rows: does this launch take the persistent 256 x 256 kernel with flushed blocks (KFL)?
+static bool deep_flush_ok(const segvlad_ctx* ctx, int M, int64_t n_rows) {
+  const SvOptions& o = ctx->opt;
+  return (o.f16_deep_cfg < 0 || o.f16_deep_cfg == 5) && ctx->f16_bias_ok && o.f16_mf != 0 && o.f16_epi != 0 && M > 128 &&
+         (int64_t)((M + 255) / 256) * ((n_rows + 255) / 256) >= 1024;
+}
+
 bool sv_f16_filter_skip_ok(const segvlad_ctx* ctx, int M, int64_t n_rows, int d) {
   const SvOptions& o = ctx->opt;
   if (!o.level_carry || M <= 128 || n_rows <= 0 || !ctx->f16_bias_ok || o.f16_mf == 0 || o.f16_epi == 0) return false;
-  if (sv_f16_kblock(o, d)) return o.f16_deep_cfg < 0 || o.f16_deep_cfg == 4;
+  if (sv_f16_kblock(o, d)) return o.f16_deep_cfg < 0 || o.f16_deep_cfg == 4 || o.f16_deep_cfg == 5;
   if (o.f16_cfg >= 0 && o.f16_cfg != 250) return false;
   if (o.f16_pp == 0 || o.f16_dsplit != 0 || o.f16_buf == 1) return false;   // (the A/B variants of the batch kernel)
   return (int64_t)((M + 255) / 256) * ((n_rows + 255) / 256) >= 1024;
@@ -1767,6 +1847,8 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
     if (skip != 16 || b_stride != 1 || !sv_f16_filter_skip_ok(ctx, M, n_sample, d))
       return ctx->fail(SEGVLAD_ERR_STATE, "f16 filter: no complement-of-sample form for this configuration");
     if (sv_f16_kblock(ctx->opt, d)) {
+      if (deep_flush_ok(ctx, M, n_sample))
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 0, 16, SV_F16_KFLUSH>(SV_F16_ARGS);
       if (ctx->opt.f16_buf != 0 && (int64_t)256 * d * 2 * 2 + 4096 < (int64_t)0xffffffffLL)
         return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1, true, 0, 16>(SV_F16_ARGS);
       return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1, false, 0, 16>(SV_F16_ARGS);
@@ -1796,8 +1878,13 @@ int sv_launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_t* R
       // fallback when the norms are too unbalanced for the bias), this kernel 126 ms; the same with the ping-pong loop 165 ms
       // (1: half the MFMAs per phase of the 64 x 128 wave tiles behind the same barriers), 128 x 128 tiles with the 16 x 16 x 32
       // shape 234 ms ping-pong / 198 ms plain (2 / 3: one wave per SIMD)
+      // round 6b: launches that fill the persistent 256 x 256 ping-pong kernel (the batch kernel of the 1024-d searches) take it, with the
+      // accumulation blocked by FLUSHING: every 64 k-tiles the accumulators are added into a global scratch slice and cleared (KFL) --
+      // the second register set that kept the 256-row tiles out of reach is gone; measured 10 000 x 46 875 x 98 304: see DESIGN.md
+      if (deep_flush_ok(ctx, M, n_sample))
+        return launch_f16_filter<256, 256, 4, 2, 64, 3, 0, true, 0, 2, 0, true, 1, 1, false, 0, 0, SV_F16_KFLUSH>(SV_F16_ARGS);
       if (ctx->f16_bias_ok && ctx->opt.f16_mf != 0 && ctx->opt.f16_epi != 0 && M > 128) {
-        if (ctx->opt.f16_deep_cfg < 0 || ctx->opt.f16_deep_cfg == 4) {   // the default: 780 vs 667 TF algorithmic at 10 000 x 50 000 x 98 304
+        if (ctx->opt.f16_deep_cfg < 0 || ctx->opt.f16_deep_cfg == 4 || ctx->opt.f16_deep_cfg == 5) {   // the default: 780 vs 667 TF algorithmic at 10 000 x 50 000 x 98 304
           if (buf_ok) return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1, true>(SV_F16_ARGS);
           return launch_f16_filter<256, 128, 4, 2, 64, 3, 0, false, 0, 0, 16, true, 1, 1>(SV_F16_ARGS);
         }
