@@ -322,7 +322,6 @@ int segvlad_set_option(segvlad_ctx* ctx, const char* key, const char* value) {
   if (!strcmp(key, "small_head")) return as_int(&o.small_head);
   if (!strcmp(key, "batch_l0_f16")) return as_int(&o.batch_l0_f16);
   if (!strcmp(key, "level_carry")) return as_int(&o.level_carry);
-  if (!strcmp(key, "deep_plan")) return as_int(&o.deep_plan);
   if (!strcmp(key, "f16_persist_wgs")) return as_int(&o.f16_persist_wgs);
   if (!strcmp(key, "debug_small_tail")) return as_int(&o.debug_small_tail);
   if (!strcmp(key, "refine_group")) return as_int(&o.refine_group);
@@ -1748,16 +1747,6 @@ int segvlad_search(segvlad_ctx* ctx, const float* Q, int nq, int k, float* d2_ou
     plh.levels = 1;
     plh.stride0 = small_stride;
     plh.ratio_last = small_stride;
-  } else if (heuristic && ctx->opt.deep_plan && nq > 128 && pl.kind == 1 && sv_f16_kblock(ctx->opt, d) && n / 64 >= 192) {
-    // deep rows, batches (round 6b): ONE filter level behind the sparsest sample of >= 192 rows with a stride <= 512.  A sampled
-    // filter level of such rows runs on a few hundred tiles that do not fill the chip (10 000 x 3125 x 98 304: 10.3 ms at the
-    // stride-16 level for 1/16 of the rows, 1.7 x the full level's time per row), while the price of the looser threshold -- longer
-    // candidate lists -- is nothing against tiles of 3 ms each
-    int ds = 64;
-    while (ds < 512 && n / (2 * ds) >= 192) ds *= 2;
-    plh.levels = 1;
-    plh.stride0 = ds;
-    plh.ratio_last = ds;
   } else if (heuristic) {
     while (plh.levels < 6 && n / (plh.stride0 * SV_RATIO) >= 192) {
       plh.stride0 *= SV_RATIO;

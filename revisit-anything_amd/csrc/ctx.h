@@ -172,10 +172,6 @@ struct SvOptions {
   int level_carry = 1;    // batch searches, guessed thresholds, fp16 filter: the last level runs over the rows the stride-16 level has not
                           // seen and that level's survivors stay in the candidate lists (1/16 of the full-level GEMM saved); 0 = every
                           // level starts from empty lists and the last one covers every row (rounds 2-6a)
-  int deep_plan = 0;      // 1: batch searches over deep rows (d >= 4096), guessed thresholds: one filter level behind a sample of >= 192 rows at
-                          // a stride <= 512 (no sampled filter level on a grid that cannot fill the chip).  Measured at 10 000 x 50 000 x 98 304:
-                          // 125.5 -> 123.2 ms per step (+1.9 %), but 3927 candidates per query instead of 1423 and the longest list at
-                          // 7266 of the 8192 slots -- one clump of duplicates away from the exact fall-back: not the default
   int small_head = 1;     // single-image passes start with small_head_kernel (plane + scale + norms + flags + sample thresholds in one
                           // launch); 0 = query preparation -> exact sample level -> reduce + rank (rounds 3-5)
   int small_tail = 1;     // single-image passes end in small_tail_kernel (no read-back); 0 = the read-back of rounds 3-5

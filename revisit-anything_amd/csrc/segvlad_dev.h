@@ -32,8 +32,6 @@
  *     "x3_tile", "x3_gm", "agg_kpb", "assign_narrow"   tile / order / geometry of the projection GEMM, the descriptor
  *                     aggregation and the assignment kernel
  *     "f16_persist_wgs" 1..32 resident workgroups per XCD of the persistent batch filter (32 = every CU; fewer leave CUs to other streams)
- *     "deep_plan"     0 | 1   batch searches over deep rows: the 16^j strides of the 1024-d plan | one filter level behind a sparse sample
- *                             (+1.9 % on config2, candidate lists at 89 % of their capacity: measured, not the default)
  *     "level_carry"   1 | 0   batch searches (guessed thresholds): the last filter level skips the rows of the stride-16 level, whose
  *                             survivors stay in the candidate lists | every level from empty lists over all of its rows
  *     "batch_l0_f16"  1 | 0   batch searches (guessed thresholds): the sampled level from the filter's own fp16 product | the exact fp32 GEMM
