@@ -1777,7 +1777,11 @@ static int launch_f16_filter(segvlad_ctx* ctx, const uint16_t* Qh, const uint16_
   // default 3: measured on 10 000 x 1 M x 1024 (rocprofv3 FETCH_SIZE, calibrated; tools/pmc_walk.sh): L2 fills of the full-level
   // launch 42.7 GB (walk 0) / 45.1 GB (2: serpentine alone) / 26.3 GB (3), at the same speed (18.39 / 18.34 ms per search's filter
   // launches, interleaved A/B)
-  int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 7) : 3) : 0;
+  // deep rows (KFL): serpentine k alone.  Measured 10 000 x 46 875 x 98 304 (config2's filter launches per step, tools/walk_sweep_cfg2.sh):
+  // walk 2 -> 93.6 ms, 0 -> 94.4-94.9, 3 -> 100.9-101.7, 1 -> 103.6, 4 -> 102.9, 5 / 6 / 7 -> 110.9 / 111.6 / 116.6; L2 fills 260-290 GB per
+  // launch either way (a query block is 8 x 50 MB there: "resident" means nothing at that depth, and the resident order makes the 32
+  // workgroups of an XCD meet a NEW database block at every step)
+  int walk = PERSIST ? (ctx->opt.f16_walk >= 0 ? (ctx->opt.f16_walk & 7) : (KFL > 0 ? 2 : 3)) : 0;
   const int pwgs = (ctx->opt.f16_persist_wgs >= 1 && ctx->opt.f16_persist_wgs <= 32) ? ctx->opt.f16_persist_wgs : 32;
   if (PERSIST) walk |= pwgs << 8;
   if (gm > 0) {
