@@ -193,6 +193,7 @@ def parse():
                    "(segvlad_search_sharded / segvlad_allgather_rows) instead of torch.distributed collectives")
     p.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="segvlad_set_option switches of the search context "
                    "(tuning A/B: e.g. --set batch_plan=1); recorded in the line")
+    p.add_argument("--shard-sim-only", action="store_true", help="of the sub-records, only `shard_sim` (tuning sweeps of the per-rank step)")
     p.add_argument("--no-ubench", action="store_true", help="skip the live MFMA ceiling micro-benchmark (tools/ubench/mfma_peak) and the "
                    "same-shape plain-GEMM yardstick (tools/yardstick_gemm.py)")
     p.add_argument("--dry-run-collectives", action="store_true", help="no benchmark: the multi-GPU exchange checked WITHOUT the other ranks "
@@ -315,7 +316,7 @@ def run(a, top=True):
     # i+1 is described (HBM side) under the search of batch i (matrix pipe side); `eng` keeps the index
     eng_d, pipe_d, s_desc = eng, pipe, None
     # (also created for the "pipelined" sub-measurement of the default N=1 line, which times both modes on one index)
-    also_pipelined = top and world == 1 and not a.pipeline and not a.no_sub_records and not a.sweep_own
+    also_pipelined = top and world == 1 and not a.pipeline and not a.no_sub_records and not a.sweep_own and not a.shard_sim_only
     if a.pipeline or also_pipelined:
         eng_d = SegVLADEngine(local)
         if pca_path:
@@ -492,7 +493,7 @@ def run(a, top=True):
                              "CUs, and both draw on the same power budget"}
     sstats = eng.search_stats()   # (of the timed run's last search: before any sub-measurement searches again)
     fp32_rec = None
-    if top and world == 1 and not a.no_sub_records and not a.sweep_own and FILTER_KIND != "fp32":
+    if top and world == 1 and not a.no_sub_records and not a.sweep_own and FILTER_KIND != "fp32" and not a.shard_sim_only:
         # The SAME workload with the same-arithmetic filter (option knn_filter=fp32: fp32 MFMA distances in every level, no
         # 16-bit product anywhere): what the line's fp16 pruning buys, and the evidence that it changes nothing -- the
         # searches' (d2, idx) must be BIT-identical and the predictions identical.
@@ -908,7 +909,7 @@ def main():
     if res is None:
         return
     world = res["n_gpus"]
-    if world == 1 and not a.no_sub_records and not a.no_pca and a.group == 4 and not a.sweep_own:
+    if world == 1 and not a.no_sub_records and not a.no_pca and a.group == 4 and not a.sweep_own and not a.shard_sim_only:
         # BASELINE configs[1] in its literal form (place_rec_main.py:49-60 with pca off): 1000 reference images x 50
         # segments of raw K*D = 98 304-d descriptors, 200 query images, search 200 -- the deep-row fp16 filter with
         # blocked accumulation + the coalesced exact refinement; which filter ran and the list occupancies are in search_stats
